@@ -1,0 +1,322 @@
+"""Golden-vector generator -- runs ONLY in the build container (needs /root/reference).
+
+Imports the reference Python modules from /root/reference with the shim recipe of
+SURVEY.md Appendix B (stub torchvision/h5py/quaternion, no-op .cuda()), runs them
+on deterministic inputs and writes small .npz fixtures to tests/golden/.  The
+fixtures hold DATA only (inputs, expected outputs); no reference source travels.
+
+    python -m oracle.gen_golden            # from the repo root
+
+While generating, every fixture is also checked against this repo's own CPU
+restatement (oracle/*.py, oracle/dcf_oracle.c) so a mismatch stops the build of
+the fixtures rather than surfacing later on the GPU box.
+"""
+import builtins
+import copy
+import importlib
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+detfill = importlib.import_module("deep_continuous_fusion_for_multi-sensor_3d_object_detection_amd.detfill")
+from oracle import geometry_ref, loss_ref, model_ref  # noqa: E402
+
+
+def _stub(name, **kw):
+    m = types.ModuleType(name)
+    m.__dict__.update(kw)
+    sys.modules[name] = m
+    return m
+
+
+def euler_zyz_rotation(v):
+    """Restated ZYZ euler -> unit quaternion -> rotation matrix (what
+    data_import_carla.py:185-186 asks of the absent numpy-quaternion package;
+    version unpinned upstream => R itself is 'parity unpinned' and is an INPUT
+    of every fixture)."""
+    a, b, g = v
+    q = np.array([np.cos(b / 2) * np.cos((a + g) / 2), -np.sin(b / 2) * np.sin((a - g) / 2),
+                  np.sin(b / 2) * np.cos((a - g) / 2), np.cos(b / 2) * np.sin((a + g) / 2)])
+    w, x, y, z = q / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def import_reference():
+    _stub("torchvision")
+    _stub("torchvision.models")
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    _stub("torchvision.utils", save_image=lambda *a, **k: None)
+    _stub("h5py")
+    _stub("quaternion", from_euler_angles=lambda v: np.asarray(v, dtype=np.float64),
+          as_rotation_matrix=euler_zyz_rotation)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+    mods = {n: importlib.import_module(n) for n in ("model", "loss", "data_import_carla")}
+    import IOU
+    IOU.min, IOU.max = builtins.min, builtins.max
+    return mods
+
+
+def carla_cfg():
+    cfg = yaml.safe_load(open(os.path.join(REF, "config", "config_carla.yaml")))
+    d = tempfile.mkdtemp()
+    cfg["train_data_dir"] = d
+    cfg["test_data_dir"] = d
+    return cfg
+
+
+def tiny_cfg():
+    """Small config the HIP kernels also accept (channel counts multiples of 32)."""
+    cfg = carla_cfg()
+    cfg.update(dict(voxel_length=64, voxel_width=32, voxel_channel=32,
+                    lidar_x_min=0.0, lidar_x_max=16.0, lidar_y_min=-4.0, lidar_y_max=4.0,
+                    image_height=240, image_width=320, max_num_pc=4096))
+    cfg["lidar_module"] = dict(out_feature1=32, out_feature2=64, out_feature3=96, out_feature4=128, out_feature5=160,
+                               num_res_block1=1, num_res_block2=1, num_res_block3=2, num_res_block4=1, num_res_block5=1)
+    return cfg
+
+
+def sparse_pack(grid):
+    flat = grid.reshape(-1)
+    nz = np.flatnonzero(flat)
+    return nz.astype(np.int32), flat[nz].astype(np.float32)
+
+
+def voxel_like_input(shape, tag):
+    u = detfill.uniform(shape, tag, 0.0, 1.0)
+    m = detfill.uniform(shape, tag + 17, 0.0, 1.0) < 0.12
+    return (u * m).astype(np.float32)
+
+
+# ------------------------------------------------------------------ generators
+def gen_geometry(mods):
+    cfg = carla_cfg()
+    cfg["max_num_pc"] = 20000
+    ds = mods["data_import_carla"].CarlaDataset(cfg)
+    crt = ds.CRT_tensor.numpy().copy()
+    lim6 = (cfg["lidar_x_min"], cfg["lidar_x_max"], cfg["lidar_y_min"], cfg["lidar_y_max"],
+            cfg["lidar_z_min"], cfg["lidar_z_max"])
+    cases = {}
+    # two in-range points (n_in == 1 would hit torch's divide-by-scalar fast path, which
+    # multiplies by the reciprocal and is 1 ulp off IEEE division: DESIGN.md "known deviations")
+    cases["two"] = np.array([[10.3, 1.7, -1.05], [42.77, -12.6, 0.31]], dtype=np.float32)
+    # five points in one voxel (F3: last writer wins) + one outside the range
+    cases["five"] = np.array([[20.02, 3.03, -1.01], [20.05, 3.07, -1.03], [20.11, 3.11, -1.04],
+                              [20.15, 3.02, -1.06], [20.08, 3.20, -1.02], [90.0, 0.5, -1.0]], dtype=np.float32)
+    cases["n1k"] = detfill.synthetic_points(1000, lim6, seed=1)
+    cases["n10k"] = detfill.synthetic_points(10000, lim6, seed=2)
+    out = {"crt": crt, "cfg_yaml": np.array(yaml.safe_dump({k: v for k, v in cfg.items() if "dir" not in k}))}
+    torch.use_deterministic_algorithms(True)
+    for name, pts in cases.items():
+        vox, pcr, uv, n, ids = ds.Voxelization_Projection(torch.from_numpy(pts.copy()))
+        vox = vox.numpy()
+        # --- check the C restatement bit-exactly, here and now
+        g, pc2, uv2, n2, ids2 = geometry_ref.voxelization_projection(pts, cfg, crt)
+        assert n2 == n, (name, n, n2)
+        assert np.array_equal(g.view(np.uint32), vox.view(np.uint32)), name + ": voxel grid differs"
+        assert np.array_equal(pc2.view(np.uint32), pcr.numpy().view(np.uint32)), name
+        assert np.array_equal(uv2.view(np.uint32), uv.numpy().view(np.uint32)), name
+        assert np.array_equal(ids2, ids.numpy()), name
+        nz, val = sparse_pack(vox)
+        out[name + "_pts"] = pts
+        out[name + "_vox_idx"] = nz
+        out[name + "_vox_val"] = val
+        out[name + "_ids"] = ids.numpy().astype(np.int16)
+        out[name + "_uv"] = uv.numpy()[:n]
+        out[name + "_xyz"] = pcr.numpy()[:n]
+        out[name + "_n"] = np.int32(n)
+        print("geometry", name, "n_in", ids.shape[1], "n_valid", n, "nnz", nz.size)
+    torch.use_deterministic_algorithms(False)
+    np.savez_compressed(os.path.join(OUT, "geometry_carla.npz"), **out)
+    return cfg, crt, cases
+
+
+def lin_functional(shape, tag):
+    return torch.from_numpy(detfill.uniform(shape, tag, -1.0, 1.0))
+
+
+def gen_model_tiny(mods):
+    cfg = tiny_cfg()
+    net = mods["model"].ObjectDetection_DCF(cfg)
+    detfill.fill_state_dict(net)
+    x = torch.from_numpy(voxel_like_input((2, 32, 64, 32), 4242))
+    img = torch.zeros(2, 3, 8, 8, dtype=torch.uint8)
+    out = {"cfg_yaml": np.array(yaml.safe_dump({k: v for k, v in cfg.items() if "dir" not in k}))}
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    # shapes table must agree with the reference's own state_dict
+    shp = model_ref.lidar_state_shapes(cfg)
+    assert list(shp.keys()) == list(sd.keys()), "state_dict key order/name mismatch"
+    assert all(tuple(sd[k].shape) == tuple(shp[k]) for k in shp)
+    for mode in ("eval", "train"):
+        net.train(mode == "train")
+        net.load_state_dict(sd)
+        with torch.no_grad():
+            pred = net(x, img)
+        mine, stages = model_ref.forward(sd, cfg, x, bn_mode=mode, return_stages=True)
+        err = (mine - pred).abs().max().item()
+        print("model tiny", mode, "pred absmax", pred.abs().max().item(), "restatement err", err)
+        assert err < 1e-4 * max(1.0, pred.abs().max().item())
+        out["pred_" + mode] = pred.numpy()
+        for k in ("layer2", "layer5", "fpn"):
+            out["stage_%s_%s" % (k, mode)] = stages[k].numpy()
+    # backward, B=1, eval-BN (what train.py trains with) and train-BN
+    R = lin_functional((1, 32, 16, 8), 777)
+    pick = ["lidar_backbone.backbone.layer1.sequential.resblock_0.conv1.weight",
+            "lidar_backbone.backbone.layer1.sequential.resblock_0.bn1.weight",
+            "lidar_backbone.backbone.layer1.sequential.resblock_0.bn1.bias",
+            "lidar_backbone.backbone.layer2.sequential.resblock_0.down_conv.weight",
+            "lidar_backbone.backbone.layer2.sequential.resblock_0.down_bn.weight",
+            "lidar_backbone.backbone.layer3.sequential.resblock_1.conv2.weight",
+            "lidar_backbone.backbone.layer5.sequential.resblock_0.bn2.bias",
+            "lidar_backbone.latconv1.weight", "lidar_backbone.downconv1.weight",
+            "lidar_backbone.latconv2.weight", "lidar_backbone.conv3.weight",
+            "lidar_backbone.classconv.weight", "lidar_backbone.bbox3dconv.weight"]
+    for mode in ("eval", "train"):
+        net.load_state_dict(sd)
+        net.train(mode == "train")
+        net.zero_grad()
+        xi = x[:1].clone().requires_grad_(True)
+        pred = net(xi, img[:1])
+        (pred * R).sum().backward()
+        out["gin_" + mode] = xi.grad.numpy()
+        named = dict(net.named_parameters())
+        for k in pick:
+            out["g_%s_%s" % (mode, k)] = named[k].grad.numpy().copy()
+        # all-parameter gradient checksum: sum|g| per parameter, in state order
+        out["gabs_" + mode] = np.array([named[k].grad.abs().sum().item() for k in named], dtype=np.float64)
+        print("model tiny bwd", mode, "gin absmax", xi.grad.abs().max().item())
+    out["grad_keys"] = np.array(pick)
+    np.savez_compressed(os.path.join(OUT, "model_tiny.npz"), **out)
+    return cfg, sd
+
+
+def gen_anchors_decode(mods):
+    cfg = carla_cfg()
+    anc = mods["model"].AnchorBoundingBoxFeature(cfg)().numpy()
+    mine = model_ref.anchors(cfg).numpy()
+    assert np.array_equal(anc.view(np.uint32), mine.view(np.uint32)), "anchor restatement not bit-exact"
+    tc = tiny_cfg()
+    dec = mods["model"].OffsettoBbox(tc)
+    reg = torch.from_numpy(detfill.uniform((2, 14, 16, 8), 991, -1.5, 1.5))
+    box = dec(reg).numpy()
+    mine = model_ref.decode(reg, model_ref.anchors(tc)).numpy()
+    assert np.allclose(box, mine, rtol=0, atol=0), "decode restatement differs"
+    np.savez_compressed(os.path.join(OUT, "anchors_decode.npz"), anchors_carla=anc, reg=reg.numpy(), box=box,
+                        anchors_tiny=model_ref.anchors(tc).numpy())
+    print("anchors", anc.shape, "decode ok")
+
+
+def tiny_boxes():
+    b = torch.zeros(2, 20, 9)
+    rows = [[3.3, -1.2, -1.0, 4.2, 1.9, 1.6, 0.4, 6, 1], [9.7, 2.1, -0.9, 3.8, 1.7, 1.5, 1.9, 6, 1],
+            [14.9, -3.6, -1.1, 4.5, 2.0, 1.7, 2.8, 6, 1]]
+    b[0, :3] = torch.tensor(rows)
+    b[1, :2] = torch.tensor([[6.1, 0.3, -1.0, 4.0, 1.8, 1.5, 0.1, 6, 1], [12.4, 3.3, -0.8, 4.4, 2.1, 1.6, 1.2, 6, 1]])
+    return b, torch.tensor([3, 2])
+
+
+def gen_loss(mods):
+    cfg = tiny_cfg()
+    L = mods["loss"].LossTotal(cfg)
+    bboxes, nb = tiny_boxes()
+    logits = torch.from_numpy(detfill.uniform((2, 4, 16, 8), 555, -2.0, 2.0))
+    cls0 = torch.cat((torch.softmax(logits[:, :2], 1), torch.softmax(logits[:, 2:], 1)), 1)
+    reg0 = torch.from_numpy(detfill.uniform((2, 14, 16, 8), 556, -0.5, 0.5))
+    out = {"bboxes": bboxes.numpy(), "nbox": nb.numpy(), "cls": cls0.numpy(), "reg": reg0.numpy()}
+    anc = model_ref.anchors(cfg)
+    for seed in (0, 1):
+        cls = cls0.clone().requires_grad_(True)
+        reg = reg0.clone().requires_grad_(True)
+        np.random.seed(seed)
+        val = L(bboxes, nb, cls, reg)
+        val.backward()
+        cls2 = cls0.clone().requires_grad_(True)
+        reg2 = reg0.clone().requires_grad_(True)
+        np.random.seed(seed)
+        mine = loss_ref.loss_total(cfg, bboxes, nb, cls2, reg2, anc)
+        mine.backward()
+        assert abs(mine.item() - val.item()) < 1e-6, (mine.item(), val.item())
+        assert torch.allclose(cls.grad, cls2.grad, atol=1e-7) and torch.allclose(reg.grad, reg2.grad, atol=1e-7)
+        out["loss_seed%d" % seed] = np.float32(val.item())
+        out["gcls_seed%d" % seed] = cls.grad.numpy()
+        out["greg_seed%d" % seed] = reg.grad.numpy()
+        print("loss seed", seed, val.item(), "sample-0 grad == 0:", float(cls.grad[0].abs().max()) == 0.0)
+    np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
+
+
+def gen_adam(mods, cfg, sd):
+    """3 train steps, B=1, eval-mode BN (test.py:37 puts the trained module in eval: F4),
+    Adam lr/betas from the config (train.py:26-28), np.random.seed(100+step) before each loss."""
+    net = mods["model"].ObjectDetection_DCF(cfg)
+    net.load_state_dict(sd)
+    net.eval()
+    L = mods["loss"].LossTotal(cfg)
+    opt = torch.optim.Adam(net.parameters(), lr=cfg["learning_rate"], betas=(cfg["beta1"], 0.999))
+    bboxes, nb = tiny_boxes()
+    x = torch.from_numpy(voxel_like_input((2, 32, 64, 32), 4242))[:1]
+    img = torch.zeros(1, 3, 8, 8, dtype=torch.uint8)
+    losses = []
+    for step in range(3):
+        pred = net(x, img)
+        cls, reg, _ = torch.split(pred, [4, 14, 14], dim=1)
+        np.random.seed(100 + step)
+        val = L(bboxes[:1], nb[:1], cls, reg)
+        opt.zero_grad()
+        val.backward()
+        opt.step()
+        losses.append(val.item())
+    w = dict(net.named_parameters())["lidar_backbone.conv3.weight"].detach().numpy()
+    print("adam trajectory", losses)
+    np.savez_compressed(os.path.join(OUT, "adam_traj.npz"), losses=np.array(losses, dtype=np.float64),
+                        conv3_after=w[:4, :4].copy())
+
+
+def gen_full_carla(mods, cfg, crt, cases):
+    """cfg1 of BASELINE.json: G-carla frame (10k pts) through the reference model on CPU, B=1, eval-BN."""
+    cfg = copy.deepcopy(cfg)
+    net = mods["model"].ObjectDetection_DCF(cfg)
+    detfill.fill_state_dict(net)
+    net.eval()
+    grid, _, _, _, _ = geometry_ref.voxelization_projection(cases["n10k"], cfg, crt)
+    x = torch.from_numpy(grid).unsqueeze(0)
+    with torch.no_grad():
+        pred = net(x, torch.zeros(1, 3, 8, 8, dtype=torch.uint8))
+    sd = {k: v for k, v in net.state_dict().items()}
+    mine = model_ref.forward(sd, cfg, x, bn_mode="eval")
+    print("full carla pred absmax", pred.abs().max().item(), "restatement err", (mine - pred).abs().max().item())
+    p = pred.numpy()[0]
+    hh = detfill.uniform((64,), 31337, 0, p.shape[1]).astype(np.int64)
+    ww = detfill.uniform((64,), 31338, 0, p.shape[2]).astype(np.int64)
+    np.savez_compressed(os.path.join(OUT, "model_carla_full.npz"), sample_h=hh, sample_w=ww,
+                        sample_pred=p[:, hh, ww].copy(), chan_sum=p.astype(np.float64).sum((1, 2)),
+                        chan_abs=np.abs(p).astype(np.float64).sum((1, 2)))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    geometry_ref.build()
+    mods = import_reference()
+    torch.manual_seed(0)
+    cfg, crt, cases = gen_geometry(mods)
+    gen_anchors_decode(mods)
+    tcfg, sd = gen_model_tiny(mods)
+    gen_loss(mods)
+    gen_adam(mods, tcfg, sd)
+    gen_full_carla(mods, cfg, crt, cases)
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

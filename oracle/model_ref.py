@@ -1,0 +1,311 @@
+"""TEST INFRASTRUCTURE -- torch-CPU fp32 restatement of the model hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product package never does.
+
+Functional, state-dict driven restatement (no nn.Module tree), fp32 on CPU:
+
+  lidar stream  -- PINNED: checked against the imported reference in
+                   tests/golden/model_*.npz (oracle/gen_golden.py):
+                   ResidualBlock        model.py:10-45
+                   ResnetCustomed       model.py:64-79
+                   FPN + heads          model.py:140-173
+                   anchors              model.py:82-113
+                   box decode           model.py:116-137
+                   output concat        model.py:194-204
+  image stream, KNN gather, fusion MLP -- the reference has none
+                   (model.py:192,199-203 TODO): "parity unpinned"; this file is
+                   the literal statement of SURVEY.md Appendix D and the HIP
+                   path is checked against it.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import geometry_ref
+
+STAGES = ("layer1", "layer2", "layer3", "layer4", "layer5")
+
+
+# --------------------------------------------------------------------------- BN
+def _bn(sd, pfx, x, bn_mode):
+    """BatchNorm2d eps=1e-5 (model.py:20).  bn_mode 'eval' uses running stats
+    (what train.py really trains with); 'train' uses batch stats."""
+    w, b = sd[pfx + ".weight"], sd[pfx + ".bias"]
+    if bn_mode == "eval":
+        return F.batch_norm(x, sd[pfx + ".running_mean"], sd[pfx + ".running_var"], w, b, False, 0.1, 1e-5)
+    return F.batch_norm(x, None, None, w, b, True, 0.1, 1e-5)
+
+
+def _resblock(sd, pfx, x, bn_mode):
+    """model.py:32-41.  Stride 2 + 1x1 shortcut iff channel count changes (:14-19,:26-30)."""
+    w1 = sd[pfx + ".conv1.weight"]
+    change = w1.shape[0] != w1.shape[1]
+    s = 2 if change else 1
+    if change:
+        r = _bn(sd, pfx + ".down_bn", F.conv2d(x, sd[pfx + ".down_conv.weight"], None, 2), bn_mode)
+    else:
+        r = x
+    y = F.relu(_bn(sd, pfx + ".bn1", F.conv2d(x, w1, None, s, 1), bn_mode))
+    y = _bn(sd, pfx + ".bn2", F.conv2d(y, sd[pfx + ".conv2.weight"], None, 1, 1), bn_mode)
+    return F.relu(y + r)
+
+
+def _stage(sd, pfx, x, bn_mode):
+    i = 0
+    while (pfx + ".sequential.resblock_%d.conv1.weight" % i) in sd:
+        x = _resblock(sd, pfx + ".sequential.resblock_%d" % i, x, bn_mode)
+        i += 1
+    return x
+
+
+# ---------------------------------------------------------------------- anchors
+def anchors(cfg):
+    """model.py:93-113.  [14,h,w]; linspace endpoints inclusive; z=-4.5; yaw2=3.1415926/2."""
+    a = cfg["anchor_bbox_feature"]
+    h = int(cfg["voxel_length"] / a["reduced_scale"])
+    w = int(cfg["voxel_width"] / a["reduced_scale"])
+    ax = torch.linspace(cfg["lidar_x_min"], cfg["lidar_x_max"], h).view(h, 1).expand(h, w)
+    ay = torch.linspace(cfg["lidar_y_min"], cfg["lidar_y_max"], w).view(1, w).expand(h, w)
+    one = torch.ones(h, w)
+    base = [ax, ay, one * (-4.5), one * a["length"], one * a["width"], one * a["height"]]
+    return torch.stack(base + [one * 0] + base + [one * 3.1415926 / 2], 0).contiguous()
+
+
+def decode(reg, anc):
+    """model.py:126-136.  reg [B,14,h,w], anc [14,h,w] -> boxes [B,14,h,w]."""
+    out = []
+    for a in range(2):
+        r = reg[:, 7 * a:7 * a + 7]
+        q = anc[7 * a:7 * a + 7].unsqueeze(0)
+        diag = torch.sqrt(torch.pow(q[:, 3:4], 2) + torch.pow(q[:, 4:5], 2))
+        out.append(r[:, 0:2] * diag + q[:, 0:2])
+        out.append(r[:, 2:3] * q[:, 5:6] + q[:, 2:3])
+        out.append(torch.exp(r[:, 3:6]) * q[:, 3:6])
+        t = r[:, 6:7] + q[:, 6:7]
+        out.append(torch.atan2(torch.sin(t), torch.cos(t)))
+    return torch.cat(out, 1)
+
+
+# ------------------------------------------------------------------ image stream
+def image_stream(sd, img_u8, bn_mode="eval", pfx="image_backbone", fpn="image_fpn"):
+    """App. D image stream: ResNet-18 trunk (torchvision key names) + FPN to stride 4.
+
+    img_u8 [B,3,H,W] uint8 -> F [B,C_f,H/4,W/4] (sizes follow the conv arithmetic).
+    """
+    x = img_u8.to(torch.float32) / 255.0
+    x = F.relu(_bn(sd, pfx + ".bn1", F.conv2d(x, sd[pfx + ".conv1.weight"], None, 2, 3), bn_mode))
+    x = F.max_pool2d(x, 3, 2, 1)
+    feats = []
+    for li in range(1, 5):
+        bi = 0
+        while ("%s.layer%d.%d.conv1.weight" % (pfx, li, bi)) in sd:
+            p = "%s.layer%d.%d" % (pfx, li, bi)
+            s = 2 if (p + ".downsample.0.weight") in sd and li > 1 else 1
+            if (p + ".downsample.0.weight") in sd:
+                r = _bn(sd, p + ".downsample.1", F.conv2d(x, sd[p + ".downsample.0.weight"], None, s), bn_mode)
+            else:
+                r = x
+            y = F.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"], None, s, 1), bn_mode))
+            y = _bn(sd, p + ".bn2", F.conv2d(y, sd[p + ".conv2.weight"], None, 1, 1), bn_mode)
+            x = F.relu(y + r)
+            bi += 1
+        feats.append(x)
+    c2, c3, c4, c5 = feats
+    p5 = F.conv2d(c5, sd[fpn + ".lat4.weight"])
+    p4 = F.conv2d(c4, sd[fpn + ".lat3.weight"]) + F.interpolate(p5, size=c4.shape[-2:], mode="bilinear", align_corners=False)
+    p3 = F.conv2d(c3, sd[fpn + ".lat2.weight"]) + F.interpolate(p4, size=c3.shape[-2:], mode="bilinear", align_corners=False)
+    p2 = F.conv2d(c2, sd[fpn + ".lat1.weight"]) + F.interpolate(p3, size=c2.shape[-2:], mode="bilinear", align_corners=False)
+    return F.conv2d(p2, sd[fpn + ".smooth.weight"], None, 1, 1)
+
+
+# ------------------------------------------------------------------------ fusion
+def bilinear_sample(Fmap, uv):
+    """App. D gather.  Fmap [C,Hf,Wf]; uv [n,2] image-pixel (u horizontal, v vertical).
+
+    Index-space position ix = u/4 - 0.5, iy = v/4 - 0.5 (align_corners=False
+    convention on the stride-4 map); the two taps per axis are clamped to the
+    border; fp32 weights.  Returns [n,C].
+    """
+    C, Hf, Wf = Fmap.shape
+    ix = uv[:, 0] * 0.25 - 0.5
+    iy = uv[:, 1] * 0.25 - 0.5
+    x0f, y0f = torch.floor(ix), torch.floor(iy)
+    wx, wy = ix - x0f, iy - y0f
+    x0, y0 = x0f.long(), y0f.long()
+    x1, y1 = x0 + 1, y0 + 1
+    x0, x1 = x0.clamp(0, Wf - 1), x1.clamp(0, Wf - 1)
+    y0, y1 = y0.clamp(0, Hf - 1), y1.clamp(0, Hf - 1)
+    f = Fmap.permute(1, 2, 0)
+    w00 = ((1 - wy) * (1 - wx)).unsqueeze(1)
+    w01 = ((1 - wy) * wx).unsqueeze(1)
+    w10 = (wy * (1 - wx)).unsqueeze(1)
+    w11 = (wy * wx).unsqueeze(1)
+    return f[y0, x0] * w00 + f[y0, x1] * w01 + f[y1, x0] * w10 + f[y1, x1] * w11
+
+
+def fusion_site(sd, pfx, x, Fmap, xyz, uv, n, stride, aff, K, rmax=None, knn_idx=None):
+    """App. D: x_s <- x_s + sum_k MLP([F(u_k,v_k); dx, dy, z_k]) for one sample.
+
+    x [C_b,h,w]; Fmap [C_f,Hf,Wf]; xyz [>=n,3]; uv [>=n,2]; first n rows valid.
+    Returns (x_fused, knn_idx [K,h,w] int32).
+    """
+    Cb, h, w = x.shape
+    if knn_idx is None:
+        knn_idx = torch.from_numpy(geometry_ref.knn_bev(xyz[:n].numpy(), K, h, w, stride, aff, rmax))
+    idx = knn_idx.long()
+    valid = idx >= 0
+    safe = idx.clamp(min=0)
+    fp = bilinear_sample(Fmap, uv[:max(n, 1)]) if n > 0 else torch.zeros(1, Fmap.shape[0])
+    xs, xo, ys, yo = float(aff[0]), float(aff[1]), float(aff[2]), float(aff[3])
+    X = ((torch.arange(h, dtype=torch.float32) + 0.5) * float(stride) - xo) / xs
+    Y = ((torch.arange(w, dtype=torch.float32) + 0.5) * float(stride) - yo) / ys
+    pts = xyz[:max(n, 1)]
+    if n == 0:
+        pts = torch.zeros(1, 3)
+    feat = fp[safe]                                     # [K,h,w,Cf]
+    dx = pts[safe][..., 0] - X.view(1, h, 1)
+    dy = pts[safe][..., 1] - Y.view(1, 1, w)
+    dz = pts[safe][..., 2]
+    inp = torch.cat((feat, dx.unsqueeze(-1), dy.unsqueeze(-1), dz.unsqueeze(-1)), -1)
+    hid = F.relu(F.linear(inp, sd[pfx + ".fc1.weight"], sd[pfx + ".fc1.bias"]))
+    out = F.linear(hid, sd[pfx + ".fc2.weight"], sd[pfx + ".fc2.bias"])
+    out = (out * valid.unsqueeze(-1).to(out.dtype)).sum(0)   # [h,w,Cb]
+    return x + out.permute(2, 0, 1), knn_idx
+
+
+# ----------------------------------------------------------------- whole forward
+def forward(sd, cfg, x_lidar, x_image=None, points=None, uv=None, n_valid=None, bn_mode="eval",
+            fusion=None, return_stages=False):
+    """model.py:194-204 (+ App. D when `fusion` is a dict(K=..., rmax=..., aff=...)).
+
+    sd: state_dict with the reference's key names (optionally 'module.'-stripped).
+    Returns pred [B,32,h,w] = cat(cls[4], reg[14], bbox[14]) (and stage outputs).
+    """
+    pre = "lidar_backbone."
+    bb = pre + "backbone."
+    B = x_lidar.shape[0]
+    fmap = None
+    if fusion is not None:
+        fmap = image_stream(sd, x_image, bn_mode)
+    x = _stage(sd, bb + "layer1", x_lidar, bn_mode)
+    outs = []
+    stages = {}
+    stride = 1
+    for si, name in enumerate(STAGES[1:], 1):
+        x = _stage(sd, bb + name, x, bn_mode)
+        stride *= 2
+        if fusion is not None:
+            fused = []
+            for b in range(B):
+                nb = int(n_valid[b])
+                xb, _ = fusion_site(sd, "fusion.site%d" % si, x[b], fmap[b], points[b], uv[b], nb,
+                                    stride, fusion["aff"], fusion["K"], fusion.get("rmax"))
+                fused.append(xb)
+            x = torch.stack(fused, 0)
+        stages[name] = x
+        outs.append(x)
+    x1, x2, x3, x4 = outs
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=True)  # model.py:149
+    t3 = F.conv2d(x3, sd[pre + "latconv1.weight"]) + up(F.conv2d(x4, sd[pre + "downconv1.weight"]))
+    t2 = F.conv2d(x2, sd[pre + "latconv2.weight"]) + up(t3)
+    xp = F.conv2d(t2, sd[pre + "conv3.weight"], None, 1, 1)
+    cls = F.conv2d(xp, sd[pre + "classconv.weight"])
+    cls = torch.cat((F.softmax(cls[:, 0:2], 1), F.softmax(cls[:, 2:4], 1)), 1)
+    reg = F.conv2d(xp, sd[pre + "bbox3dconv.weight"])
+    box = decode(reg, anchors(cfg))
+    pred = torch.cat((cls, reg, box), 1)
+    if return_stages:
+        stages["fpn"] = t2
+        stages["head"] = xp
+        return pred, stages
+    return pred
+
+
+def strip_module_prefix(sd):
+    return {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+
+
+# -------------------------------------------------- state-dict shapes (spec side)
+def lidar_state_shapes(cfg):
+    """Key -> shape of the reference's ObjectDetection_DCF state_dict (model.py:176-191)."""
+    lm = cfg["lidar_module"]
+    widths = [lm["out_feature%d" % i] for i in range(1, 6)]
+    blocks = [lm["num_res_block%d" % i] for i in range(1, 6)]
+    shapes = {}
+
+    def bn(p, c):
+        shapes[p + ".weight"] = (c,); shapes[p + ".bias"] = (c,)
+        shapes[p + ".running_mean"] = (c,); shapes[p + ".running_var"] = (c,)
+        shapes[p + ".num_batches_tracked"] = ()
+
+    cin = widths[0]
+    for si in range(5):
+        cout = widths[si]
+        for bi in range(blocks[si]):
+            p = "lidar_backbone.backbone.layer%d.sequential.resblock_%d" % (si + 1, bi)
+            ci = cin if bi == 0 else cout
+            shapes[p + ".conv1.weight"] = (cout, ci, 3, 3); bn(p + ".bn1", cout)
+            shapes[p + ".conv2.weight"] = (cout, cout, 3, 3); bn(p + ".bn2", cout)
+            if ci != cout:
+                shapes[p + ".down_conv.weight"] = (cout, ci, 1, 1); bn(p + ".down_bn", cout)
+        cin = cout
+    p = "lidar_backbone."
+    shapes[p + "latconv1.weight"] = (widths[3], widths[3], 1, 1)
+    shapes[p + "downconv1.weight"] = (widths[3], widths[4], 1, 1)
+    shapes[p + "latconv2.weight"] = (widths[3], widths[2], 1, 1)
+    shapes[p + "conv3.weight"] = (widths[3], widths[3], 3, 3)
+    shapes[p + "classconv.weight"] = (4, widths[3], 1, 1)
+    shapes[p + "bbox3dconv.weight"] = (14, widths[3], 1, 1)
+    return shapes
+
+
+def image_state_shapes(cf=64, widths=(64, 128, 256, 512), blocks=(2, 2, 2, 2)):
+    """App. D image stream (ResNet-18 BasicBlock trunk, torchvision key names) + FPN."""
+    shapes = {}
+
+    def bn(p, c):
+        shapes[p + ".weight"] = (c,); shapes[p + ".bias"] = (c,)
+        shapes[p + ".running_mean"] = (c,); shapes[p + ".running_var"] = (c,)
+        shapes[p + ".num_batches_tracked"] = ()
+
+    shapes["image_backbone.conv1.weight"] = (widths[0], 3, 7, 7); bn("image_backbone.bn1", widths[0])
+    cin = widths[0]
+    for li in range(4):
+        cout = widths[li]
+        for bi in range(blocks[li]):
+            p = "image_backbone.layer%d.%d" % (li + 1, bi)
+            ci = cin if bi == 0 else cout
+            shapes[p + ".conv1.weight"] = (cout, ci, 3, 3); bn(p + ".bn1", cout)
+            shapes[p + ".conv2.weight"] = (cout, cout, 3, 3); bn(p + ".bn2", cout)
+            if bi == 0 and li > 0:
+                shapes[p + ".downsample.0.weight"] = (cout, ci, 1, 1); bn(p + ".downsample.1", cout)
+        cin = cout
+    for li in range(4):
+        shapes["image_fpn.lat%d.weight" % (li + 1)] = (cf, widths[li], 1, 1)
+    shapes["image_fpn.smooth.weight"] = (cf, cf, 3, 3)
+    return shapes
+
+
+def fusion_state_shapes(cfg, cf=64):
+    lm = cfg["lidar_module"]
+    shapes = {}
+    for si in range(1, 5):
+        cb = lm["out_feature%d" % (si + 1)]
+        p = "fusion.site%d" % si
+        shapes[p + ".fc1.weight"] = (cb, cf + 3); shapes[p + ".fc1.bias"] = (cb,)
+        shapes[p + ".fc2.weight"] = (cb, cb); shapes[p + ".fc2.bias"] = (cb,)
+    return shapes
+
+
+def make_state_dict(shapes):
+    """Deterministic state dict from a shape table (same rule the product uses)."""
+    import importlib
+    detfill = importlib.import_module("deep_continuous_fusion_for_multi-sensor_3d_object_detection_amd.detfill")
+    sd = {}
+    for k, s in shapes.items():
+        a = detfill.fill_rule(k, tuple(s))
+        sd[k] = torch.from_numpy(np.ascontiguousarray(a)).reshape(tuple(s))
+    return sd
