@@ -1,0 +1,155 @@
+"""ctypes binding of libdcf_hip.so (include/dcf_hip.h) -- the only compute path.
+
+There is no CPU or eager-torch fallback: if the shared library is missing or a call
+fails, an exception is raised.  torch is used for device memory and streams only
+(`tensor.data_ptr()`, `torch.cuda.current_stream()`).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdcf_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+F32, BF16 = 0, 1
+VOXEL_COMPAT, VOXEL_ACCUM = 0, 1
+PROJ_COMPAT, PROJ_CORRECT = 0, 1
+
+c_int, c_float, c_i64, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p
+P = c_void_p
+
+# name -> (restype, argtypes); mirrors include/dcf_hip.h one to one
+SIGNATURES = {
+    "dcf_last_error": (ctypes.c_char_p, []),
+    "dcf_version": (c_int, []),
+    "dcf_prof_enable": (c_int, [c_int]),
+    "dcf_prof_reset": (c_int, []),
+    "dcf_prof_read": (c_int, [P, P, P, c_int]),
+    "dcf_compact_workspace_bytes": (c_size_t, [c_int]),
+    "dcf_range_filter": (c_int, [P, c_int, P, P, P, P, P, P]),
+    "dcf_voxelize_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dcf_voxelize": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, P, P, P]),
+    "dcf_project_filter": (c_int, [P, c_int, P, P, c_float, c_float, c_int, P, P, P, P, P, P]),
+    "dcf_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dcf_knn_bev": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, P, P, P]),
+    "dcf_nchw_to_nhwc": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P]),
+    "dcf_image_to_nhwc4": (c_int, [c_int, P, P, c_int, c_int, c_int, P]),
+    "dcf_conv2d_fwd": (c_int, [c_int, P, P, P, P, P] + [c_int] * 12 + [P]),
+    "dcf_conv2d_dgrad": (c_int, [c_int, P, P, P, P] + [c_int] * 11 + [P]),
+    "dcf_conv2d_wgrad_splits": (c_int, [c_int] * 7),
+    "dcf_conv2d_wgrad": (c_int, [c_int, P, P, P, c_int] + [c_int] * 11 + [P]),
+    "dcf_stem7x7_fwd": (c_int, [c_int, P, P, P, P] + [c_int] * 7 + [P]),
+    "dcf_stem7x7_wgrad": (c_int, [c_int, P, P, P, c_int] + [c_int] * 6 + [P]),
+    "dcf_weight_prep": (c_int, [c_int, P, c_int, P, P, P, P, c_float, P]),
+    "dcf_wgrad_finalize": (c_int, [P, c_int, P, P, P, P, P, P, c_float, P]),
+    "dcf_relu_bwd_chansum": (c_int, [c_int, P, P, P, c_i64, c_int, c_int, P]),
+    "dcf_resize_bilinear_fwd": (c_int, [c_int, P, P, P] + [c_int] * 7 + [P]),
+    "dcf_resize_bilinear_bwd": (c_int, [c_int, P, P] + [c_int] * 7 + [P]),
+    "dcf_maxpool3x3s2_fwd": (c_int, [c_int, P, P] + [c_int] * 6 + [P]),
+    "dcf_maxpool3x3s2_bwd": (c_int, [c_int, P, P, P, P] + [c_int] * 6 + [P]),
+    "dcf_head_fwd": (c_int, [c_int, P, c_int, P, P, c_int, c_int, c_int, P]),
+    "dcf_head_bwd": (c_int, [c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
+    "dcf_point_sample_fwd": (c_int, [c_int, P, c_int, c_int, c_int, P, P, c_int, P, P]),
+    "dcf_point_sample_bwd": (c_int, [c_int, P, c_int, c_int, c_int, P, P, c_int, P, P]),
+    "dcf_fusion_gather_fwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P, P, c_int, P, P, P]),
+    "dcf_fusion_gather_bwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P, P, c_int, P, P, P, P, P]),
+    "dcf_rowscale_bias_fwd": (c_int, [c_int, P, P, P, c_i64, c_int, P]),
+    "dcf_rowscale_bias_bwd": (c_int, [c_int, P, P, P, c_i64, c_int, P]),
+    "dcf_cast": (c_int, [c_int, P, c_int, P, c_i64, P]),
+    "dcf_adam_step": (c_int, [P, P, P, P, c_i64, c_float, c_float, c_float, c_float, c_int, c_float, P]),
+}
+
+
+class ConvParam(ctypes.Structure):
+    """struct dcf_conv_param of include/dcf_hip.h."""
+    _fields_ = [("w_off", c_i64), ("gamma_off", c_i64), ("beta_off", c_i64), ("mean_off", c_i64), ("var_off", c_i64),
+                ("wfwd_off", c_i64), ("wdgrad_off", c_i64), ("shift_off", c_i64), ("slab_off", c_i64), ("gsum_off", c_i64),
+                ("cout", ctypes.c_int32), ("cin", ctypes.c_int32), ("taps", ctypes.c_int32), ("cout_pad", ctypes.c_int32),
+                ("nsplit", ctypes.c_int32), ("flags", ctypes.c_int32), ("pad0", ctypes.c_int32), ("pad1", ctypes.c_int32)]
+
+
+class DcfError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+
+def build(force=False):
+    """Compile libdcf_hip.so for gfx950 with hipcc (in-tree, see csrc/Makefile)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
+    subprocess.check_call(["make", "-s", "-j8", "-C", CSRC])
+    return LIB_PATH
+
+
+def lib():
+    """Load the shared library; raises (no fallback) when it is missing."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise DcfError("libdcf_hip.so is not built (%s). Run __graft_entry__.build() / make -C %s; "
+                           "there is no CPU fallback for the HIP hot path." % (LIB_PATH, CSRC))
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        return t.data_ptr()
+    if isinstance(t, np.ndarray):
+        return t.ctypes.data
+    return t
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke dcf_<name>; tensors/ndarrays become raw pointers; non-zero status raises."""
+    L = lib()
+    fn = getattr(L, name)
+    rc = fn(*[_ptr(a) for a in args])
+    if fn.restype is c_int and rc != 0 and name not in ("dcf_version", "dcf_conv2d_wgrad_splits", "dcf_prof_read"):
+        raise DcfError("%s failed (%d): %s" % (name, rc, L.dcf_last_error().decode()))
+    return rc
+
+
+def dtype_code(dt):
+    if dt in (torch.float32, "f32", "fp32", F32):
+        return F32
+    if dt in (torch.bfloat16, "bf16", BF16):
+        return BF16
+    raise DcfError("unsupported compute dtype %r (f32 or bf16)" % (dt,))
+
+
+def torch_dtype(code):
+    return torch.float32 if code == F32 else torch.bfloat16
+
+
+def host_f32(values):
+    return np.ascontiguousarray(np.asarray(values, dtype=np.float32))
+
+
+def prof_read(cap=256):
+    names = ctypes.create_string_buffer(cap * 64)
+    tot = (ctypes.c_double * cap)()
+    cnt = (ctypes.c_int64 * cap)()
+    k = lib().dcf_prof_read(ctypes.cast(names, c_void_p), ctypes.cast(tot, c_void_p), ctypes.cast(cnt, c_void_p), cap)
+    out = {}
+    for i in range(k):
+        nm = names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode()
+        out[nm] = (tot[i], cnt[i])
+    return out

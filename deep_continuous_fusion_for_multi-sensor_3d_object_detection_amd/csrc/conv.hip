@@ -1,0 +1,558 @@
+// conv.hip -- implicit-GEMM convolution on the gfx950 matrix cores (MFMA 32x32).
+//
+// Replaces every nn.Conv2d (+ folded eval-mode BatchNorm2d + residual add + ReLU) of
+// /root/reference/model.py:15-41 (ResidualBlock) and :147-157 (FPN, heads), forward,
+// input-gradient and weight-gradient.
+//
+// Data layout: activations NHWC, i.e. a matrix [pixels][channels] whose rows are
+// contiguous channel vectors; weights [Cout][kh][kw][Cin], i.e. [N][K] with K =
+// (tap, channel) contiguous -- so the implicit GEMM is the "A row-major x B^T row-major"
+// form and both operands stage as rows of contiguous K bytes.
+//
+//   forward / dgrad:  D[n][m] = sum_{tap,c} Wt[n][tap][c] * X[src(m,tap)][c]
+//       m = output pixel, n = output channel; the weight tile is the MFMA A operand so
+//       each lane ends up with 4 consecutive output channels of one pixel (8/16 B stores).
+//       dgrad is the same kernel with the transposed-conv gather (TRANSPOSED) and the
+//       [Cin][tap][Cout] weight image written by dcf_weight_prep.
+//   wgrad:            G[co][tap][ci] = sum_p gy[p][co] * x[src(p,tap)][ci]
+//       reduction over pixels = the ROW index of both NHWC operands, so fragments are read
+//       transposed out of LDS (ds_read_b64_tr_b16 for bf16, ds_read_b32 for fp32); each
+//       wave is an independent split-K worker with a wave-private LDS region (no barriers)
+//       and writes its own fp32 slab with plain 128-B row stores (fixed-order reduce later).
+//
+// dtype: bf16 -> v_mfma_f32_32x32x16_bf16;  fp32 -> v_mfma_f32_32x32x2_f32 (exact fp32,
+// used by the parity tests against the reference's fp32 CPU path).  fp32 accumulate.
+#include "dcf_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+    const char *x;       // gathered tensor [B][Hi][Wi][Ck]
+    const char *w;       // [Cn][taps][Ck]
+    const float *shift;  // [Cn] or null
+    const char *res;     // [M][Cn] or null
+    char *y;             // [M][Cn]
+    int B, Hi, Wi, Ck;
+    int Ho, Wo, Cn;
+    int kh, kw, stride, pad, relu;
+    int M;
+    int pixbytes;        // byte pitch between adjacent input pixels (= Ck*esize except for the stem)
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    // one 16-byte fragment pair = one K=16 MFMA
+    __device__ static __forceinline__ void run(const uint4 &a, const uint4 &b, f32x16 &acc)
+    {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // one 16-byte fragment pair = four K=2 MFMAs (lane half h owns k = 4h+j of each 8-group;
+    // the k permutation is the same for both operands, so the sum is unchanged)
+    __device__ static __forceinline__ void run(const uint4 &a, const uint4 &b, f32x16 &acc)
+    {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// forward / dgrad kernel.  Block = 256 threads = WN x WM waves; wave tile TN*32 output
+// channels x TM*32 pixels.  K is walked tap by tap in chunks of KB bytes of channels.
+// LDS rows are padded by 16 B: the ds_read_b128 fragment reads are then conflict free.
+// ------------------------------------------------------------------------------------
+template <typename T, int KB, int TN, int TM, int WN, int WM, bool TRANSPOSED>
+__global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
+{
+    constexpr int ES = DT<T>::size;
+    constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
+    constexpr int PITCH = KB + 16;
+    constexpr int CPR = KB / 16;                 // 16-byte chunks per row
+    constexpr int NCW = BN * CPR, NCX = BM * CPR;
+    constexpr int NLW = (NCW + 255) / 256, NLX = (NCX + 255) / 256;
+    __shared__ __attribute__((aligned(16))) char lds[(BN + BM) * PITCH];
+    char *ldsW = lds, *ldsX = lds + BN * PITCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wn = wid / WM, wm = wid % WM;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    const int m0 = blockIdx.x * BM;
+    const int taps = a.kh * a.kw;
+    const int rowbytes = a.Ck * ES;              // bytes of one pixel's channel vector
+    const int cchunks = rowbytes / KB;
+
+    // per-thread gather bookkeeping for its X chunks (fixed over the K loop)
+    int xb[NLX], xh[NLX], xw[NLX], xoff[NLX];
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {
+        const int c = tid + i * 256;
+        const int row = c / CPR;
+        const int m = m0 + row;
+        xoff[i] = (c % CPR) * 16;
+        if (c < NCX && m < a.M) {
+            const int b = m / (a.Ho * a.Wo);
+            const int rem = m - b * (a.Ho * a.Wo);
+            const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+            xb[i] = b * a.Hi * a.Wi;
+            if (TRANSPOSED) { xh[i] = oh + a.pad; xw[i] = ow + a.pad; }
+            else { xh[i] = oh * a.stride - a.pad; xw[i] = ow * a.stride - a.pad; }
+        } else {
+            xb[i] = -1; xh[i] = 0; xw[i] = 0;
+        }
+    }
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    uint4 rw[NLW], rx[NLX];
+    auto load_global = [&](int tap, int cc) {
+        const int ki = tap / a.kw, kj = tap - ki * a.kw;
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) {
+            const int c = tid + i * 256;
+            if (NCW % 256 == 0 || c < NCW) {
+                const int row = c / CPR;
+                const char *p = a.w + ((size_t)(n0 + row) * taps + tap) * rowbytes + cc * KB + (c % CPR) * 16;
+                rw[i] = *reinterpret_cast<const uint4 *>(p);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NLX; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (xb[i] >= 0) {
+                int ih, iw;
+                bool ok;
+                if (TRANSPOSED) {
+                    const int th = xh[i] - ki, tw = xw[i] - kj;
+                    ok = (th >= 0) && (tw >= 0);
+                    if (a.stride == 2) { ok = ok && !((th | tw) & 1); ih = th >> 1; iw = tw >> 1; }
+                    else { ih = th; iw = tw; }
+                    ok = ok && (ih < a.Hi) && (iw < a.Wi);
+                } else {
+                    ih = xh[i] + ki; iw = xw[i] + kj;
+                    ok = (ih >= 0) && (ih < a.Hi) && (iw >= 0) && (iw < a.Wi);
+                }
+                if (ok) {
+                    const char *p = a.x + ((size_t)(xb[i] + ih * a.Wi + iw)) * a.pixbytes + cc * KB + xoff[i];
+                    v = *reinterpret_cast<const uint4 *>(p);
+                }
+            }
+            rx[i] = v;
+        }
+    };
+    auto store_lds = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) {
+            const int c = tid + i * 256;
+            if (NCW % 256 == 0 || c < NCW) *reinterpret_cast<uint4 *>(ldsW + (c / CPR) * PITCH + (c % CPR) * 16) = rw[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NLX; ++i) {
+            const int c = tid + i * 256;
+            if (NCX % 256 == 0 || c < NCX) *reinterpret_cast<uint4 *>(ldsX + (c / CPR) * PITCH + (c % CPR) * 16) = rx[i];
+        }
+    };
+
+    const int nit = taps * cchunks;
+    int tap = 0, cc = 0;
+    load_global(0, 0);
+    store_lds();
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+        int ntap = tap, ncc = cc + 1;
+        if (ncc == cchunks) { ncc = 0; ++ntap; }
+        const bool more = (it + 1 < nit);
+        if (more) load_global(ntap, ncc);  // in flight under the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < KB / 32; ++ks) {
+            uint4 fa[TN], fb[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                fa[i] = *reinterpret_cast<const uint4 *>(ldsW + ((wn * TN + i) * 32 + r) * PITCH + ks * 32 + h * 16);
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                fb[j] = *reinterpret_cast<const uint4 *>(ldsX + ((wm * TM + j) * 32 + r) * PITCH + ks * 32 + h * 16);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+        __syncthreads();
+        if (more) {
+            store_lds();
+            __syncthreads();
+        }
+        tap = ntap; cc = ncc;
+    }
+
+    // epilogue: lane (pixel r, half h) holds channels 8q+4h+{0..3} of each 32-channel tile
+    T *y = reinterpret_cast<T *>(a.y);
+    const T *res = reinterpret_cast<const T *>(a.res);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + (wm * TM + j) * 32 + r;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = n0 + (wn * TN + i) * 32 + 8 * q + 4 * h;
+                float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                if (a.shift) {
+                    const float4 s = *reinterpret_cast<const float4 *>(a.shift + c);
+                    v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+                }
+                const size_t o = (size_t)m * a.Cn + c;
+                if (res) {
+                    const float4 rr = ld4(res + o);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
+                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                st4(y + o, v);
+            }
+        }
+    }
+}
+
+template <typename T, bool TR>
+int launch_igemm(const ConvArgs &a, hipStream_t s, const char *name)
+{
+    constexpr int ES = DT<T>::size;
+    const int rowbytes = a.Ck * ES;
+    const bool kb128 = (rowbytes % 128) == 0;
+#define DCF_IGEMM(KB_, TN_, TM_, WN_, WM_)                                                                          \
+    do {                                                                                                            \
+        constexpr int BN_ = WN_ * TN_ * 32, BM_ = WM_ * TM_ * 32;                                                   \
+        dim3 grid(cdiv(a.M, BM_), a.Cn / BN_);                                                                      \
+        DCF_LAUNCH(name, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR>), grid, dim3(256), 0, s, a)); \
+        return DCF_OK;                                                                                              \
+    } while (0)
+    if (a.Cn % 128 == 0) {
+        if (kb128) DCF_IGEMM(128, 2, 2, 2, 2); else DCF_IGEMM(64, 2, 2, 2, 2);
+    } else if (a.Cn % 64 == 0) {
+        if (kb128) DCF_IGEMM(128, 2, 1, 1, 4); else DCF_IGEMM(64, 2, 1, 1, 4);
+    } else {
+        if (kb128) DCF_IGEMM(128, 1, 1, 1, 4); else DCF_IGEMM(64, 1, 1, 1, 4);
+    }
+#undef DCF_IGEMM
+}
+
+// ------------------------------------------------------------------------------------
+// wgrad kernel.  grid.x = co_tiles*ci_tiles*taps, grid.y = nsplit/4; every wave is its
+// own split-K worker over a contiguous pixel range, staging PK pixels per step into a
+// wave-private LDS region ([pixel][channel] rows, read back transposed).
+// ------------------------------------------------------------------------------------
+struct WgArgs {
+    const char *x;   // [B][H][W][Cin]
+    const char *gy;  // [B][Ho][Wo][Cout]
+    float *slabs;    // [nsplit][Cout][taps][Cin]
+    int B, H, W, Cin, Ho, Wo, Cout;
+    int kh, kw, stride, pad;
+    int M, nsplit, per_split;  // per_split = pixels per split (multiple of PK)
+    int co_tiles, ci_tiles;
+    int pixbytes;              // byte pitch between adjacent x pixels (= Cin*esize except for the stem)
+};
+
+template <typename T, int TM, int TN>
+__global__ void __launch_bounds__(256) k_conv_wgrad(WgArgs a)
+{
+    constexpr int ES = DT<T>::size;
+    constexpr int PK = 32;                        // pixels per stage
+    constexpr int RA = TM * 32 * ES, RB = TN * 32 * ES;     // row bytes of the two tiles
+    // bf16: pitch = 64 or 192 (mod 256) keeps the 4 rows x 64 B of one transposed read on
+    // distinct bank groups; fp32 reads are one row per 32-lane half (any pitch is conflict free)
+    constexpr int PA = (ES == 2) ? (RA == 64 ? 64 : 192) : RA + 16;
+    constexpr int PB = (ES == 2) ? (RB == 64 ? 64 : 192) : RB + 16;
+    constexpr int WAVE_LDS = PK * (PA + PB);
+    __shared__ __attribute__((aligned(16))) char lds_all[4 * WAVE_LDS];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    char *ldsA = lds_all + wid * WAVE_LDS;
+    char *ldsB = ldsA + PK * PA;
+
+    int t = blockIdx.x;
+    const int tap = t % (a.kh * a.kw); t /= (a.kh * a.kw);
+    const int cit = t % a.ci_tiles;
+    const int cot = t / a.ci_tiles;
+    const int co0 = cot * TM * 32, ci0 = cit * TN * 32;
+    const int ki = tap / a.kw, kj = tap - ki * a.kw;
+    const int split = blockIdx.y * 4 + wid;
+    const int p_begin = split * a.per_split;
+    const int p_end = min(p_begin + a.per_split, a.M);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    constexpr int CA = RA / 16, CB = RB / 16;       // 16-B chunks per row
+    constexpr int NLA = PK * CA / 64, NLB = PK * CB / 64;
+    const int rowA = a.Cout * ES;
+    const int coutA = min(TM * 32, a.Cout - co0) * ES;  // valid bytes of this tile's rows
+    const int cinB = min(TN * 32, a.Cin - ci0) * ES;
+
+    for (int p0 = p_begin; p0 < p_end; p0 += PK) {
+        uint4 ra[NLA], rb[NLB];
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            const int c = lane + i * 64;
+            const int row = c / CA, off = (c % CA) * 16;
+            const int p = p0 + row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (p < p_end && off < coutA) v = *reinterpret_cast<const uint4 *>(a.gy + (size_t)p * rowA + co0 * ES + off);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) {
+            const int c = lane + i * 64;
+            const int row = c / CB, off = (c % CB) * 16;
+            const int p = p0 + row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (p < p_end && off < cinB) {
+                const int b = p / (a.Ho * a.Wo);
+                const int rem = p - b * (a.Ho * a.Wo);
+                const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+                const int ih = oh * a.stride - a.pad + ki, iw = ow * a.stride - a.pad + kj;
+                if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
+                    v = *reinterpret_cast<const uint4 *>(a.x + ((size_t)(b * a.H + ih) * a.W + iw) * a.pixbytes + ci0 * ES + off);
+            }
+            rb[i] = v;
+        }
+        // previous stage's LDS reads have all been consumed by MFMAs issued before this
+        // point in program order of the same wave; ds ops of one wave execute in order.
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            const int c = lane + i * 64;
+            *reinterpret_cast<uint4 *>(ldsA + (c / CA) * PA + (c % CA) * 16) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) {
+            const int c = lane + i * 64;
+            *reinterpret_cast<uint4 *>(ldsB + (c / CB) * PB + (c % CB) * 16) = rb[i];
+        }
+        __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order: no s_barrier needed
+        if constexpr (ES == 2) {
+            // bf16: per K=16 step two transposed 4x16 reads per 32-channel fragment.
+            // lane = 16g+4q+p: rows (pixels) kbase+8h+{q, 4+q}, columns 16(g&1)+4p..+3, h = g>>1.
+            const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, hh = g >> 1;
+#pragma unroll
+            for (int ks = 0; ks < PK / 16; ++ks) {
+                uint4 fa[TM], fb[TN];
+                const int row0 = ks * 16 + 8 * hh + q;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const char *base = ldsA + row0 * PA + (i * 32 + 16 * (g & 1) + 4 * pp) * 2;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base + 4 * PA));
+                    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                    fa[i] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const char *base = ldsB + row0 * PB + (j * 32 + 16 * (g & 1) + 4 * pp) * 2;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base + 4 * PB));
+                    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                    fb[j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
+                                                                            acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // fp32: lane (i = lane&31, k = lane>>5) reads element [pixel 2*ks+k][channel i]
+            const int r = lane & 31, kk = lane >> 5;
+#pragma unroll
+            for (int ks = 0; ks < PK / 2; ++ks) {
+                float fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float *>(ldsA + (2 * ks + kk) * PA + (i * 32 + r) * 4);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float *>(ldsB + (2 * ks + kk) * PB + (j * 32 + r) * 4);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // slab store: acc lane l: column (ci) = l&31, rows (co) = (reg&3)+8(reg>>2)+4(l>>5)
+    const int taps = a.kh * a.kw;
+    float *slab = a.slabs + (size_t)split * a.Cout * taps * a.Cin;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ci = ci0 + j * 32 + r;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int co = co0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (co < a.Cout && ci < a.Cin) slab[((size_t)co * taps + tap) * a.Cin + ci] = acc[i][j][q];
+            }
+        }
+}
+
+}  // namespace
+
+// ================================================================== C ABI
+static int check_conv(const char *who, int dtype, int Cin, int Cout, int kh, int kw, int stride)
+{
+    const int es = dtype == DCF_F32 ? 4 : 2;
+    DCF_REQUIRE(dtype == DCF_F32 || dtype == DCF_BF16, "%s: unsupported dtype %d", who, dtype);
+    DCF_REQUIRE((Cin * es) % 64 == 0, "%s: Cin*esize must be a multiple of 64 bytes (Cin=%d)", who, Cin);
+    DCF_REQUIRE(Cout % 32 == 0, "%s: Cout must be a multiple of 32 (Cout=%d)", who, Cout);
+    DCF_REQUIRE(kh >= 1 && kw >= 1 && kh <= 7 && kw <= 7, "%s: kernel size %dx%d unsupported", who, kh, kw);
+    DCF_REQUIRE(stride == 1 || stride == 2, "%s: stride %d unsupported", who, stride);
+    return DCF_OK;
+}
+
+extern "C" int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const float *shift, const void *res, void *y,
+                              int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                              int relu, dcf_stream_t stream)
+{
+    int rc = check_conv("dcf_conv2d_fwd", dtype, Cin, Cout, kh, kw, stride);
+    if (rc) return rc;
+    DCF_REQUIRE(x && w && y, "dcf_conv2d_fwd: null pointer");
+    DCF_REQUIRE(Ho == (H + 2 * pad - kh) / stride + 1 && Wo == (W + 2 * pad - kw) / stride + 1, "dcf_conv2d_fwd: output size mismatch");
+    DCF_REQUIRE((int64_t)B * H * W * Cin < (1ll << 31) * 1, "dcf_conv2d_fwd: tensor too large for 32-bit pixel index");
+    ConvArgs a;
+    a.x = (const char *)x; a.w = (const char *)w; a.shift = shift; a.res = (const char *)res; a.y = (char *)y;
+    a.B = B; a.Hi = H; a.Wi = W; a.Ck = Cin; a.Ho = Ho; a.Wo = Wo; a.Cn = Cout;
+    a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.relu = relu; a.M = B * Ho * Wo;
+    a.pixbytes = Cin * (dtype == DCF_F32 ? 4 : 2);
+    if (dtype == DCF_F32) return launch_igemm<float, false>(a, S(stream), "conv_fwd_f32");
+    return launch_igemm<bf16_t, false>(a, S(stream), "conv_fwd_bf16");
+}
+
+extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const void *res, void *gx,
+                                int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                                dcf_stream_t stream)
+{
+    // roles swap: reduction channels = Cout, produced channels = Cin
+    int rc = check_conv("dcf_conv2d_dgrad", dtype, Cout, Cin, kh, kw, stride);
+    if (rc) return rc;
+    DCF_REQUIRE(gy && wt && gx, "dcf_conv2d_dgrad: null pointer");
+    ConvArgs a;
+    a.x = (const char *)gy; a.w = (const char *)wt; a.shift = nullptr; a.res = (const char *)res; a.y = (char *)gx;
+    a.B = B; a.Hi = Ho; a.Wi = Wo; a.Ck = Cout; a.Ho = H; a.Wo = W; a.Cn = Cin;
+    a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.relu = 0; a.M = B * H * W;
+    a.pixbytes = Cout * (dtype == DCF_F32 ? 4 : 2);
+    if (dtype == DCF_F32) return launch_igemm<float, true>(a, S(stream), "conv_dgrad_f32");
+    return launch_igemm<bf16_t, true>(a, S(stream), "conv_dgrad_bf16");
+}
+
+static void wgrad_tiles(int Cin, int Cout, int &TM, int &TN) { TM = Cout >= 64 ? 2 : 1; TN = Cin >= 64 ? 2 : 1; }
+
+extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw)
+{
+    int TM, TN;
+    wgrad_tiles(Cin, Cout, TM, TN);
+    const int tiles = cdiv(Cout, TM * 32) * cdiv(Cin, TN * 32) * kh * kw;
+    const int64_t M = (int64_t)B * Ho * Wo;
+    int64_t want = cdiv(3072, tiles);                 // ~12 waves per CU in total
+    int64_t maxs = (M + 127) / 128;                   // at least 4 stages of 32 pixels per split
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    return (int)((want + 3) / 4 * 4);
+}
+
+extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float *slabs, int nsplit,
+                                int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                                dcf_stream_t stream)
+{
+    int rc = check_conv("dcf_conv2d_wgrad", dtype, Cin, Cout, kh, kw, stride);
+    if (rc) return rc;
+    DCF_REQUIRE(x && gy && slabs && nsplit > 0 && nsplit % 4 == 0, "dcf_conv2d_wgrad: bad arguments");
+    WgArgs a;
+    a.x = (const char *)x; a.gy = (const char *)gy; a.slabs = slabs;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+    a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
+    a.M = B * Ho * Wo; a.nsplit = nsplit;
+    a.pixbytes = Cin * (dtype == DCF_F32 ? 4 : 2);
+    a.per_split = cdiv(cdiv(a.M, nsplit), 32) * 32;
+    int TM, TN;
+    wgrad_tiles(Cin, Cout, TM, TN);
+    a.co_tiles = cdiv(Cout, TM * 32);
+    a.ci_tiles = cdiv(Cin, TN * 32);
+    dim3 grid(a.co_tiles * a.ci_tiles * kh * kw, nsplit / 4);
+    hipStream_t s = S(stream);
+#define DCF_WG(T_, NAME_)                                                                                                      \
+    do {                                                                                                                       \
+        if (TM == 2 && TN == 2) DCF_LAUNCH(NAME_, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 2, 2>), grid, dim3(256), 0, s, a));   \
+        else if (TM == 2) DCF_LAUNCH(NAME_, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 2, 1>), grid, dim3(256), 0, s, a));         \
+        else if (TN == 2) DCF_LAUNCH(NAME_, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 1, 2>), grid, dim3(256), 0, s, a));         \
+        else DCF_LAUNCH(NAME_, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 1, 1>), grid, dim3(256), 0, s, a));                      \
+    } while (0)
+    if (dtype == DCF_F32) DCF_WG(float, "conv_wgrad_f32"); else DCF_WG(bf16_t, "conv_wgrad_bf16");
+#undef DCF_WG
+    return DCF_OK;
+}
+
+
+// ------------------------------------------------------------------ image stem
+// 7x7 stride-2 pad-3 convolution of the RGB image (SURVEY.md App. D image stream; the
+// reference only has the commented-out torchvision resnet18 at model.py:192).
+// The image is stored NHWC4 with a zero halo (dcf_image_to_nhwc4): one kernel row of
+// 7 taps x 3 channels is then 8 pixels x 4 channels = 32 CONTIGUOUS elements, so the stem
+// is the same implicit GEMM with 7 vertical taps of K=32, pixel pitch 4 elements, stride 2
+// and no bounds checks.  Weights [Cout][7][8][4] (tap kw=7 and channel 3 are zero).
+extern "C" int dcf_stem7x7_fwd(int dtype, const void *img4, const void *w, const float *shift, void *y,
+                               int B, int H, int W, int Ho, int Wo, int Cout, int relu, dcf_stream_t stream)
+{
+    DCF_REQUIRE(img4 && w && y && Cout % 32 == 0, "dcf_stem7x7_fwd: bad arguments");
+    DCF_REQUIRE(Ho == (H + 6 - 7) / 2 + 1 && Wo == (W + 6 - 7) / 2 + 1, "dcf_stem7x7_fwd: output size mismatch");
+    ConvArgs a;
+    a.x = (const char *)img4; a.w = (const char *)w; a.shift = shift; a.res = nullptr; a.y = (char *)y;
+    a.B = B; a.Hi = H + 6; a.Wi = W + 8; a.Ck = 32; a.Ho = Ho; a.Wo = Wo; a.Cn = Cout;
+    a.kh = 7; a.kw = 1; a.stride = 2; a.pad = 0; a.relu = relu; a.M = B * Ho * Wo;
+    a.pixbytes = 4 * (dtype == DCF_F32 ? 4 : 2);
+    if (dtype == DCF_F32) return launch_igemm<float, false>(a, S(stream), "stem_fwd_f32");
+    return launch_igemm<bf16_t, false>(a, S(stream), "stem_fwd_bf16");
+}
+
+extern "C" int dcf_stem7x7_wgrad(int dtype, const void *img4, const void *gy, float *slabs, int nsplit,
+                                 int B, int H, int W, int Ho, int Wo, int Cout, dcf_stream_t stream)
+{
+    DCF_REQUIRE(img4 && gy && slabs && nsplit > 0 && nsplit % 4 == 0 && Cout % 32 == 0, "dcf_stem7x7_wgrad: bad arguments");
+    WgArgs a;
+    a.x = (const char *)img4; a.gy = (const char *)gy; a.slabs = slabs;
+    a.B = B; a.H = H + 6; a.W = W + 8; a.Cin = 32; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+    a.kh = 7; a.kw = 1; a.stride = 2; a.pad = 0;
+    a.M = B * Ho * Wo; a.nsplit = nsplit;
+    a.pixbytes = 4 * (dtype == DCF_F32 ? 4 : 2);
+    a.per_split = cdiv(cdiv(a.M, nsplit), 32) * 32;
+    const int TM = Cout >= 64 ? 2 : 1;
+    a.co_tiles = cdiv(Cout, TM * 32);
+    a.ci_tiles = 1;
+    dim3 grid(a.co_tiles * 7, nsplit / 4);
+    hipStream_t s = S(stream);
+    if (dtype == DCF_F32) {
+        if (TM == 2) DCF_LAUNCH("stem_wgrad_f32", s, hipLaunchKernelGGL((k_conv_wgrad<float, 2, 1>), grid, dim3(256), 0, s, a));
+        else DCF_LAUNCH("stem_wgrad_f32", s, hipLaunchKernelGGL((k_conv_wgrad<float, 1, 1>), grid, dim3(256), 0, s, a));
+    } else {
+        if (TM == 2) DCF_LAUNCH("stem_wgrad_bf16", s, hipLaunchKernelGGL((k_conv_wgrad<bf16_t, 2, 1>), grid, dim3(256), 0, s, a));
+        else DCF_LAUNCH("stem_wgrad_bf16", s, hipLaunchKernelGGL((k_conv_wgrad<bf16_t, 1, 1>), grid, dim3(256), 0, s, a));
+    }
+    return DCF_OK;
+}

@@ -1,0 +1,116 @@
+// dcf_common.h -- shared host/device helpers of libdcf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dcf_hip.h"
+
+// ---------------------------------------------------------------- error handling
+void dcf_set_error(const char *fmt, ...);
+
+#define DCF_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            dcf_set_error(__VA_ARGS__);        \
+            return DCF_EINVAL;                 \
+        }                                      \
+    } while (0)
+
+#define DCF_HIP(call)                                                                 \
+    do {                                                                              \
+        hipError_t e__ = (call);                                                      \
+        if (e__ != hipSuccess) {                                                      \
+            dcf_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+            return DCF_ELAUNCH;                                                       \
+        }                                                                             \
+    } while (0)
+
+// ---------------------------------------------------------------- launch + profiling
+// Every kernel launch goes through DCF_LAUNCH so that the optional event timing
+// (dcf_prof_enable) brackets it on the stream it is launched on.
+void dcf_prof_begin(const char *name, hipStream_t s);
+void dcf_prof_end(hipStream_t s);
+extern int g_dcf_prof_on;
+
+#define DCF_LAUNCH(name, stream, ...)                                               \
+    do {                                                                            \
+        if (g_dcf_prof_on) dcf_prof_begin(name, stream);                            \
+        __VA_ARGS__;                                                                \
+        if (g_dcf_prof_on) dcf_prof_end(stream);                                    \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            dcf_set_error("launch %s failed: %s", name, hipGetErrorString(e__));    \
+            return DCF_ELAUNCH;                                                     \
+        }                                                                           \
+    } while (0)
+
+static inline hipStream_t S(dcf_stream_t s) { return (hipStream_t)s; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- dtype helpers
+typedef unsigned short bf16_t;  // raw bits
+
+__device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((unsigned)u) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f)
+{
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+    static constexpr int size = 4;
+    __device__ static __forceinline__ float ld(const float *p) { return *p; }
+    __device__ static __forceinline__ void st(float *p, float v) { *p = v; }
+};
+template <> struct DT<bf16_t> {
+    static constexpr int size = 2;
+    __device__ static __forceinline__ float ld(const bf16_t *p) { return bf2f(*p); }
+    __device__ static __forceinline__ void st(bf16_t *p, float v) { *p = f2bf(v); }
+};
+
+// load/store 4 consecutive channels as float4
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t *p)
+{
+    uint2 u = *reinterpret_cast<const uint2 *>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t *p, float4 v)
+{
+    uint2 u;
+    u.x = pack2bf(v.x, v.y);
+    u.y = pack2bf(v.z, v.w);
+    *reinterpret_cast<uint2 *>(p) = u;
+}
+
+// wave64 reductions
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+#define DCF_DISPATCH_DTYPE(dtype, ...)                        \
+    if ((dtype) == DCF_F32) {                                 \
+        typedef float T;                                      \
+        __VA_ARGS__                                           \
+    } else if ((dtype) == DCF_BF16) {                         \
+        typedef bf16_t T;                                     \
+        __VA_ARGS__                                           \
+    } else {                                                  \
+        dcf_set_error("unsupported dtype %d", (int)(dtype));  \
+        return DCF_EUNSUPPORTED;                              \
+    }

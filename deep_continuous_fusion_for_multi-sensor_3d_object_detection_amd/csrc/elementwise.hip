@@ -1,0 +1,705 @@
+// elementwise.hip -- the HBM-bound kernels around the convolutions: layout conversion,
+// ReLU backward + channel sums, bilinear resize, 3x3/2 max-pool, detection heads
+// (softmax pairs + box decode), per-step weight preparation / gradient finalisation
+// (folded BatchNorm chain rule) and the fused Adam step.
+//
+// All activations are NHWC; every kernel moves 8-16 B per lane and is priced against the
+// HBM roofline.  Reference lines are cited per kernel.
+#include "dcf_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------
+// NCHW fp32 -> NHWC dtype.  One thread per pixel: coalesced 4-B reads across the wave
+// for each channel plane, one contiguous C-vector store per thread.
+// (model.py:194 takes the voxel grid as [B,Cz,L,W]; the engine computes in NHWC.)
+// ------------------------------------------------------------------------------------
+template <typename T, int CV>
+__global__ void __launch_bounds__(256) k_nchw_to_nhwc(const float *x, T *y, int C, int64_t HW, int64_t total)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // b*HW + pixel
+    if (p >= total) return;
+    const int64_t b = p / HW, q = p - b * HW;
+    const float *src = x + b * C * HW + q;
+    T *dst = y + p * C;
+    for (int c0 = 0; c0 < C; c0 += CV) {
+        float v[CV];
+#pragma unroll
+        for (int k = 0; k < CV; ++k) v[k] = src[(int64_t)(c0 + k) * HW];
+#pragma unroll
+        for (int k = 0; k < CV; k += 4) st4(dst + c0 + k, make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]));
+    }
+}
+
+// uint8 NCHW -> x/255 NHWC4 with a 3-pixel zero halo (rows and columns), row pitch (W+8)
+// pixels so that rows stay 16-B aligned in bf16.  Image tensor contract: data_import_carla.py:62.
+template <typename T>
+__global__ void __launch_bounds__(256) k_image_to_nhwc4(const uint8_t *img, T *y, int B, int H, int W)
+{
+    const int Hp = H + 6, Wp = W + 8;
+    const int64_t total = (int64_t)B * Hp * Wp;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    const int b = (int)(p / ((int64_t)Hp * Wp));
+    const int rem = (int)(p - (int64_t)b * Hp * Wp);
+    const int hp = rem / Wp, wp = rem - hp * Wp;
+    const int h = hp - 3, w = wp - 3;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (h >= 0 && h < H && w >= 0 && w < W) {
+        const int64_t HW = (int64_t)H * W;
+        const uint8_t *s = img + (int64_t)b * 3 * HW + (int64_t)h * W + w;
+        v.x = (float)s[0] / 255.0f;
+        v.y = (float)s[HW] / 255.0f;
+        v.z = (float)s[2 * HW] / 255.0f;
+    }
+    st4(y + p * 4, v);
+}
+
+// ------------------------------------------------------------------------------------
+// ReLU backward + per-channel sum.  g = gy * (y > 0) written in place; gsum[c] += sum g.
+// (ReLU: model.py:21,25,40; the channel sum is dL/d(beta) of the folded BatchNorm.)
+// Each thread owns one 4-channel group for its whole grid-stride loop.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_relu_bwd_chansum(T *gy, const T *y, float *gsum, int64_t nvec, int cgroups, int relu,
+                                                          int64_t stride)
+{
+    extern __shared__ float sm[];  // [cgroups*4]
+    for (int i = threadIdx.x; i < cgroups * 4; i += blockDim.x) sm[i] = 0.f;
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < stride) {
+        const int cg = (int)(t % cgroups);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t e = t; e < nvec; e += stride) {
+            float4 g = ld4(gy + e * 4);
+            if (relu) {
+                const float4 yy = ld4(y + e * 4);
+                g.x = yy.x > 0.f ? g.x : 0.f;
+                g.y = yy.y > 0.f ? g.y : 0.f;
+                g.z = yy.z > 0.f ? g.z : 0.f;
+                g.w = yy.w > 0.f ? g.w : 0.f;
+                st4(gy + e * 4, g);
+            }
+            acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+        }
+        atomicAdd(&sm[cg * 4 + 0], acc.x);
+        atomicAdd(&sm[cg * 4 + 1], acc.y);
+        atomicAdd(&sm[cg * 4 + 2], acc.z);
+        atomicAdd(&sm[cg * 4 + 3], acc.w);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cgroups * 4; i += blockDim.x) atomicAdd(&gsum[i], sm[i]);
+}
+
+// ------------------------------------------------------------------------------------
+// Bilinear resize, NHWC.  align_corners=1: nn.UpsamplingBilinear2d (model.py:149,151);
+// align_corners=0: the image FPN of SURVEY.md App. D.  Source index rule = ATen's
+// area_pixel_compute_source_index.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void src_index(int o, float scale, int align, int in_size, int &i0, int &i1, float &l)
+{
+    float s;
+    if (align) s = scale * (float)o;
+    else {
+        s = scale * ((float)o + 0.5f) - 0.5f;
+        s = s < 0.f ? 0.f : s;
+    }
+    i0 = (int)s;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l = s - (float)i0;
+}
+
+__host__ __device__ inline float resize_scale(int in, int out, int align)
+{
+    if (align) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    return (float)in / (float)out;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_resize_fwd(const T *x, const T *add, T *y, int B, int Hi, int Wi, int Ho, int Wo, int C4,
+                                                    int align, float sh, float sw)
+{
+    const int64_t total = (int64_t)B * Ho * Wo * C4;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)(e % C4);
+    int64_t p = e / C4;
+    const int ow = (int)(p % Wo); p /= Wo;
+    const int oh = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_index(oh, sh, align, Hi, y0, y1, ly);
+    src_index(ow, sw, align, Wi, x0, x1, lx);
+    const int C = C4 * 4;
+    const T *base = x + (int64_t)b * Hi * Wi * C + c * 4;
+    const float4 v00 = ld4(base + ((int64_t)y0 * Wi + x0) * C), v01 = ld4(base + ((int64_t)y0 * Wi + x1) * C);
+    const float4 v10 = ld4(base + ((int64_t)y1 * Wi + x0) * C), v11 = ld4(base + ((int64_t)y1 * Wi + x1) * C);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    float4 o;
+    o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+    o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+    o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+    o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+    const int64_t oo = e * 4;
+    if (add) {
+        const float4 a = ld4(add + oo);
+        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    }
+    st4(y + oo, o);
+}
+
+// gather-form transpose: input pixel (ih,iw) sums every output pixel that sampled it.
+// Candidate output rows form a contiguous window around ih/scale; each is re-derived
+// exactly with src_index, so the result is deterministic (no atomics).
+template <typename T>
+__global__ void __launch_bounds__(256) k_resize_bwd(const T *gy, T *gx, int B, int Hi, int Wi, int Ho, int Wo, int C4, int align,
+                                                    float sh, float sw)
+{
+    const int64_t total = (int64_t)B * Hi * Wi * C4;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)(e % C4);
+    int64_t p = e / C4;
+    const int iw = (int)(p % Wi); p /= Wi;
+    const int ih = (int)(p % Hi);
+    const int b = (int)(p / Hi);
+    const int C = C4 * 4;
+    const float inv_h = sh > 0.f ? 1.f / sh : (float)Ho, inv_w = sw > 0.f ? 1.f / sw : (float)Wo;
+    int oh_lo = (int)floorf(((float)ih - 1.f) * inv_h) - 2, oh_hi = (int)ceilf(((float)ih + 1.f) * inv_h) + 2;
+    int ow_lo = (int)floorf(((float)iw - 1.f) * inv_w) - 2, ow_hi = (int)ceilf(((float)iw + 1.f) * inv_w) + 2;
+    oh_lo = max(oh_lo, 0); oh_hi = min(oh_hi, Ho - 1);
+    ow_lo = max(ow_lo, 0); ow_hi = min(ow_hi, Wo - 1);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const T *base = gy + (int64_t)b * Ho * Wo * C + c * 4;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+        int y0, y1;
+        float ly;
+        src_index(oh, sh, align, Hi, y0, y1, ly);
+        float wy = 0.f;
+        if (y0 == ih) wy += 1.f - ly;
+        if (y1 == ih) wy += ly;
+        if (wy == 0.f) continue;
+        for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+            int x0, x1;
+            float lx;
+            src_index(ow, sw, align, Wi, x0, x1, lx);
+            float wx = 0.f;
+            if (x0 == iw) wx += 1.f - lx;
+            if (x1 == iw) wx += lx;
+            if (wx == 0.f) continue;
+            const float4 g = ld4(base + ((int64_t)oh * Wo + ow) * C);
+            const float wgt = wy * wx;
+            acc.x += wgt * g.x; acc.y += wgt * g.y; acc.z += wgt * g.z; acc.w += wgt * g.w;
+        }
+    }
+    st4(gx + e * 4, acc);
+}
+
+// ------------------------------------------------------------------------------------
+// 3x3 stride-2 pad-1 max-pool (image stem, torchvision ResNet layout), NHWC.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_maxpool_fwd(const T *x, T *y, int B, int H, int W, int Ho, int Wo, int C4)
+{
+    const int64_t total = (int64_t)B * Ho * Wo * C4;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)(e % C4);
+    int64_t p = e / C4;
+    const int ow = (int)(p % Wo); p /= Wo;
+    const int oh = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const int C = C4 * 4;
+    float4 m = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+    for (int dh = 0; dh < 3; ++dh) {
+        const int ih = oh * 2 - 1 + dh;
+        if (ih < 0 || ih >= H) continue;
+        for (int dw = 0; dw < 3; ++dw) {
+            const int iw = ow * 2 - 1 + dw;
+            if (iw < 0 || iw >= W) continue;
+            const float4 v = ld4(x + (((int64_t)b * H + ih) * W + iw) * C + c * 4);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    st4(y + e * 4, m);
+}
+
+// gather-form backward: input pixel collects gy from every window whose FIRST max (scan
+// order dh,dw) is this pixel -- the same element ATen's max_pool2d backward routes to.
+template <typename T>
+__global__ void __launch_bounds__(256) k_maxpool_bwd(const T *x, const T *gy, T *gx, int B, int H, int W, int Ho, int Wo, int C4)
+{
+    const int64_t total = (int64_t)B * H * W * C4;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)(e % C4);
+    int64_t p = e / C4;
+    const int iw = (int)(p % W); p /= W;
+    const int ih = (int)(p % H);
+    const int b = (int)(p / H);
+    const int C = C4 * 4;
+    const float4 me = ld4(x + e * 4);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float mev[4] = {me.x, me.y, me.z, me.w};
+    for (int oh = (ih + 1) / 2 - 1; oh <= (ih + 1) / 2; ++oh) {
+        if (oh < 0 || oh >= Ho || ih < oh * 2 - 1 || ih > oh * 2 + 1) continue;
+        for (int ow = (iw + 1) / 2 - 1; ow <= (iw + 1) / 2; ++ow) {
+            if (ow < 0 || ow >= Wo || iw < ow * 2 - 1 || iw > ow * 2 + 1) continue;
+            // find the first arg-max of this window per channel
+            float best[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+            int bpos[4] = {-1, -1, -1, -1};
+            for (int dh = 0; dh < 3; ++dh) {
+                const int hh = oh * 2 - 1 + dh;
+                if (hh < 0 || hh >= H) continue;
+                for (int dw = 0; dw < 3; ++dw) {
+                    const int ww = ow * 2 - 1 + dw;
+                    if (ww < 0 || ww >= W) continue;
+                    const float4 v = ld4(x + (((int64_t)b * H + hh) * W + ww) * C + c * 4);
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (vv[k] > best[k]) { best[k] = vv[k]; bpos[k] = hh * W + ww; }
+                }
+            }
+            const float4 g = ld4(gy + (((int64_t)b * Ho + oh) * Wo + ow) * C + c * 4);
+            const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (bpos[k] == ih * W + iw) acc[k] += gv[k];
+        }
+    }
+    (void)mev;
+    st4(gx + e * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+}
+
+// ------------------------------------------------------------------------------------
+// Detection heads.  head [B,h,w,Cp]: channels 0..3 class logits, 4..17 box offsets.
+// pred [B,32,h,w] fp32 = cat(softmax(l0,l1), softmax(l2,l3), reg14, decode(reg14)).
+// model.py:168-172 (softmax pairs), :126-136 (decode), :204 (concat).  fp32 math.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_head_fwd(const T *head, int Cp, const float *anc, float *pred, int B, int hw)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (int64_t)B * hw) return;
+    const int b = (int)(p / hw), q = (int)(p - (int64_t)b * hw);
+    const T *hp = head + p * Cp;
+    float v[20];
+#pragma unroll
+    for (int k = 0; k < 20; k += 4) {
+        const float4 t = ld4(hp + k);
+        v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
+    }
+    float *o = pred + (int64_t)b * 32 * hw + q;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const float l0 = v[2 * a], l1 = v[2 * a + 1];
+        const float m = fmaxf(l0, l1);
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+        const float inv = 1.0f / (e0 + e1);
+        o[(int64_t)(2 * a) * hw] = e0 * inv;
+        o[(int64_t)(2 * a + 1) * hw] = e1 * inv;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const float *r = v + 4 + 7 * a;
+        float an[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) an[k] = anc[(int64_t)(7 * a + k) * hw + q];
+        const float diag = sqrtf(an[3] * an[3] + an[4] * an[4]);
+        float box[7];
+        box[0] = r[0] * diag + an[0];
+        box[1] = r[1] * diag + an[1];
+        box[2] = r[2] * an[5] + an[2];
+        box[3] = expf(r[3]) * an[3];
+        box[4] = expf(r[4]) * an[4];
+        box[5] = expf(r[5]) * an[5];
+        const float t = r[6] + an[6];
+        box[6] = atan2f(sinf(t), cosf(t));
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            o[(int64_t)(4 + 7 * a + k) * hw] = r[k];
+            o[(int64_t)(18 + 7 * a + k) * hw] = box[k];
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_head_bwd(int Cp, const float *anc, const float *pred, const float *gpred, T *ghead, int B, int hw)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (int64_t)B * hw) return;
+    const int b = (int)(p / hw), q = (int)(p - (int64_t)b * hw);
+    const float *o = pred + (int64_t)b * 32 * hw + q;
+    const float *g = gpred + (int64_t)b * 32 * hw + q;
+    float out[20];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const float p0 = o[(int64_t)(2 * a) * hw], p1 = o[(int64_t)(2 * a + 1) * hw];
+        const float g0 = g[(int64_t)(2 * a) * hw], g1 = g[(int64_t)(2 * a + 1) * hw];
+        const float dot = g0 * p0 + g1 * p1;
+        out[2 * a] = p0 * (g0 - dot);
+        out[2 * a + 1] = p1 * (g1 - dot);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const float al = anc[(int64_t)(7 * a + 3) * hw + q], aw = anc[(int64_t)(7 * a + 4) * hw + q], ah = anc[(int64_t)(7 * a + 5) * hw + q];
+        const float diag = sqrtf(al * al + aw * aw);
+        float dj[7];
+        dj[0] = diag; dj[1] = diag; dj[2] = ah;
+        dj[3] = o[(int64_t)(18 + 7 * a + 3) * hw];  // d exp(r)*anc / dr = box value
+        dj[4] = o[(int64_t)(18 + 7 * a + 4) * hw];
+        dj[5] = o[(int64_t)(18 + 7 * a + 5) * hw];
+        dj[6] = 1.0f;                               // d atan2(sin t, cos t)/dt
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            out[4 + 7 * a + k] = g[(int64_t)(4 + 7 * a + k) * hw] + g[(int64_t)(18 + 7 * a + k) * hw] * dj[k];
+    }
+    out[18] = 0.f; out[19] = 0.f;
+    T *hp = ghead + p * Cp;
+#pragma unroll
+    for (int k = 0; k < 20; k += 4) st4(hp + k, make_float4(out[k], out[k + 1], out[k + 2], out[k + 3]));
+    for (int k = 20; k < Cp; k += 4) st4(hp + k, make_float4(0.f, 0.f, 0.f, 0.f));
+}
+
+// ------------------------------------------------------------------------------------
+// Per-step weight preparation, one launch for every convolution (blockIdx.y = conv).
+// Folds the eval-mode BatchNorm (model.py:20,24,29; eval per SURVEY.md F4) into the weights:
+//   scale = gamma*rsqrt(var+eps), shift = beta - mean*scale,  w' = cast(scale*W).
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_weight_prep(const dcf_conv_param *table, const float *params, const float *buffers, char *warena,
+                                                     float *ssarena, float eps)
+{
+    const dcf_conv_param d = table[blockIdx.y];
+    const int K = d.taps * d.cin;
+    const int64_t total = (int64_t)d.cout_pad * K;
+    T *wf = reinterpret_cast<T *>(warena + d.wfwd_off);
+    T *wd = d.wdgrad_off >= 0 ? reinterpret_cast<T *>(warena + d.wdgrad_off) : nullptr;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(e / K);
+        const int k = (int)(e - (int64_t)co * K);
+        float v = 0.f;
+        if (co < d.cout) {
+            float scale = 1.f;
+            if (d.gamma_off >= 0) scale = params[d.gamma_off + co] * rsqrtf(buffers[d.var_off + co] + eps);
+            v = params[d.w_off + e] * scale;
+            if (k == 0) {
+                float shift = 0.f;
+                if (d.gamma_off >= 0) shift = params[d.beta_off + co] - buffers[d.mean_off + co] * scale;
+                ssarena[d.shift_off + co] = scale;
+                ssarena[d.shift_off + d.cout_pad + co] = shift;
+            }
+        } else if (k == 0) {
+            ssarena[d.shift_off + co] = 0.f;
+            ssarena[d.shift_off + d.cout_pad + co] = 0.f;
+        }
+        DT<T>::st(wf + e, v);
+        if (wd) {
+            const int tap = k / d.cin, ci = k - tap * d.cin;
+            DT<T>::st(wd + ((int64_t)ci * d.taps + tap) * d.cout_pad + co, v);
+        }
+    }
+}
+
+// Gradient finalisation, one block per (conv, output channel): fixed-order reduction of the
+// wgrad slabs, then the folded-BN chain rule
+//   dW = scale*G ; dbeta = sum g ; dgamma = (<W,G> - mean*dbeta) * rsqrt(var+eps).
+__global__ void __launch_bounds__(256) k_wgrad_finalize(const dcf_conv_param *table, const float *params, const float *buffers,
+                                                        const float *ssarena, const float *slabs, const float *gsum, float *grads, float eps)
+{
+    const dcf_conv_param d = table[blockIdx.y];
+    const int co = blockIdx.x;
+    if (co >= d.cout) return;
+    const int K = d.taps * d.cin;
+    const int64_t slab_elems = (int64_t)d.cout_pad * K;
+    const float scale = ssarena[d.shift_off + co];
+    float dot = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const int64_t e = (int64_t)co * K + k;
+        float G = 0.f;
+        const float *sp = slabs + d.slab_off + e;
+        for (int s = 0; s < d.nsplit; ++s) G += sp[(int64_t)s * slab_elems];
+        grads[d.w_off + e] = d.gamma_off >= 0 ? scale * G : G;
+        dot += params[d.w_off + e] * G;
+    }
+    if (d.gamma_off < 0) return;
+    __shared__ float red[4];
+    dot = wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = red[0] + red[1] + red[2] + red[3];
+        const float dbeta = gsum[d.gsum_off + co];
+        const float invstd = rsqrtf(buffers[d.var_off + co] + eps);
+        grads[d.beta_off + co] = dbeta;
+        grads[d.gamma_off + co] = (tot - buffers[d.mean_off + co] * dbeta) * invstd;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Fused Adam (train.py:28,36), torch.optim.Adam semantics, flat arena, float4 per lane.
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_adam(float *p, const float *g, float *m, float *v, int64_t n, float lr_over_bc1, float b1, float b2,
+                                              float inv_sqrt_bc2, float eps, float gscale)
+{
+    const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    if (i4 + 4 <= n) {
+        float4 pp = ld4(p + i4), gg = ld4(g + i4), mm = ld4(m + i4), vv = ld4(v + i4);
+        float *P = &pp.x, *G = &gg.x, *M = &mm.x, *V = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = G[k] * gscale;
+            M[k] = b1 * M[k] + (1.f - b1) * gk;
+            V[k] = b2 * V[k] + (1.f - b2) * gk * gk;
+            P[k] -= lr_over_bc1 * M[k] / (sqrtf(V[k]) * inv_sqrt_bc2 + eps);
+        }
+        st4(p + i4, pp); st4(m + i4, mm); st4(v + i4, vv);
+    } else {
+        for (int64_t i = i4; i < n; ++i) {
+            const float gk = g[i] * gscale;
+            m[i] = b1 * m[i] + (1.f - b1) * gk;
+            v[i] = b2 * v[i] + (1.f - b2) * gk * gk;
+            p[i] -= lr_over_bc1 * m[i] / (sqrtf(v[i]) * inv_sqrt_bc2 + eps);
+        }
+    }
+}
+
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256) k_cast(const TS *s, TD *d, int64_t n4)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) st4(d + i * 4, ld4(s + i * 4));
+}
+
+// y[p][c] += cnt[p]*b2[c]  /  gb2[c] += sum_p cnt[p]*gy[p][c]   (fc2 bias of the fusion K-sum)
+template <typename T>
+__global__ void __launch_bounds__(256) k_rowscale_bias_fwd(T *y, const float *cnt, const float *b2, int64_t nvec, int C4)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nvec) return;
+    const int64_t p = e / C4;
+    const int c = (int)(e - p * C4) * 4;
+    const float k = cnt[p];
+    float4 v = ld4(y + e * 4);
+    const float4 b = *reinterpret_cast<const float4 *>(b2 + c);
+    v.x += k * b.x; v.y += k * b.y; v.z += k * b.z; v.w += k * b.w;
+    st4(y + e * 4, v);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_rowscale_bias_bwd(const T *gy, const float *cnt, float *gb2, int64_t nvec, int cgroups, int64_t stride)
+{
+    extern __shared__ float sm[];
+    for (int i = threadIdx.x; i < cgroups * 4; i += blockDim.x) sm[i] = 0.f;
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < stride) {
+        const int cg = (int)(t % cgroups);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t e = t; e < nvec; e += stride) {
+            const float4 g = ld4(gy + e * 4);
+            const float k = cnt[e / cgroups];
+            acc.x += k * g.x; acc.y += k * g.y; acc.z += k * g.z; acc.w += k * g.w;
+        }
+        atomicAdd(&sm[cg * 4 + 0], acc.x);
+        atomicAdd(&sm[cg * 4 + 1], acc.y);
+        atomicAdd(&sm[cg * 4 + 2], acc.z);
+        atomicAdd(&sm[cg * 4 + 3], acc.w);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cgroups * 4; i += blockDim.x) atomicAdd(&gb2[i], sm[i]);
+}
+
+}  // namespace
+
+// ================================================================== C ABI
+extern "C" int dcf_nchw_to_nhwc(int dtype, const float *x, void *y, int B, int C, int H, int W, dcf_stream_t stream)
+{
+    DCF_REQUIRE(x && y && C % 4 == 0, "dcf_nchw_to_nhwc: C must be a multiple of 4");
+    const int64_t HW = (int64_t)H * W, total = (int64_t)B * HW;
+    hipStream_t s = S(stream);
+    DCF_DISPATCH_DTYPE(dtype, {
+        if (C % 8 == 0) DCF_LAUNCH("nchw_to_nhwc", s, hipLaunchKernelGGL((k_nchw_to_nhwc<T, 8>), dim3(cdiv(total, 256)), dim3(256), 0, s, x, (T *)y, C, HW, total));
+        else DCF_LAUNCH("nchw_to_nhwc", s, hipLaunchKernelGGL((k_nchw_to_nhwc<T, 4>), dim3(cdiv(total, 256)), dim3(256), 0, s, x, (T *)y, C, HW, total));
+    })
+    return DCF_OK;
+}
+
+extern "C" int dcf_image_to_nhwc4(int dtype, const uint8_t *img, void *y, int B, int H, int W, dcf_stream_t stream)
+{
+    DCF_REQUIRE(img && y, "dcf_image_to_nhwc4: null pointer");
+    const int64_t total = (int64_t)B * (H + 6) * (W + 8);
+    hipStream_t s = S(stream);
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("image_to_nhwc4", s, hipLaunchKernelGGL(k_image_to_nhwc4<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, img, (T *)y, B, H, W)); })
+    return DCF_OK;
+}
+
+static inline int64_t chan_stride(int64_t nvec, int cgroups, int &blocks)
+{
+    int64_t want = nvec < 256 * 1024 ? nvec : 256 * 1024;  // ~1024 blocks of 256 threads
+    if (want < cgroups) want = cgroups;
+    const int64_t stride = want / cgroups * cgroups;
+    blocks = cdiv(stride, 256);
+    return stride;
+}
+
+extern "C" int dcf_relu_bwd_chansum(int dtype, void *gy, const void *y, float *gsum, int64_t npix, int C, int relu,
+                                    dcf_stream_t stream)
+{
+    DCF_REQUIRE(gy && gsum && C % 4 == 0 && (!relu || y), "dcf_relu_bwd_chansum: bad arguments");
+    const int cg = C / 4;
+    const int64_t nvec = npix * cg;
+    if (nvec == 0) return DCF_OK;
+    int blocks;
+    const int64_t stride = chan_stride(nvec, cg, blocks);
+    hipStream_t s = S(stream);
+    DCF_DISPATCH_DTYPE(dtype, {
+        DCF_LAUNCH("relu_bwd_chansum", s, hipLaunchKernelGGL(k_relu_bwd_chansum<T>, dim3(blocks), dim3(256), sizeof(float) * C, s, (T *)gy, (const T *)y, gsum,
+                                                              nvec, cg, relu, stride));
+    })
+    return DCF_OK;
+}
+
+extern "C" int dcf_resize_bilinear_fwd(int dtype, const void *x, const void *add, void *y, int B, int Hi, int Wi, int Ho, int Wo,
+                                       int C, int align_corners, dcf_stream_t stream)
+{
+    DCF_REQUIRE(x && y && C % 4 == 0, "dcf_resize_bilinear_fwd: bad arguments");
+    const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
+    const float sh = resize_scale(Hi, Ho, align_corners), sw = resize_scale(Wi, Wo, align_corners);
+    hipStream_t s = S(stream);
+    DCF_DISPATCH_DTYPE(dtype, {
+        DCF_LAUNCH("resize_fwd", s, hipLaunchKernelGGL(k_resize_fwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, (const T *)add, (T *)y, B, Hi, Wi,
+                                                        Ho, Wo, C / 4, align_corners, sh, sw));
+    })
+    return DCF_OK;
+}
+
+extern "C" int dcf_resize_bilinear_bwd(int dtype, const void *gy, void *gx, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                       int align_corners, dcf_stream_t stream)
+{
+    DCF_REQUIRE(gy && gx && C % 4 == 0, "dcf_resize_bilinear_bwd: bad arguments");
+    const int64_t total = (int64_t)B * Hi * Wi * (C / 4);
+    const float sh = resize_scale(Hi, Ho, align_corners), sw = resize_scale(Wi, Wo, align_corners);
+    hipStream_t s = S(stream);
+    DCF_DISPATCH_DTYPE(dtype, {
+        DCF_LAUNCH("resize_bwd", s, hipLaunchKernelGGL(k_resize_bwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)gy, (T *)gx, B, Hi, Wi, Ho, Wo, C / 4,
+                                                        align_corners, sh, sw));
+    })
+    return DCF_OK;
+}
+
+extern "C" int dcf_maxpool3x3s2_fwd(int dtype, const void *x, void *y, int B, int H, int W, int Ho, int Wo, int C,
+                                    dcf_stream_t stream)
+{
+    DCF_REQUIRE(x && y && C % 4 == 0 && Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, "dcf_maxpool3x3s2_fwd: bad arguments");
+    const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
+    hipStream_t s = S(stream);
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("maxpool_fwd", s, hipLaunchKernelGGL(k_maxpool_fwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, (T *)y, B, H, W, Ho, Wo, C / 4)); })
+    return DCF_OK;
+}
+
+extern "C" int dcf_maxpool3x3s2_bwd(int dtype, const void *x, const void *y, const void *gy, void *gx, int B, int H, int W,
+                                    int Ho, int Wo, int C, dcf_stream_t stream)
+{
+    (void)y;
+    DCF_REQUIRE(x && gy && gx && C % 4 == 0, "dcf_maxpool3x3s2_bwd: bad arguments");
+    const int64_t total = (int64_t)B * H * W * (C / 4);
+    hipStream_t s = S(stream);
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("maxpool_bwd", s, hipLaunchKernelGGL(k_maxpool_bwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, (const T *)gy, (T *)gx, B, H, W, Ho, Wo, C / 4)); })
+    return DCF_OK;
+}
+
+extern "C" int dcf_head_fwd(int dtype, const void *head, int Cp, const float *anchors, float *pred, int B, int h, int w,
+                            dcf_stream_t stream)
+{
+    DCF_REQUIRE(head && anchors && pred && Cp >= 20 && Cp % 4 == 0, "dcf_head_fwd: bad arguments (Cp=%d)", Cp);
+    const int hw = h * w;
+    hipStream_t s = S(stream);
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("head_fwd", s, hipLaunchKernelGGL(k_head_fwd<T>, dim3(cdiv((int64_t)B * hw, 256)), dim3(256), 0, s, (const T *)head, Cp, anchors, pred, B, hw)); })
+    return DCF_OK;
+}
+
+extern "C" int dcf_head_bwd(int dtype, const void *head, int Cp, const float *anchors, const float *pred, const float *gpred,
+                            void *ghead, int B, int h, int w, dcf_stream_t stream)
+{
+    (void)head;
+    DCF_REQUIRE(anchors && pred && gpred && ghead && Cp >= 20 && Cp % 4 == 0, "dcf_head_bwd: bad arguments");
+    const int hw = h * w;
+    hipStream_t s = S(stream);
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("head_bwd", s, hipLaunchKernelGGL(k_head_bwd<T>, dim3(cdiv((int64_t)B * hw, 256)), dim3(256), 0, s, Cp, anchors, pred, gpred, (T *)ghead, B, hw)); })
+    return DCF_OK;
+}
+
+extern "C" int dcf_weight_prep(int dtype, const dcf_conv_param *table, int nconv, const float *params, const float *buffers,
+                               void *warena, float *ssarena, float eps, dcf_stream_t stream)
+{
+    DCF_REQUIRE(table && nconv > 0 && params && warena && ssarena, "dcf_weight_prep: bad arguments");
+    hipStream_t s = S(stream);
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("weight_prep", s, hipLaunchKernelGGL(k_weight_prep<T>, dim3(64, nconv), dim3(256), 0, s, table, params, buffers, (char *)warena, ssarena, eps)); })
+    return DCF_OK;
+}
+
+extern "C" int dcf_wgrad_finalize(const dcf_conv_param *table, int nconv, const float *params, const float *buffers,
+                                  const float *ssarena, const float *slabs, const float *gsum, float *grads, float eps,
+                                  dcf_stream_t stream)
+{
+    DCF_REQUIRE(table && nconv > 0 && params && ssarena && slabs && gsum && grads, "dcf_wgrad_finalize: bad arguments");
+    hipStream_t s = S(stream);
+    DCF_LAUNCH("wgrad_finalize", s, hipLaunchKernelGGL(k_wgrad_finalize, dim3(2048, nconv), dim3(256), 0, s, table, params, buffers, ssarena, slabs, gsum, grads, eps));
+    return DCF_OK;
+}
+
+extern "C" int dcf_adam_step(float *params, const float *grads, float *m, float *v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, int step, float gscale, dcf_stream_t stream)
+{
+    DCF_REQUIRE(params && grads && m && v && n >= 0 && step >= 1, "dcf_adam_step: bad arguments");
+    if (n == 0) return DCF_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipStream_t s = S(stream);
+    DCF_LAUNCH("adam", s, hipLaunchKernelGGL(k_adam, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, s, params, grads, m, v, n, (float)(lr / bc1), beta1, beta2,
+                                             (float)(1.0 / sqrt(bc2)), eps, gscale));
+    return DCF_OK;
+}
+
+extern "C" int dcf_cast(int dtype_src, const void *src, int dtype_dst, void *dst, int64_t n, dcf_stream_t stream)
+{
+    DCF_REQUIRE(src && dst && n % 4 == 0, "dcf_cast: n must be a multiple of 4");
+    hipStream_t s = S(stream);
+    const int64_t n4 = n / 4;
+    if (n4 == 0) return DCF_OK;
+    dim3 g(cdiv(n4, 256)), b(256);
+    if (dtype_src == DCF_F32 && dtype_dst == DCF_BF16) DCF_LAUNCH("cast", s, hipLaunchKernelGGL((k_cast<float, bf16_t>), g, b, 0, s, (const float *)src, (bf16_t *)dst, n4));
+    else if (dtype_src == DCF_BF16 && dtype_dst == DCF_F32) DCF_LAUNCH("cast", s, hipLaunchKernelGGL((k_cast<bf16_t, float>), g, b, 0, s, (const bf16_t *)src, (float *)dst, n4));
+    else if (dtype_src == DCF_F32 && dtype_dst == DCF_F32) DCF_LAUNCH("cast", s, hipLaunchKernelGGL((k_cast<float, float>), g, b, 0, s, (const float *)src, (float *)dst, n4));
+    else if (dtype_src == DCF_BF16 && dtype_dst == DCF_BF16) DCF_LAUNCH("cast", s, hipLaunchKernelGGL((k_cast<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t *)src, (bf16_t *)dst, n4));
+    else { dcf_set_error("dcf_cast: unsupported dtype pair"); return DCF_EUNSUPPORTED; }
+    return DCF_OK;
+}
+
+extern "C" int dcf_rowscale_bias_fwd(int dtype, void *y, const float *cnt, const float *b2, int64_t npix, int C, dcf_stream_t stream)
+{
+    DCF_REQUIRE(y && cnt && b2 && C % 4 == 0, "dcf_rowscale_bias_fwd: bad arguments");
+    const int64_t nvec = npix * (C / 4);
+    if (nvec == 0) return DCF_OK;
+    hipStream_t s = S(stream);
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("rowscale_bias_fwd", s, hipLaunchKernelGGL(k_rowscale_bias_fwd<T>, dim3(cdiv(nvec, 256)), dim3(256), 0, s, (T *)y, cnt, b2, nvec, C / 4)); })
+    return DCF_OK;
+}
+
+extern "C" int dcf_rowscale_bias_bwd(int dtype, const void *gy, const float *cnt, float *gb2, int64_t npix, int C, dcf_stream_t stream)
+{
+    DCF_REQUIRE(gy && cnt && gb2 && C % 4 == 0, "dcf_rowscale_bias_bwd: bad arguments");
+    const int cg = C / 4;
+    const int64_t nvec = npix * cg;
+    if (nvec == 0) return DCF_OK;
+    int blocks;
+    const int64_t stride = chan_stride(nvec, cg, blocks);
+    hipStream_t s = S(stream);
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("rowscale_bias_bwd", s, hipLaunchKernelGGL(k_rowscale_bias_bwd<T>, dim3(blocks), dim3(256), sizeof(float) * C, s, (const T *)gy, cnt, gb2, nvec, cg, stride)); })
+    return DCF_OK;
+}

@@ -1,0 +1,242 @@
+// fusion.hip -- the gather/scatter half of the continuous-fusion layer (SURVEY.md App. D;
+// the reference leaves it as a TODO at /root/reference/model.py:199-203).
+//
+// The layer  x_s += sum_k fc2(relu(fc1([F(u_k,v_k); dx,dy,z])))  is evaluated as
+//   (1) fp[n][Cf]  = bilinear sample of the camera map at every valid point   (this file)
+//   (2) P[n][Cb]   = fp . W1f^T                                  (1x1 conv GEMM, conv.hip)
+//   (3) hsum[p][c] = sum_k relu(P[idx_k][c] + W1d[c].(dx,dy,z) + b1[c])        (this file)
+//   (4) x_s       += hsum . W2^T + cnt*b2                        (1x1 conv GEMM + bias row)
+// which is the same arithmetic re-associated: the F-dependent half of fc1 is per POINT, not
+// per (pixel, neighbour), and fc2 is linear so it commutes with the K-sum.  Steps (1),(3)
+// are gathers of whole contiguous channel rows (coalesced 8-16 B per lane); their backward
+// passes are scatter-adds with fp32 atomics.
+#include "dcf_common.h"
+
+namespace {
+
+struct Taps {
+    int x0, x1, y0, y1;
+    float w00, w01, w10, w11;
+};
+
+// ix = u/4 - 0.5, iy = v/4 - 0.5 on the stride-4 map, border clamp (oracle/model_ref.py bilinear_sample)
+__device__ __forceinline__ Taps make_taps(float u, float v, int Hf, int Wf)
+{
+    const float ix = u * 0.25f - 0.5f, iy = v * 0.25f - 0.5f;
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float wx = ix - x0f, wy = iy - y0f;
+    Taps t;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    t.x0 = min(max(x0, 0), Wf - 1); t.x1 = min(max(x0 + 1, 0), Wf - 1);
+    t.y0 = min(max(y0, 0), Hf - 1); t.y1 = min(max(y0 + 1, 0), Hf - 1);
+    t.w00 = (1.f - wy) * (1.f - wx); t.w01 = (1.f - wy) * wx;
+    t.w10 = wy * (1.f - wx); t.w11 = wy * wx;
+    return t;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_point_sample_fwd(const T *fmap, int Hf, int Wf, int C4, const float *uv, const int *count, int n_max, T *fp)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = min(*count, n_max);
+    const int64_t p = e / C4;
+    if (p >= n) return;
+    const int c = (int)(e - p * C4) * 4;
+    const Taps t = make_taps(uv[2 * p], uv[2 * p + 1], Hf, Wf);
+    const int C = C4 * 4;
+    const float4 a = ld4(fmap + ((int64_t)t.y0 * Wf + t.x0) * C + c), b = ld4(fmap + ((int64_t)t.y0 * Wf + t.x1) * C + c);
+    const float4 cc = ld4(fmap + ((int64_t)t.y1 * Wf + t.x0) * C + c), d = ld4(fmap + ((int64_t)t.y1 * Wf + t.x1) * C + c);
+    float4 o;
+    o.x = a.x * t.w00 + b.x * t.w01 + cc.x * t.w10 + d.x * t.w11;
+    o.y = a.y * t.w00 + b.y * t.w01 + cc.y * t.w10 + d.y * t.w11;
+    o.z = a.z * t.w00 + b.z * t.w01 + cc.z * t.w10 + d.z * t.w11;
+    o.w = a.w * t.w00 + b.w * t.w01 + cc.w * t.w10 + d.w * t.w11;
+    st4(fp + e * 4, o);
+}
+
+__device__ __forceinline__ void atomic_add4(float *p, float4 v, float w)
+{
+    atomicAdd(p + 0, v.x * w); atomicAdd(p + 1, v.y * w); atomicAdd(p + 2, v.z * w); atomicAdd(p + 3, v.w * w);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_point_sample_bwd(const T *gfp, int Hf, int Wf, int C4, const float *uv, const int *count, int n_max,
+                                                          float *gfmap)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = min(*count, n_max);
+    const int64_t p = e / C4;
+    if (p >= n) return;
+    const int c = (int)(e - p * C4) * 4;
+    const Taps t = make_taps(uv[2 * p], uv[2 * p + 1], Hf, Wf);
+    const int C = C4 * 4;
+    const float4 g = ld4(gfp + e * 4);
+    atomic_add4(gfmap + ((int64_t)t.y0 * Wf + t.x0) * C + c, g, t.w00);
+    atomic_add4(gfmap + ((int64_t)t.y0 * Wf + t.x1) * C + c, g, t.w01);
+    atomic_add4(gfmap + ((int64_t)t.y1 * Wf + t.x0) * C + c, g, t.w10);
+    atomic_add4(gfmap + ((int64_t)t.y1 * Wf + t.x1) * C + c, g, t.w11);
+}
+
+struct FuseGeom {
+    int h, w, stride, K;
+    float xs, xo, ys, yo;
+};
+
+__device__ __forceinline__ void pixel_centre(const FuseGeom &g, int i, int j, float &X, float &Y)
+{
+    const float s = (float)g.stride;
+    X = __fdiv_rn(__fsub_rn(__fmul_rn((float)i + 0.5f, s), g.xo), g.xs);
+    Y = __fdiv_rn(__fsub_rn(__fmul_rn((float)j + 0.5f, s), g.yo), g.ys);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_fusion_gather_fwd(const T *P, const float *xyz, const int *idx, FuseGeom g, const float *w1d,
+                                                           const float *b1, int C4, T *hsum, float *cnt)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int hw = g.h * g.w;
+    const int64_t p = e / C4;
+    if (p >= hw) return;
+    const int c = (int)(e - p * C4) * 4;
+    const int C = C4 * 4;
+    float X, Y;
+    pixel_centre(g, (int)(p / g.w), (int)(p % g.w), X, Y);
+    float wd[4][3], bb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        wd[q][0] = w1d[(c + q) * 3]; wd[q][1] = w1d[(c + q) * 3 + 1]; wd[q][2] = w1d[(c + q) * 3 + 2];
+        bb[q] = b1[c + q];
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int nv = 0;
+    for (int k = 0; k < g.K; ++k) {
+        const int id = idx[(int64_t)k * hw + p];
+        if (id < 0) continue;
+        ++nv;
+        const float dx = xyz[3 * id] - X, dy = xyz[3 * id + 1] - Y, dz = xyz[3 * id + 2];
+        const float4 pv = ld4(P + (int64_t)id * C + c);
+        const float pp[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float pre = pp[q] + (wd[q][0] * dx + wd[q][1] * dy + wd[q][2] * dz) + bb[q];
+            acc[q] += fmaxf(pre, 0.f);
+        }
+    }
+    st4(hsum + e * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    if (c == 0) cnt[p] = (float)nv;
+}
+
+// backward: thread t owns channel group t % C4 over a grid-stride loop of (pixel, group) items
+template <typename T>
+__global__ void __launch_bounds__(256) k_fusion_gather_bwd(const T *P, const float *xyz, const int *idx, FuseGeom g, const float *w1d,
+                                                           const float *b1, int C4, const T *ghsum, float *gP, float *gw1d, float *gb1,
+                                                           int64_t stride)
+{
+    extern __shared__ float sm[];  // [C][4]: gw1d x3, gb1
+    const int C = C4 * 4;
+    for (int i = threadIdx.x; i < C * 4; i += blockDim.x) sm[i] = 0.f;
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int hw = g.h * g.w;
+    const int64_t nvec = (int64_t)hw * C4;
+    if (t < stride) {
+        const int c = (int)(t % C4) * 4;
+        float wd[4][3], bb[4], aw[4][3], ab[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            wd[q][0] = w1d[(c + q) * 3]; wd[q][1] = w1d[(c + q) * 3 + 1]; wd[q][2] = w1d[(c + q) * 3 + 2];
+            bb[q] = b1[c + q];
+            aw[q][0] = aw[q][1] = aw[q][2] = 0.f; ab[q] = 0.f;
+        }
+        for (int64_t e = t; e < nvec; e += stride) {
+            const int64_t p = e / C4;
+            float X, Y;
+            pixel_centre(g, (int)(p / g.w), (int)(p % g.w), X, Y);
+            const float4 gv = ld4(ghsum + e * 4);
+            const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+            for (int k = 0; k < g.K; ++k) {
+                const int id = idx[(int64_t)k * hw + p];
+                if (id < 0) continue;
+                const float dx = xyz[3 * id] - X, dy = xyz[3 * id + 1] - Y, dz = xyz[3 * id + 2];
+                const float4 pv = ld4(P + (int64_t)id * C + c);
+                const float pp[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float pre = pp[q] + (wd[q][0] * dx + wd[q][1] * dy + wd[q][2] * dz) + bb[q];
+                    const float d = pre > 0.f ? gg[q] : 0.f;
+                    if (d != 0.f) atomicAdd(gP + (int64_t)id * C + c + q, d);
+                    aw[q][0] += d * dx; aw[q][1] += d * dy; aw[q][2] += d * dz; ab[q] += d;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            atomicAdd(&sm[(c + q) * 4 + 0], aw[q][0]);
+            atomicAdd(&sm[(c + q) * 4 + 1], aw[q][1]);
+            atomicAdd(&sm[(c + q) * 4 + 2], aw[q][2]);
+            atomicAdd(&sm[(c + q) * 4 + 3], ab[q]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        atomicAdd(&gw1d[i * 3 + 0], sm[i * 4 + 0]);
+        atomicAdd(&gw1d[i * 3 + 1], sm[i * 4 + 1]);
+        atomicAdd(&gw1d[i * 3 + 2], sm[i * 4 + 2]);
+        atomicAdd(&gb1[i], sm[i * 4 + 3]);
+    }
+}
+
+}  // namespace
+
+// ================================================================== C ABI
+extern "C" int dcf_point_sample_fwd(int dtype, const void *fmap, int Hf, int Wf, int Cf, const float *uv, const int32_t *count_dev,
+                                    int n_max, void *fp, dcf_stream_t stream)
+{
+    DCF_REQUIRE(fmap && uv && count_dev && fp && Cf % 4 == 0, "dcf_point_sample_fwd: bad arguments");
+    if (n_max == 0) return DCF_OK;
+    hipStream_t s = S(stream);
+    const int64_t total = (int64_t)n_max * (Cf / 4);
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("point_sample_fwd", s, hipLaunchKernelGGL(k_point_sample_fwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)fmap, Hf, Wf, Cf / 4, uv, count_dev, n_max, (T *)fp)); })
+    return DCF_OK;
+}
+
+extern "C" int dcf_point_sample_bwd(int dtype, const void *gfp, int Hf, int Wf, int Cf, const float *uv, const int32_t *count_dev,
+                                    int n_max, float *gfmap, dcf_stream_t stream)
+{
+    DCF_REQUIRE(gfp && uv && count_dev && gfmap && Cf % 4 == 0, "dcf_point_sample_bwd: bad arguments");
+    if (n_max == 0) return DCF_OK;
+    hipStream_t s = S(stream);
+    const int64_t total = (int64_t)n_max * (Cf / 4);
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("point_sample_bwd", s, hipLaunchKernelGGL(k_point_sample_bwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)gfp, Hf, Wf, Cf / 4, uv, count_dev, n_max, gfmap)); })
+    return DCF_OK;
+}
+
+extern "C" int dcf_fusion_gather_fwd(int dtype, const void *P, const float *xyz, const int32_t *idx, int K, int h, int w,
+                                     int stride, float xs, float xo, float ys, float yo, const float *w1d, const float *b1,
+                                     int Cb, void *hsum, float *cnt, dcf_stream_t stream)
+{
+    DCF_REQUIRE(P && xyz && idx && w1d && b1 && hsum && cnt && Cb % 4 == 0 && K >= 1, "dcf_fusion_gather_fwd: bad arguments");
+    FuseGeom g;
+    g.h = h; g.w = w; g.stride = stride; g.K = K; g.xs = xs; g.xo = xo; g.ys = ys; g.yo = yo;
+    hipStream_t s = S(stream);
+    const int64_t total = (int64_t)h * w * (Cb / 4);
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("fusion_gather_fwd", s, hipLaunchKernelGGL(k_fusion_gather_fwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)P, xyz, idx, g, w1d, b1, Cb / 4, (T *)hsum, cnt)); })
+    return DCF_OK;
+}
+
+extern "C" int dcf_fusion_gather_bwd(int dtype, const void *P, const float *xyz, const int32_t *idx, int K, int h, int w,
+                                     int stride, float xs, float xo, float ys, float yo, const float *w1d, const float *b1,
+                                     int Cb, const void *ghsum, float *gP, float *gw1d, float *gb1, dcf_stream_t stream)
+{
+    DCF_REQUIRE(P && xyz && idx && w1d && b1 && ghsum && gP && gw1d && gb1 && Cb % 4 == 0, "dcf_fusion_gather_bwd: bad arguments");
+    FuseGeom g;
+    g.h = h; g.w = w; g.stride = stride; g.K = K; g.xs = xs; g.xo = xo; g.ys = ys; g.yo = yo;
+    hipStream_t s = S(stream);
+    const int C4 = Cb / 4;
+    const int64_t nvec = (int64_t)h * w * C4;
+    int64_t want = nvec < 128 * 1024 ? nvec : 128 * 1024;
+    if (want < C4) want = C4;
+    const int64_t stride_t = want / C4 * C4;
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("fusion_gather_bwd", s, hipLaunchKernelGGL(k_fusion_gather_bwd<T>, dim3(cdiv(stride_t, 256)), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, idx, g, w1d, b1, C4, (const T *)ghsum, gP, gw1d, gb1, stride_t)); })
+    return DCF_OK;
+}

@@ -1,0 +1,558 @@
+// geometry.hip -- per-frame geometry kernels: range filter, trilinear voxeliser,
+// pinhole projection + compaction, BEV K-nearest-neighbour.
+//
+// Replaces CarlaDataset.Voxelization_Projection / Projection
+// (/root/reference/data_import_carla.py:196-267), which run on the CPU inside the
+// DataLoader.  All of it is HBM/latency bound integer+fp32 work: one thread per
+// point / per BEV pixel, coalesced SoA-free reads of the [n][3] cloud, atomics only
+// where the algorithm has a real collision (voxel ownership, cell histogram).
+//
+// Bit-exactness contract (checked against oracle/dcf_oracle.c): this file is
+// compiled with -ffp-contract=off and spells every fused step as __fmaf_rn, so each
+// product/sum rounds exactly where the reference's CPU arithmetic rounds.
+#include "dcf_common.h"
+
+namespace {
+
+struct Lim6 { float v[6]; };
+struct Aff6 { float v[6]; };
+struct Crt12 { float v[12]; };
+
+__device__ __forceinline__ bool in_range(float x, float y, float z, const Lim6 &l)
+{
+    return x > l.v[0] && x < l.v[1] && y > l.v[2] && y < l.v[3] && z > l.v[4] && z < l.v[5];
+}
+
+// ------------------------------------------------------------------------------
+// Order-preserving compaction: count -> scan -> scatter.  1024 items per block.
+// ------------------------------------------------------------------------------
+constexpr int CP_THREADS = 256;
+constexpr int CP_ITEMS = 4;
+constexpr int CP_TILE = CP_THREADS * CP_ITEMS;
+
+// block-wide exclusive scan of one int per thread (256 threads = 4 waves); returns
+// the exclusive prefix and writes the block total to *total (valid in all threads).
+__device__ __forceinline__ int block_excl_scan(int v, int *total)
+{
+    __shared__ int wsum[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int s = wsum[i];
+        if (i < wid) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+struct RangePred {
+    Lim6 lim;
+    __device__ bool operator()(const float *pts, int i, float *u, float *v) const
+    {
+        return in_range(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], lim);
+    }
+};
+
+// data_import_carla.py:196-205 on top of the range filter of :215-226
+struct ProjPred {
+    Lim6 lim;
+    Crt12 c;
+    float ulim, vlim;
+    int mode;
+    __device__ bool operator()(const float *pts, int i, float *u, float *v) const
+    {
+        const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        if (!in_range(x, y, z, lim)) return false;
+        float a[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float t = __fmul_rn(x, c.v[j]);       // the reference's K=4 sgemm chain
+            t = __fmaf_rn(y, c.v[3 + j], t);
+            t = __fmaf_rn(z, c.v[6 + j], t);
+            t = __fmaf_rn(1.0f, c.v[9 + j], t);
+            a[j] = t;
+        }
+        const float uu = __fdiv_rn(a[0], a[2]), vv = __fdiv_rn(a[1], a[2]);
+        *u = uu;
+        *v = vv;
+        bool keep = uu > 0.0f && uu < ulim && vv > 0.0f && vv < vlim;
+        if (mode == DCF_PROJ_CORRECT) keep = keep && a[2] > 0.0f;
+        return keep;
+    }
+};
+
+template <class Pred>
+__global__ void __launch_bounds__(CP_THREADS) k_compact_count(const float *pts, int n, Pred pred, int *blocksum)
+{
+    const int base = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS;
+    int c = 0;
+    float u, v;
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k) {
+        int i = base + k;
+        if (i < n && pred(pts, i, &u, &v)) ++c;
+    }
+    int tot;
+    block_excl_scan(c, &tot);
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of nb block sums in place; total -> *count
+__global__ void __launch_bounds__(CP_THREADS) k_compact_scan(int *blocksum, int nb, int *count)
+{
+    int carry = 0;
+    for (int b0 = 0; b0 < nb; b0 += CP_THREADS) {
+        int i = b0 + threadIdx.x;
+        int v = i < nb ? blocksum[i] : 0;
+        int tot;
+        int ex = block_excl_scan(v, &tot);
+        if (i < nb) blocksum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *count = carry;
+}
+
+template <class Pred, bool EMIT_UV>
+__global__ void __launch_bounds__(CP_THREADS) k_compact_scatter(const float *pts, int n, Pred pred, const int *blockoff,
+                                                                float *out_uv, float *out_xyz, int *out_src)
+{
+    const int base = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS;
+    bool keep[CP_ITEMS];
+    float u[CP_ITEMS], v[CP_ITEMS];
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k) {
+        int i = base + k;
+        keep[k] = (i < n) && pred(pts, i, &u[k], &v[k]);
+        c += keep[k] ? 1 : 0;
+    }
+    int tot;
+    int pos = blockoff[blockIdx.x] + block_excl_scan(c, &tot);
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k) {
+        if (keep[k]) {
+            int i = base + k;
+            out_xyz[3 * pos] = pts[3 * i];
+            out_xyz[3 * pos + 1] = pts[3 * i + 1];
+            out_xyz[3 * pos + 2] = pts[3 * i + 2];
+            if (EMIT_UV) {
+                out_uv[2 * pos] = u[k];
+                out_uv[2 * pos + 1] = v[k];
+            }
+            if (out_src) out_src[pos] = i;
+            ++pos;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------
+// Voxeliser.  data_import_carla.py:236-258.
+// ------------------------------------------------------------------------------
+struct Corner8 {
+    int vox[8];
+    float w[8];
+};
+
+// index affine = fl(fl(p*scale)+offset)  (the sgemm chain on the sparse 4x3 matrix)
+__device__ __forceinline__ void corners(float x, float y, float z, const Aff6 &a, int L, int W, Corner8 &o)
+{
+    const float fx = __fadd_rn(__fmul_rn(x, a.v[0]), a.v[1]);
+    const float fy = __fadd_rn(__fmul_rn(y, a.v[2]), a.v[3]);
+    const float fz = __fadd_rn(__fmul_rn(z, a.v[4]), a.v[5]);
+    const int xl = (int)fx, yl = (int)fy, zl = (int)fz;  // trunc, like .type(torch.long)
+    const float dx = __fsub_rn(fx, (float)xl), dy = __fsub_rn(fy, (float)yl), dz = __fsub_rn(fz, (float)zl);
+    const float ax = __fsub_rn(1.0f, dx), ay = __fsub_rn(1.0f, dy), az = __fsub_rn(1.0f, dz);
+    const float pxy[4] = {__fmul_rn(ax, ay), __fmul_rn(dx, ay), __fmul_rn(ax, dy), __fmul_rn(dx, dy)};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int zz = zl + (c & 1), xx = xl + ((c >> 1) & 1), yy = yl + ((c >> 2) & 1);
+        o.vox[c] = (zz * L + xx) * W + yy;
+        o.w[c] = __fmul_rn(pxy[c >> 1], (c & 1) ? dz : az);
+    }
+}
+
+// Round r (0..8) of the compat voxeliser: resolve pass r-1, claim pass r.
+// owner[parity][voxel] holds (highest claiming point index + 1), 0 = unclaimed.
+__global__ void __launch_bounds__(256) k_voxel_compat_round(const float *pts, int n, Lim6 lim, Aff6 aff, int L, int W,
+                                                            int nvox, int round, float *grid, int *owner)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    if (!in_range(x, y, z, lim)) return;
+    Corner8 c8;
+    corners(x, y, z, aff, L, W, c8);
+    if (round >= 1) {
+        const int c = round - 1;
+        int *ow = owner + (size_t)(c & 1) * nvox;
+        const int v = c8.vox[c];
+        if (ow[v] == i + 1) {  // this point is the last writer of pass c
+            grid[v] = __fadd_rn(grid[v], c8.w[c]);
+            ow[v] = 0;
+        }
+    }
+    if (round <= 7) {
+        int *ow = owner + (size_t)(round & 1) * nvox;
+        atomicMax(&ow[c8.vox[round]], i + 1);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_voxel_accum(const float *pts, int n, Lim6 lim, Aff6 aff, int L, int W, float *grid)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    if (!in_range(x, y, z, lim)) return;
+    Corner8 c8;
+    corners(x, y, z, aff, L, W, c8);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) atomicAdd(&grid[c8.vox[c]], c8.w[c]);
+}
+
+// ------------------------------------------------------------------------------
+// BEV KNN.  Points are counting-sorted into the stride-s BEV cells (8x8-blocked cell
+// order so that a coarse block's points are one contiguous range), then every BEV
+// pixel searches fine rings first and coarse block rings when the neighbourhood is
+// sparse.  Result = K smallest by (d2, index) -- independent of visiting order.
+// ------------------------------------------------------------------------------
+struct KnnGrid {
+    int h, w, h8, w8, stride;
+    float xs, xo, ys, yo;
+};
+
+__device__ __forceinline__ int cell_key(int ci, int cj, const KnnGrid &g)
+{
+    return (((ci >> 3) * g.w8 + (cj >> 3)) << 6) + ((ci & 7) << 3) + (cj & 7);
+}
+
+__device__ __forceinline__ void point_cell(float x, float y, const KnnGrid &g, int &ci, int &cj)
+{
+    const float fx = __fadd_rn(__fmul_rn(x, g.xs), g.xo), fy = __fadd_rn(__fmul_rn(y, g.ys), g.yo);
+    ci = (int)floorf(fx / (float)g.stride);
+    cj = (int)floorf(fy / (float)g.stride);
+    ci = min(max(ci, 0), g.h - 1);
+    cj = min(max(cj, 0), g.w - 1);
+}
+
+__global__ void __launch_bounds__(256) k_knn_hist(const float *xyz, const int *count, int n_max, KnnGrid g, int *cellcnt,
+                                                  int *pkey)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = min(*count, n_max);
+    if (i >= n) return;
+    int ci, cj;
+    point_cell(xyz[3 * i], xyz[3 * i + 1], g, ci, cj);
+    const int key = cell_key(ci, cj, g);
+    pkey[i] = key;
+    atomicAdd(&cellcnt[key], 1);
+}
+
+// generic multi-block exclusive scan over ints (count -> start), 3 phases
+__global__ void __launch_bounds__(CP_THREADS) k_scan_blocksum(const int *in, int n, int *blocksum)
+{
+    const int base = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k)
+        if (base + k < n) c += in[base + k];
+    int tot;
+    block_excl_scan(c, &tot);
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(CP_THREADS) k_scan_apply(const int *in, int n, const int *blockoff, int *out, int *cursor)
+{
+    const int base = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS;
+    int v[CP_ITEMS];
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        c += v[k];
+    }
+    int tot;
+    int pos = blockoff[blockIdx.x] + block_excl_scan(c, &tot);
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k) {
+        if (base + k < n) {
+            out[base + k] = pos;
+            cursor[base + k] = pos;
+            pos += v[k];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_knn_fill(const float *xyz, const int *count, int n_max, const int *pkey, int *cursor,
+                                                  float4 *sorted)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = min(*count, n_max);
+    if (i >= n) return;
+    const int pos = atomicAdd(&cursor[pkey[i]], 1);
+    sorted[pos] = make_float4(xyz[3 * i], xyz[3 * i + 1], __int_as_float(i), 0.f);
+}
+
+template <int K>
+struct TopK {
+    float d[K];
+    int id[K];
+    int cnt;
+    __device__ __forceinline__ void clear()
+    {
+        cnt = 0;
+#pragma unroll
+        for (int q = 0; q < K; ++q) { d[q] = 3.0e38f; id[q] = 0x7fffffff; }
+    }
+    __device__ __forceinline__ float kth() const { return d[K - 1]; }
+    __device__ __forceinline__ bool full() const { return cnt >= K; }
+    // insert keeping ascending (d2, index); fully unrolled bubble from the tail
+    __device__ __forceinline__ void insert(float dd, int ii)
+    {
+        if (!(dd < d[K - 1] || (dd == d[K - 1] && ii < id[K - 1]))) return;
+        d[K - 1] = dd;
+        id[K - 1] = ii;
+#pragma unroll
+        for (int q = K - 1; q > 0; --q) {
+            const bool sw = (d[q] < d[q - 1]) || (d[q] == d[q - 1] && id[q] < id[q - 1]);
+            if (sw) {
+                float td = d[q]; d[q] = d[q - 1]; d[q - 1] = td;
+                int ti = id[q]; id[q] = id[q - 1]; id[q - 1] = ti;
+            }
+        }
+        if (cnt < K) ++cnt;
+    }
+};
+
+template <int K>
+__global__ void __launch_bounds__(256) k_knn_search(const int *count, int n_max, KnnGrid g, const int *cellstart,
+                                                    const float4 *sorted, float rmax2, int *out)
+{
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= g.h * g.w) return;
+    const int i = pix / g.w, j = pix % g.w;
+    const float s = (float)g.stride;
+    const float X = __fdiv_rn(__fsub_rn(__fmul_rn((float)i + 0.5f, s), g.xo), g.xs);
+    const float Y = __fdiv_rn(__fsub_rn(__fmul_rn((float)j + 0.5f, s), g.yo), g.ys);
+    const float cwx = s / g.xs, cwy = s / g.ys;       // metric size of one cell
+    const float cwmin = fminf(cwx, cwy);
+    const int n = min(*count, n_max);
+
+    TopK<K> top;
+    top.clear();
+    bool done = (n == 0);
+
+    auto scan_range = [&](int b, int e) {
+        for (int p = b; p < e; ++p) {
+            const float4 q = sorted[p];
+            const float dx = __fsub_rn(q.x, X), dy = __fsub_rn(q.y, Y);
+            const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+            if (rmax2 >= 0.0f && d2 > rmax2) continue;
+            top.insert(d2, __float_as_int(q.z));
+        }
+    };
+
+    // ---- phase A: fine rings 0..2 around the pixel's own cell
+    constexpr int RA = 2;
+    if (!done) {
+        for (int r = 0; r <= RA && !done; ++r) {
+            for (int a = -r; a <= r; ++a) {
+                const int ci = i + a;
+                if (ci < 0 || ci >= g.h) continue;
+                const bool edge = (a == -r || a == r);
+                for (int b = -r; b <= r; b += (edge ? 1 : 2 * r)) {
+                    const int cj = j + b;
+                    if (cj >= 0 && cj < g.w) {
+                        const int key = cell_key(ci, cj, g);
+                        scan_range(cellstart[key], cellstart[key + 1]);
+                    }
+                    if (r == 0) break;
+                }
+            }
+            // every unvisited point is farther than (r+0.5) cells (1 mm safety margin)
+            const float bound = ((float)r + 0.5f) * cwmin - 1e-3f;
+            if (top.full() && top.kth() < bound * bound) done = true;
+            if (rmax2 >= 0.0f && bound > 0.f && bound * bound > rmax2) done = true;
+        }
+    }
+    // ---- phase B: coarse 8x8-block rings (restart: visiting order does not matter)
+    if (!done) {
+        top.clear();
+        const int I = i >> 3, J = j >> 3;
+        const int Rmax = max(g.h8, g.w8);
+        for (int R = 0; R <= Rmax && !done; ++R) {
+            for (int a = -R; a <= R; ++a) {
+                const int bi = I + a;
+                if (bi < 0 || bi >= g.h8) continue;
+                const bool edge = (a == -R || a == R);
+                for (int b = -R; b <= R; b += (edge ? 1 : 2 * R)) {
+                    const int bj = J + b;
+                    if (bj >= 0 && bj < g.w8) {
+                        const int k0 = (bi * g.w8 + bj) << 6;
+                        const int ps = cellstart[k0], pe = cellstart[k0 + 64];
+                        if (pe > ps) {
+                            bool visit = true;
+                            if (top.full()) {  // prune by the block's metric bounding box
+                                const float lox = ((float)(bi * 8) * s - g.xo) / g.xs, hix = ((float)(bi * 8 + 8) * s - g.xo) / g.xs;
+                                const float loy = ((float)(bj * 8) * s - g.yo) / g.ys, hiy = ((float)(bj * 8 + 8) * s - g.yo) / g.ys;
+                                const float ddx = fmaxf(0.f, fmaxf(lox - X, X - hix) - 1e-3f);
+                                const float ddy = fmaxf(0.f, fmaxf(loy - Y, Y - hiy) - 1e-3f);
+                                visit = (ddx * ddx + ddy * ddy) <= top.kth();
+                            }
+                            if (visit) scan_range(ps, pe);
+                        }
+                    }
+                    if (R == 0) break;
+                }
+            }
+            const float bound = (8.0f * (float)R + 0.5f) * cwmin - 1e-3f;
+            if (top.full() && top.kth() < bound * bound) done = true;
+            if (rmax2 >= 0.0f && bound * bound > rmax2) done = true;
+        }
+    }
+    const int hw = g.h * g.w;
+#pragma unroll
+    for (int q = 0; q < K; ++q) out[q * hw + pix] = (q < top.cnt) ? top.id[q] : -1;
+}
+
+}  // namespace
+
+// ================================================================== C ABI
+extern "C" size_t dcf_compact_workspace_bytes(int n) { return sizeof(int) * (size_t)(cdiv(n > 0 ? n : 1, CP_TILE) + 8); }
+
+extern "C" int dcf_range_filter(const float *pts, int n, const float *lim, float *out_pts, int32_t *out_src,
+                                int32_t *count_dev, void *ws, dcf_stream_t stream)
+{
+    DCF_REQUIRE(n >= 0 && lim && count_dev && ws, "dcf_range_filter: bad arguments");
+    hipStream_t s = S(stream);
+    if (n == 0) { DCF_HIP(hipMemsetAsync(count_dev, 0, sizeof(int), s)); return DCF_OK; }
+    RangePred p;
+    memcpy(p.lim.v, lim, sizeof(p.lim.v));
+    int nb = cdiv(n, CP_TILE);
+    int *bs = (int *)ws;
+    DCF_LAUNCH("compact_count", s, hipLaunchKernelGGL(k_compact_count<RangePred>, dim3(nb), dim3(CP_THREADS), 0, s, pts, n, p, bs));
+    DCF_LAUNCH("compact_scan", s, hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(CP_THREADS), 0, s, bs, nb, count_dev));
+    DCF_LAUNCH("compact_scatter", s, hipLaunchKernelGGL((k_compact_scatter<RangePred, false>), dim3(nb), dim3(CP_THREADS), 0, s, pts, n, p, bs,
+                                                         (float *)nullptr, out_pts, out_src));
+    return DCF_OK;
+}
+
+extern "C" int dcf_project_filter(const float *pts, int n, const float *lim, const float *crt, float ulim, float vlim,
+                                  int mode, float *uv_out, float *xyz_out, int32_t *src_out, int32_t *count_dev,
+                                  void *ws, dcf_stream_t stream)
+{
+    DCF_REQUIRE(n >= 0 && lim && crt && count_dev && ws && uv_out && xyz_out, "dcf_project_filter: bad arguments");
+    hipStream_t s = S(stream);
+    if (n == 0) { DCF_HIP(hipMemsetAsync(count_dev, 0, sizeof(int), s)); return DCF_OK; }
+    ProjPred p;
+    memcpy(p.lim.v, lim, sizeof(p.lim.v));
+    memcpy(p.c.v, crt, sizeof(p.c.v));
+    p.ulim = ulim; p.vlim = vlim; p.mode = mode;
+    int nb = cdiv(n, CP_TILE);
+    int *bs = (int *)ws;
+    DCF_LAUNCH("project_count", s, hipLaunchKernelGGL(k_compact_count<ProjPred>, dim3(nb), dim3(CP_THREADS), 0, s, pts, n, p, bs));
+    DCF_LAUNCH("compact_scan", s, hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(CP_THREADS), 0, s, bs, nb, count_dev));
+    DCF_LAUNCH("project_scatter", s, hipLaunchKernelGGL((k_compact_scatter<ProjPred, true>), dim3(nb), dim3(CP_THREADS), 0, s, pts, n, p, bs,
+                                                         uv_out, xyz_out, src_out));
+    return DCF_OK;
+}
+
+extern "C" size_t dcf_voxelize_workspace_bytes(int Cz, int L, int W) { return sizeof(int) * 2 * (size_t)Cz * L * W; }
+
+extern "C" int dcf_voxelize(const float *pts, int n, const float *lim, const float *aff, int Cz, int L, int W,
+                            int mode, float *grid, void *owner_ws, dcf_stream_t stream)
+{
+    DCF_REQUIRE(n >= 0 && lim && aff && grid && Cz > 0 && L > 0 && W > 0, "dcf_voxelize: bad arguments");
+    DCF_REQUIRE((int64_t)Cz * L * W < (1ll << 31), "dcf_voxelize: grid too large for int32 voxel ids");
+    hipStream_t s = S(stream);
+    const int nvox = Cz * L * W;
+    DCF_HIP(hipMemsetAsync(grid, 0, sizeof(float) * (size_t)nvox, s));
+    if (n == 0) return DCF_OK;
+    Lim6 l; Aff6 a;
+    memcpy(l.v, lim, sizeof(l.v));
+    memcpy(a.v, aff, sizeof(a.v));
+    const int nb = cdiv(n, 256);
+    if (mode == DCF_VOXEL_COMPAT) {
+        DCF_REQUIRE(owner_ws != nullptr, "dcf_voxelize: compat mode needs the zeroed owner workspace");
+        for (int r = 0; r <= 8; ++r)
+            DCF_LAUNCH("voxel_compat_round", s, hipLaunchKernelGGL(k_voxel_compat_round, dim3(nb), dim3(256), 0, s, pts, n, l, a, L, W, nvox, r,
+                                                                   grid, (int *)owner_ws));
+    } else if (mode == DCF_VOXEL_ACCUM) {
+        DCF_LAUNCH("voxel_accum", s, hipLaunchKernelGGL(k_voxel_accum, dim3(nb), dim3(256), 0, s, pts, n, l, a, L, W, grid));
+    } else {
+        dcf_set_error("dcf_voxelize: unknown mode %d", mode);
+        return DCF_EINVAL;
+    }
+    return DCF_OK;
+}
+
+static inline void knn_dims(int h, int w, int &h8, int &w8, int &ncell) { h8 = (h + 7) / 8; w8 = (w + 7) / 8; ncell = h8 * w8 * 64; }
+
+// workspace layout (ints): cellcnt[ncell+1] | cellstart[ncell+1] | cursor[ncell+1] | blocksum[nb+8] | pkey[n_max] | sorted float4[n_max]
+extern "C" size_t dcf_knn_workspace_bytes(int n_max, int h, int w)
+{
+    int h8, w8, ncell;
+    knn_dims(h, w, h8, w8, ncell);
+    size_t ints = 3 * (size_t)(ncell + 1) + (size_t)cdiv(ncell + 1, CP_TILE) + 8 + (size_t)n_max;
+    ints = (ints + 3) & ~(size_t)3;
+    return ints * sizeof(int) + sizeof(float4) * (size_t)n_max + 64;
+}
+
+extern "C" int dcf_knn_bev(const float *xyz, const int32_t *count_dev, int n_max, int K, int h, int w, int stride,
+                           float xs, float xo, float ys, float yo, float rmax2, int32_t *idx_out, void *ws,
+                           dcf_stream_t stream)
+{
+    DCF_REQUIRE(xyz && count_dev && idx_out && ws, "dcf_knn_bev: null pointer");
+    DCF_REQUIRE(K >= 1 && K <= 8, "dcf_knn_bev: K must be 1..8 (got %d)", K);
+    DCF_REQUIRE(h > 0 && w > 0 && stride > 0 && n_max >= 0, "dcf_knn_bev: bad dims");
+    hipStream_t s = S(stream);
+    KnnGrid g;
+    g.h = h; g.w = w; g.stride = stride; g.xs = xs; g.xo = xo; g.ys = ys; g.yo = yo;
+    int ncell;
+    knn_dims(h, w, g.h8, g.w8, ncell);
+    const int nscan = ncell + 1;
+    const int nsb = cdiv(nscan, CP_TILE);
+    int *cellcnt = (int *)ws;
+    int *cellstart = cellcnt + nscan;
+    int *cursor = cellstart + nscan;
+    int *blocksum = cursor + nscan;
+    int *pkey = blocksum + nsb + 8;
+    size_t ints = 3 * (size_t)nscan + (size_t)nsb + 8 + (size_t)n_max;
+    ints = (ints + 3) & ~(size_t)3;
+    float4 *sorted = (float4 *)((char *)ws + ints * sizeof(int));
+    DCF_HIP(hipMemsetAsync(cellcnt, 0, sizeof(int) * (size_t)nscan, s));
+    if (n_max > 0) {
+        const int nb = cdiv(n_max, 256);
+        DCF_LAUNCH("knn_hist", s, hipLaunchKernelGGL(k_knn_hist, dim3(nb), dim3(256), 0, s, xyz, count_dev, n_max, g, cellcnt, pkey));
+    }
+    int *total = blocksum + nsb;  // scratch int for the scan total
+    DCF_LAUNCH("scan_blocksum", s, hipLaunchKernelGGL(k_scan_blocksum, dim3(nsb), dim3(CP_THREADS), 0, s, cellcnt, nscan, blocksum));
+    DCF_LAUNCH("compact_scan", s, hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(CP_THREADS), 0, s, blocksum, nsb, total));
+    DCF_LAUNCH("scan_apply", s, hipLaunchKernelGGL(k_scan_apply, dim3(nsb), dim3(CP_THREADS), 0, s, cellcnt, nscan, blocksum, cellstart, cursor));
+    if (n_max > 0) {
+        const int nb = cdiv(n_max, 256);
+        DCF_LAUNCH("knn_fill", s, hipLaunchKernelGGL(k_knn_fill, dim3(nb), dim3(256), 0, s, xyz, count_dev, n_max, pkey, cursor, sorted));
+    }
+    const int npix = h * w;
+    const int nbp = cdiv(npix, 256);
+#define KNN_CASE(KK)                                                                                                     \
+    case KK:                                                                                                             \
+        DCF_LAUNCH("knn_search", s, hipLaunchKernelGGL(k_knn_search<KK>, dim3(nbp), dim3(256), 0, s, count_dev, n_max, g, \
+                                                       cellstart, sorted, rmax2, idx_out));                              \
+        break;
+    switch (K) {
+        KNN_CASE(1) KNN_CASE(2) KNN_CASE(3) KNN_CASE(4) KNN_CASE(5) KNN_CASE(6) KNN_CASE(7) KNN_CASE(8)
+    }
+#undef KNN_CASE
+    return DCF_OK;
+}

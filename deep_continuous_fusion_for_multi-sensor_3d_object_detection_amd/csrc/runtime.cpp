@@ -1,0 +1,122 @@
+// runtime.cpp -- error text, version and the optional event-timing layer of libdcf_hip.so.
+#include <stdarg.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "dcf_common.h"
+
+static thread_local char g_err[512] = "";
+
+void dcf_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *dcf_last_error(void) { return g_err; }
+extern "C" int dcf_version(void) { return 100; }
+
+// ------------------------------------------------------------------ profiling
+// HIP events recorded on the launch stream around every DCF_LAUNCH while enabled.
+// Elapsed times are only read in dcf_prof_read (which synchronises the events);
+// nothing here runs unless the bench explicitly turns it on.
+int g_dcf_prof_on = 0;
+
+namespace {
+struct Rec {
+    int name_id;
+    hipEvent_t a, b;
+};
+std::mutex g_mu;
+std::vector<std::string> g_names;
+std::map<std::string, int> g_name_id;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t g_cur_a;
+int g_cur_name = -1;
+
+hipEvent_t get_event()
+{
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+void dcf_prof_begin(const char *name, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_name_id.find(name);
+    int id;
+    if (it == g_name_id.end()) {
+        id = (int)g_names.size();
+        g_names.push_back(name);
+        g_name_id[name] = id;
+    } else {
+        id = it->second;
+    }
+    g_cur_name = id;
+    g_cur_a = get_event();
+    (void)hipEventRecord(g_cur_a, s);
+}
+
+void dcf_prof_end(hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    hipEvent_t b = get_event();
+    (void)hipEventRecord(b, s);
+    g_recs.push_back(Rec{g_cur_name, g_cur_a, b});
+}
+
+extern "C" int dcf_prof_enable(int on)
+{
+    g_dcf_prof_on = on ? 1 : 0;
+    return DCF_OK;
+}
+
+extern "C" int dcf_prof_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &r : g_recs) {
+        (void)hipEventSynchronize(r.b);
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
+    }
+    g_recs.clear();
+    return DCF_OK;
+}
+
+extern "C" int dcf_prof_read(char *names, double *total_ms, int64_t *calls, int cap)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = (int)g_names.size();
+    std::vector<double> tot(n, 0.0);
+    std::vector<int64_t> cnt(n, 0);
+    for (auto &r : g_recs) {
+        (void)hipEventSynchronize(r.b);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        tot[r.name_id] += ms;
+        cnt[r.name_id] += 1;
+    }
+    int k = 0;
+    for (int i = 0; i < n && k < cap; ++i) {
+        if (cnt[i] == 0) continue;
+        strncpy(names + (size_t)k * 64, g_names[i].c_str(), 63);
+        names[(size_t)k * 64 + 63] = 0;
+        total_ms[k] = tot[i];
+        calls[k] = cnt[i];
+        ++k;
+    }
+    return k;
+}

@@ -1,0 +1,260 @@
+"""Operator layer: one Python function per C-ABI entry point of libdcf_hip.so.
+
+Each function takes torch CUDA tensors (NHWC activations, compute dtype f32 or bf16),
+allocates the output with torch (device memory = plumbing) and enqueues the HIP kernel on
+torch's current stream.  No arithmetic happens in torch here.
+"""
+import numpy as np
+import torch
+
+from . import _hip as H
+
+
+def _chk(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous()):
+        raise H.DcfError("%s must be a contiguous CUDA tensor" % name)
+    return t
+
+
+def conv_out_size(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+# ------------------------------------------------------------------ layout
+def nchw_to_nhwc(x, dtype):
+    B, C, Hh, W = x.shape
+    _chk(x, "x")
+    y = torch.empty((B, Hh, W, C), dtype=H.torch_dtype(dtype), device=x.device)
+    H.call("dcf_nchw_to_nhwc", dtype, x, y, B, C, Hh, W, H.stream_ptr())
+    return y
+
+
+def image_to_nhwc4(img_u8, dtype):
+    B, C, Hh, W = img_u8.shape
+    assert C == 3 and img_u8.dtype == torch.uint8
+    _chk(img_u8, "image")
+    y = torch.empty((B, Hh + 6, W + 8, 4), dtype=H.torch_dtype(dtype), device=img_u8.device)
+    H.call("dcf_image_to_nhwc4", dtype, img_u8, y, B, Hh, W, H.stream_ptr())
+    return y
+
+
+# ------------------------------------------------------------------ convolution
+def conv2d_fwd(dtype, x, w, shift, res, kh, kw, stride, pad, relu, cout):
+    B, Hh, W, Cin = x.shape
+    Ho, Wo = conv_out_size(Hh, kh, stride, pad), conv_out_size(W, kw, stride, pad)
+    y = torch.empty((B, Ho, Wo, cout), dtype=x.dtype, device=x.device)
+    H.call("dcf_conv2d_fwd", dtype, x, w, shift, res, y, B, Hh, W, Cin, Ho, Wo, cout, kh, kw, stride, pad, int(relu),
+           H.stream_ptr())
+    return y
+
+
+def conv2d_dgrad(dtype, gy, wt, res, in_shape, kh, kw, stride, pad):
+    B, Hh, W, Cin = in_shape
+    _, Ho, Wo, Cout = gy.shape
+    gx = torch.empty((B, Hh, W, Cin), dtype=gy.dtype, device=gy.device)
+    H.call("dcf_conv2d_dgrad", dtype, gy, wt, res, gx, B, Hh, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, H.stream_ptr())
+    return gx
+
+
+def conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, kh, kw):
+    return H.lib().dcf_conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, kh, kw)
+
+
+def conv2d_wgrad(dtype, x, gy, slabs, nsplit, kh, kw, stride, pad):
+    B, Hh, W, Cin = x.shape
+    _, Ho, Wo, Cout = gy.shape
+    H.call("dcf_conv2d_wgrad", dtype, x, gy, slabs, nsplit, B, Hh, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, H.stream_ptr())
+    return slabs
+
+
+def stem7x7_fwd(dtype, img4, w, shift, relu, cout, Hh, W):
+    B = img4.shape[0]
+    Ho, Wo = conv_out_size(Hh, 7, 2, 3), conv_out_size(W, 7, 2, 3)
+    y = torch.empty((B, Ho, Wo, cout), dtype=img4.dtype, device=img4.device)
+    H.call("dcf_stem7x7_fwd", dtype, img4, w, shift, y, B, Hh, W, Ho, Wo, cout, int(relu), H.stream_ptr())
+    return y
+
+
+def stem7x7_wgrad(dtype, img4, gy, slabs, nsplit, Hh, W):
+    B, Ho, Wo, Cout = gy.shape
+    H.call("dcf_stem7x7_wgrad", dtype, img4, gy, slabs, nsplit, B, Hh, W, Ho, Wo, Cout, H.stream_ptr())
+    return slabs
+
+
+# ------------------------------------------------------------------ elementwise
+def relu_bwd_chansum(dtype, gy, y, gsum, relu=True):
+    C = gy.shape[-1]
+    npix = gy.numel() // C
+    H.call("dcf_relu_bwd_chansum", dtype, gy, y if relu else None, gsum, npix, C, int(relu), H.stream_ptr())
+    return gy
+
+
+def resize_bilinear_fwd(dtype, x, out_hw, align_corners, add=None):
+    B, Hi, Wi, C = x.shape
+    Ho, Wo = out_hw
+    y = torch.empty((B, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    H.call("dcf_resize_bilinear_fwd", dtype, x, add, y, B, Hi, Wi, Ho, Wo, C, int(align_corners), H.stream_ptr())
+    return y
+
+
+def resize_bilinear_bwd(dtype, gy, in_hw, align_corners):
+    B, Ho, Wo, C = gy.shape
+    Hi, Wi = in_hw
+    gx = torch.empty((B, Hi, Wi, C), dtype=gy.dtype, device=gy.device)
+    H.call("dcf_resize_bilinear_bwd", dtype, gy, gx, B, Hi, Wi, Ho, Wo, C, int(align_corners), H.stream_ptr())
+    return gx
+
+
+def maxpool_fwd(dtype, x):
+    B, Hh, W, C = x.shape
+    Ho, Wo = (Hh - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((B, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    H.call("dcf_maxpool3x3s2_fwd", dtype, x, y, B, Hh, W, Ho, Wo, C, H.stream_ptr())
+    return y
+
+
+def maxpool_bwd(dtype, x, y, gy):
+    B, Hh, W, C = x.shape
+    _, Ho, Wo, _ = gy.shape
+    gx = torch.empty_like(x)
+    H.call("dcf_maxpool3x3s2_bwd", dtype, x, y, gy, gx, B, Hh, W, Ho, Wo, C, H.stream_ptr())
+    return gx
+
+
+def head_fwd(dtype, head, anchors):
+    B, h, w, Cp = head.shape
+    pred = torch.empty((B, 32, h, w), dtype=torch.float32, device=head.device)
+    H.call("dcf_head_fwd", dtype, head, Cp, anchors, pred, B, h, w, H.stream_ptr())
+    return pred
+
+
+def head_bwd(dtype, head, anchors, pred, gpred):
+    B, h, w, Cp = head.shape
+    ghead = torch.empty_like(head)
+    H.call("dcf_head_bwd", dtype, head, Cp, anchors, pred, _chk(gpred, "gpred"), ghead, B, h, w, H.stream_ptr())
+    return ghead
+
+
+def cast(src, dtype_dst):
+    dst = torch.empty(src.shape, dtype=H.torch_dtype(dtype_dst), device=src.device)
+    H.call("dcf_cast", H.dtype_code(src.dtype), src, dtype_dst, dst, src.numel(), H.stream_ptr())
+    return dst
+
+
+def adam_step(params, grads, m, v, lr, beta1, beta2, eps, step, gscale=1.0):
+    H.call("dcf_adam_step", params, grads, m, v, params.numel(), lr, beta1, beta2, eps, step, gscale, H.stream_ptr())
+
+
+# ------------------------------------------------------------------ geometry
+class GridSpec(object):
+    """Grid constants of CarlaDataset.__init__ (data_import_carla.py:35-43) and the filter
+    thresholds of :215-226 -- host-side integer arithmetic only."""
+
+    def __init__(self, cfg):
+        L, W, Cz = cfg["voxel_length"], cfg["voxel_width"], cfg["voxel_channel"]
+        self.dims = (Cz, L, W)
+        self.xs = int(L / (cfg["lidar_x_max"] - cfg["lidar_x_min"]))
+        self.ys = int(W / (cfg["lidar_y_max"] - cfg["lidar_y_min"]))
+        self.zs = int(Cz / (cfg["lidar_z_max"] - cfg["lidar_z_min"]))
+        self.xo = int(-cfg["lidar_x_min"] * self.xs)
+        self.yo = int(-cfg["lidar_y_min"] * self.ys)
+        self.zo = int(-cfg["lidar_z_min"] * self.zs)
+        d = cfg["delta"]
+        self.lim = np.array([cfg["lidar_x_min"], cfg["lidar_x_max"] - d, cfg["lidar_y_min"], cfg["lidar_y_max"] - d,
+                             cfg["lidar_z_min"], cfg["lidar_z_max"] - d], dtype=np.float64).astype(np.float32)
+        self.aff = np.array([self.xs, self.xo, self.ys, self.yo, self.zs, self.zo], dtype=np.float32)
+        self.image_height = cfg["image_height"]
+        self.image_width = cfg["image_width"]
+
+
+def range_filter(pts, lim):
+    n = pts.shape[0]
+    dev = pts.device
+    out = torch.empty((max(n, 1), 3), dtype=torch.float32, device=dev)
+    src = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws = torch.empty((H.lib().dcf_compact_workspace_bytes(n),), dtype=torch.uint8, device=dev)
+    H.call("dcf_range_filter", _chk(pts, "pts"), n, H.host_f32(lim), out, src, cnt, ws, H.stream_ptr())
+    return out, src, cnt
+
+
+def voxelize(pts, lim, aff, dims, mode=H.VOXEL_COMPAT, owner_ws=None):
+    Cz, L, W = dims
+    dev = pts.device
+    grid = torch.empty((Cz, L, W), dtype=torch.float32, device=dev)
+    if mode == H.VOXEL_COMPAT and owner_ws is None:
+        owner_ws = torch.zeros((2, Cz * L * W), dtype=torch.int32, device=dev)
+    H.call("dcf_voxelize", _chk(pts, "pts"), pts.shape[0], H.host_f32(lim), H.host_f32(aff), Cz, L, W, mode, grid, owner_ws,
+           H.stream_ptr())
+    return grid
+
+
+def project_filter(pts, lim, crt, ulim, vlim, mode=H.PROJ_COMPAT, n_out=None, want_src=False):
+    """Returns (uv [n_out,2], xyz [n_out,3], count int32[1] (device), src or None); rows past count are zero."""
+    n = pts.shape[0]
+    dev = pts.device
+    n_out = n if n_out is None else n_out
+    if n_out < n:
+        raise H.DcfError("project_filter: output rows (%d) < input points (%d)" % (n_out, n))
+    uv = torch.zeros((max(n_out, 1), 2), dtype=torch.float32, device=dev)
+    xyz = torch.zeros((max(n_out, 1), 3), dtype=torch.float32, device=dev)
+    src = torch.empty((max(n, 1),), dtype=torch.int32, device=dev) if want_src else None
+    cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws = torch.empty((H.lib().dcf_compact_workspace_bytes(n),), dtype=torch.uint8, device=dev)
+    H.call("dcf_project_filter", _chk(pts, "pts"), n, H.host_f32(lim), H.host_f32(crt).reshape(-1), float(ulim), float(vlim), mode,
+           uv, xyz, src, cnt, ws, H.stream_ptr())
+    return uv, xyz, cnt, src
+
+
+def knn_bev(xyz, cnt, K, h, w, stride, aff, rmax=None, ws=None):
+    n_max = xyz.shape[0]
+    dev = xyz.device
+    idx = torch.empty((K, h, w), dtype=torch.int32, device=dev)
+    if ws is None:
+        ws = torch.empty((H.lib().dcf_knn_workspace_bytes(n_max, h, w),), dtype=torch.uint8, device=dev)
+    r2 = -1.0 if rmax is None else float(np.float32(rmax) * np.float32(rmax))
+    H.call("dcf_knn_bev", _chk(xyz, "xyz"), cnt, n_max, K, h, w, stride, float(aff[0]), float(aff[1]), float(aff[2]), float(aff[3]),
+           r2, idx, ws, H.stream_ptr())
+    return idx
+
+
+# ------------------------------------------------------------------ fusion
+def point_sample_fwd(dtype, fmap, uv, cnt, n_max):
+    Hf, Wf, Cf = fmap.shape
+    fp = torch.zeros((max(n_max, 1), Cf), dtype=fmap.dtype, device=fmap.device)
+    H.call("dcf_point_sample_fwd", dtype, fmap, Hf, Wf, Cf, uv, cnt, n_max, fp, H.stream_ptr())
+    return fp
+
+
+def point_sample_bwd(dtype, gfp, uv, cnt, n_max, gfmap):
+    Hf, Wf, Cf = gfmap.shape
+    H.call("dcf_point_sample_bwd", dtype, gfp, Hf, Wf, Cf, uv, cnt, n_max, gfmap, H.stream_ptr())
+    return gfmap
+
+
+def fusion_gather_fwd(dtype, P, xyz, idx, stride, aff, w1d, b1):
+    K, h, w = idx.shape
+    Cb = P.shape[1]
+    hsum = torch.empty((h, w, Cb), dtype=P.dtype, device=P.device)
+    cnt = torch.empty((h * w,), dtype=torch.float32, device=P.device)
+    H.call("dcf_fusion_gather_fwd", dtype, P, xyz, idx, K, h, w, stride, float(aff[0]), float(aff[1]), float(aff[2]), float(aff[3]),
+           w1d, b1, Cb, hsum, cnt, H.stream_ptr())
+    return hsum, cnt
+
+
+def fusion_gather_bwd(dtype, P, xyz, idx, stride, aff, w1d, b1, ghsum, gP, gw1d, gb1):
+    K, h, w = idx.shape
+    Cb = P.shape[1]
+    H.call("dcf_fusion_gather_bwd", dtype, P, xyz, idx, K, h, w, stride, float(aff[0]), float(aff[1]), float(aff[2]), float(aff[3]),
+           w1d, b1, Cb, ghsum, gP, gw1d, gb1, H.stream_ptr())
+
+
+def rowscale_bias_fwd(dtype, y, cnt, b2):
+    C = y.shape[-1]
+    H.call("dcf_rowscale_bias_fwd", dtype, y, cnt, b2, y.numel() // C, C, H.stream_ptr())
+    return y
+
+
+def rowscale_bias_bwd(dtype, gy, cnt, gb2):
+    C = gy.shape[-1]
+    H.call("dcf_rowscale_bias_bwd", dtype, gy, cnt, gb2, gy.numel() // C, C, H.stream_ptr())

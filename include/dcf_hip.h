@@ -1,0 +1,201 @@
+/*
+ * dcf_hip.h -- C ABI of libdcf_hip.so, the MI355X (gfx950) implementation of the
+ * continuous-fusion train-step hot path.
+ *
+ * The reference (Chanuk-Yang/Deep_Continuous_Fusion_for_Multi-Sensor_3D_Object_Detection)
+ * is pure Python on torch: it has no FFI of its own, so the drop-in boundary is the
+ * Python module surface (model.py / data_import_carla.py / loss.py / train.py) and THIS
+ * header is what that surface binds underneath, through ctypes
+ * (deep_continuous_fusion_for_multi-sensor_3d_object_detection_amd/_hip.py).
+ * Every entry point names the reference code it replaces (file:line under /root/reference).
+ *
+ * Conventions:
+ *   - plain pointers and sizes; device pointers unless marked HOST; no torch types
+ *   - returns 0 on success or a negative DCF_E* code; dcf_last_error() gives the text
+ *   - never allocates, frees or synchronises; all work is enqueued on `stream`
+ *     (a hipStream_t passed as void*); workspaces are caller-provided
+ *   - activations are NHWC ("pixel rows of channels"); dtype DCF_F32 or DCF_BF16,
+ *     accumulation is always fp32
+ *   - counts that are produced on the device (n_valid ...) stay on the device
+ */
+#ifndef DCF_HIP_H
+#define DCF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *dcf_stream_t; /* hipStream_t */
+
+enum { DCF_OK = 0, DCF_EINVAL = -1, DCF_ELAUNCH = -2, DCF_EUNSUPPORTED = -3 };
+enum { DCF_F32 = 0, DCF_BF16 = 1 };
+enum { DCF_VOXEL_COMPAT = 0, DCF_VOXEL_ACCUM = 1 };
+enum { DCF_PROJ_COMPAT = 0, DCF_PROJ_CORRECT = 1 };
+
+const char *dcf_last_error(void);
+int dcf_version(void);
+/* Optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg). */
+int dcf_prof_enable(int on);
+int dcf_prof_reset(void);
+/* Fills up to `cap` records; returns the number of kernel classes seen. HOST pointers. */
+int dcf_prof_read(char *names /*[cap][64]*/, double *total_ms, int64_t *calls, int cap);
+
+/* ------------------------------------------------------------------ geometry
+ * Replaces CarlaDataset.Voxelization_Projection / Projection
+ * (data_import_carla.py:196-267, constants :31-43).                          */
+
+/* Range filter + order-preserving compaction (data_import_carla.py:215-229).
+ * lim HOST float[6] = {xlo,xhi,ylo,yhi,zlo,zhi}, strict inequalities.
+ * out_pts [n][3], out_src [n] (may be NULL), count_dev int[1].
+ * ws: dcf_compact_workspace_bytes(n). */
+size_t dcf_compact_workspace_bytes(int n);
+int dcf_range_filter(const float *pts, int n, const float *lim, float *out_pts, int32_t *out_src,
+                     int32_t *count_dev, void *ws, dcf_stream_t stream);
+
+/* Trilinear voxeliser (data_import_carla.py:236-258). Raw points in, range filter fused.
+ * aff HOST float[6] = {sx,ox,sy,oy,sz,oz}.  grid [Cz][L][W] fp32 is fully written.
+ * mode COMPAT: bit-exact "last writer wins per corner pass" (SURVEY.md F3);
+ *      ACCUM : atomic trilinear splat.
+ * owner_ws: int32[2][Cz*L*W], must be ZERO on entry and is returned ZERO (COMPAT only). */
+size_t dcf_voxelize_workspace_bytes(int Cz, int L, int W);
+int dcf_voxelize(const float *pts, int n, const float *lim, const float *aff, int Cz, int L, int W,
+                 int mode, float *grid, void *owner_ws, dcf_stream_t stream);
+
+/* Pinhole projection + in-image filter + compaction (data_import_carla.py:196-210,:261-266).
+ * Raw points in; keeps points passing the range filter AND the image test, in order.
+ * crt HOST float[12] = CRT_tensor [4][3].  uv_out [n][2], xyz_out [n][3], src_out [n] or NULL.
+ * Rows >= *count_dev are left untouched (caller pre-zeroes for the zero padding of :263-266). */
+int dcf_project_filter(const float *pts, int n, const float *lim, const float *crt, float ulim, float vlim,
+                       int mode, float *uv_out, float *xyz_out, int32_t *src_out, int32_t *count_dev,
+                       void *ws, dcf_stream_t stream);
+
+/* BEV K-nearest-neighbour (reference: model.py:199-203 TODO; spec SURVEY.md App. D).
+ * xyz [n_max][3], first *count_dev rows valid.  idx_out int32 [K][h][w], -1 padding.
+ * rmax2 < 0 = unbounded.  K <= 8.  ws: dcf_knn_workspace_bytes(n_max,h,w). */
+size_t dcf_knn_workspace_bytes(int n_max, int h, int w);
+int dcf_knn_bev(const float *xyz, const int32_t *count_dev, int n_max, int K, int h, int w, int stride,
+                float xs, float xo, float ys, float yo, float rmax2, int32_t *idx_out, void *ws,
+                dcf_stream_t stream);
+
+/* ------------------------------------------------------------ layout / input
+ * NCHW fp32 -> NHWC dtype (the model keeps the reference's NCHW voxel input, model.py:194). */
+int dcf_nchw_to_nhwc(int dtype, const float *x, void *y, int B, int C, int H, int W, dcf_stream_t stream);
+/* uint8 NCHW image -> x/255 as NHWC with C padded to 4 and a zero halo of 3 pixels (stem input). */
+int dcf_image_to_nhwc4(int dtype, const uint8_t *img, void *y, int B, int H, int W, dcf_stream_t stream);
+
+/* -------------------------------------------------------------- convolution
+ * Replaces nn.Conv2d (+ folded eval BatchNorm + residual + ReLU) of model.py:15-41,147-157.
+ * Implicit GEMM on MFMA; x [B,H,W,Cin], w [Cout][kh][kw][Cin] (dtype), y [B,Ho,Wo,Cout].
+ * y = act(conv(x,w) + shift[c] + res);  shift fp32 [Cout] or NULL; res (dtype, like y) or NULL.
+ * Cin*esize must be a multiple of 64 bytes; Cout a multiple of 32. */
+int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const float *shift, const void *res, void *y,
+                   int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                   int relu, dcf_stream_t stream);
+/* Input gradient: gx [B,H,W,Cin] = conv_transpose(gy [B,Ho,Wo,Cout], wt) (+ res).
+ * wt [Cin][kh][kw][Cout] (dtype) as produced by dcf_weight_prep. */
+int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const void *res, void *gx,
+                     int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                     dcf_stream_t stream);
+/* Weight gradient, split over pixel ranges: slabs fp32 [nsplit][Cout][kh][kw][Cin] (plain stores,
+ * reduced in fixed order by dcf_wgrad_finalize => bitwise reproducible).
+ * nsplit = dcf_conv2d_wgrad_splits(...). */
+int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw);
+int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float *slabs, int nsplit,
+                     int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                     dcf_stream_t stream);
+/* The 7x7/2 RGB stem of the image stream on the NHWC4+halo image. */
+int dcf_stem7x7_fwd(int dtype, const void *img4, const void *w, const float *shift, void *y,
+                    int B, int H, int W, int Ho, int Wo, int Cout, int relu, dcf_stream_t stream);
+int dcf_stem7x7_wgrad(int dtype, const void *img4, const void *gy, float *slabs, int nsplit,
+                      int B, int H, int W, int Ho, int Wo, int Cout, dcf_stream_t stream);
+
+/* Per-step parameter preparation (table driven, one launch for the whole net):
+ * for conv i: scale = gamma*rsqrt(var+eps) (or 1), shift = beta - mean*scale (or 0),
+ * w_fwd = cast(scale[co]*W), w_dgrad = transpose of the same.  Descriptor table lives on
+ * the device (struct dcf_conv_param, below). */
+typedef struct dcf_conv_param {
+    int64_t w_off;      /* element offset of W [Cout][taps][Cin] fp32 in the parameter arena */
+    int64_t gamma_off;  /* BN gamma/beta offsets in the parameter arena, -1 = no BN            */
+    int64_t beta_off;
+    int64_t mean_off;   /* running mean/var offsets in the buffer arena                        */
+    int64_t var_off;
+    int64_t wfwd_off;   /* byte offsets into the compute-dtype weight arena                    */
+    int64_t wdgrad_off; /* -1 = not needed                                                      */
+    int64_t shift_off;  /* element offset into the fp32 scale/shift arena: [scale Cout][shift Cout] */
+    int64_t slab_off;   /* element offset of this conv's wgrad slabs in the slab arena         */
+    int64_t gsum_off;   /* element offset of this conv's per-channel sum(g) in the gsum arena */
+    int32_t cout, cin, taps, cout_pad;
+    int32_t nsplit, flags, pad0, pad1;
+} dcf_conv_param;
+int dcf_weight_prep(int dtype, const dcf_conv_param *table, int nconv, const float *params, const float *buffers,
+                    void *warena, float *ssarena, float eps, dcf_stream_t stream);
+/* Reduce wgrad slabs in split order and apply the folded-BN chain rule:
+ * dW = scale*G, dgamma = (<W,G> - mean*dbeta)*invstd, dbeta = sum g (from gsum arena). */
+int dcf_wgrad_finalize(const dcf_conv_param *table, int nconv, const float *params, const float *buffers,
+                       const float *ssarena, const float *slabs, const float *gsum, float *grads, float eps,
+                       dcf_stream_t stream);
+
+/* ------------------------------------------------------------- elementwise
+ * g = gy * (y > 0) in place on gy (ReLU backward, model.py:21,25) and per-channel sums
+ * gsum[c] += sum_p g[p][c] (the BN-beta gradient).  gsum fp32 [C], pre-zeroed by caller. */
+int dcf_relu_bwd_chansum(int dtype, void *gy, const void *y, float *gsum, int64_t npix, int C, int relu,
+                         dcf_stream_t stream);
+/* Bilinear resize NHWC (model.py:149,151 nn.UpsamplingBilinear2d => align_corners=1; the
+ * image FPN uses align_corners=0).  y = resize(x) + (add ? add : 0). */
+int dcf_resize_bilinear_fwd(int dtype, const void *x, const void *add, void *y, int B, int Hi, int Wi, int Ho, int Wo,
+                            int C, int align_corners, dcf_stream_t stream);
+/* gx = resize^T(gy): gather form (each input pixel sums its contributing output pixels). */
+int dcf_resize_bilinear_bwd(int dtype, const void *gy, void *gx, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                            int align_corners, dcf_stream_t stream);
+/* 3x3/2 max-pool pad 1 (image stem), NHWC; bwd routes to the first arg-max in scan order. */
+int dcf_maxpool3x3s2_fwd(int dtype, const void *x, void *y, int B, int H, int W, int Ho, int Wo, int C,
+                         dcf_stream_t stream);
+int dcf_maxpool3x3s2_bwd(int dtype, const void *x, const void *y, const void *gy, void *gx, int B, int H, int W,
+                         int Ho, int Wo, int C, dcf_stream_t stream);
+/* Heads (model.py:168-172 softmax pairs, :116-137 box decode, :204 concat):
+ * head [B,h,w,Cp] (first 18 channels = 4 class logits + 14 offsets) ->
+ * pred [B,32,h,w] fp32 NCHW = cat(softmax2,softmax2, reg14, decode(reg14, anchors[14,h,w])). */
+int dcf_head_fwd(int dtype, const void *head, int Cp, const float *anchors, float *pred, int B, int h, int w,
+                 dcf_stream_t stream);
+/* gpred [B,32,h,w] fp32 -> ghead [B,h,w,Cp] (dtype), pad channels zero. */
+int dcf_head_bwd(int dtype, const void *head, int Cp, const float *anchors, const float *pred, const float *gpred,
+                 void *ghead, int B, int h, int w, dcf_stream_t stream);
+
+/* ------------------------------------------------------------------ fusion
+ * SURVEY.md App. D (reference: model.py:199-203 TODO).  Per sample.
+ * (1) per-point camera feature: fp [n][Cf] = bilinear(F [Hf][Wf][Cf], u/4-0.5, v/4-0.5), border clamp */
+int dcf_point_sample_fwd(int dtype, const void *fmap, int Hf, int Wf, int Cf, const float *uv, const int32_t *count_dev,
+                         int n_max, void *fp, dcf_stream_t stream);
+/*     backward: gF[tap] += w_tap * gfp (fp32 atomics into gfmap fp32 [Hf][Wf][Cf]) */
+int dcf_point_sample_bwd(int dtype, const void *gfp, int Hf, int Wf, int Cf, const float *uv, const int32_t *count_dev,
+                         int n_max, float *gfmap, dcf_stream_t stream);
+/* (2) per BEV pixel: hsum[p][c] = sum_k relu(P[idx_k][c] + W1d[c][0..2].(dx,dy,z) + b1[c]),
+ *     cnt[p] = number of valid neighbours.  P [n][Cb] (dtype); w1d fp32 [Cb][3]; b1 fp32 [Cb]. */
+int dcf_fusion_gather_fwd(int dtype, const void *P, const float *xyz, const int32_t *idx, int K, int h, int w,
+                          int stride, float xs, float xo, float ys, float yo, const float *w1d, const float *b1,
+                          int Cb, void *hsum, float *cnt, dcf_stream_t stream);
+/*     backward: recompute the ReLU mask; gP[idx_k] += m*gh (fp32 atomics, gP fp32 [n][Cb]);
+ *     gw1d[c][j] += sum m*gh*delta_j ; gb1[c] += sum m*gh. */
+int dcf_fusion_gather_bwd(int dtype, const void *P, const float *xyz, const int32_t *idx, int K, int h, int w,
+                          int stride, float xs, float xo, float ys, float yo, const float *w1d, const float *b1,
+                          int Cb, const void *ghsum, float *gP, float *gw1d, float *gb1, dcf_stream_t stream);
+/* y[p][c] += cnt[p]*b2[c]  (the fc2 bias of the K-sum), and its gradient gb2[c] += sum_p cnt[p]*gy[p][c]. */
+int dcf_rowscale_bias_fwd(int dtype, void *y, const float *cnt, const float *b2, int64_t npix, int C, dcf_stream_t stream);
+int dcf_rowscale_bias_bwd(int dtype, const void *gy, const float *cnt, float *gb2, int64_t npix, int C, dcf_stream_t stream);
+/* dtype <-> fp32 casts of whole buffers (gradient hand-offs of the fusion path). */
+int dcf_cast(int dtype_src, const void *src, int dtype_dst, void *dst, int64_t n, dcf_stream_t stream);
+
+/* ------------------------------------------------------------------- optimiser
+ * Fused Adam over the flat fp32 parameter arena (train.py:28,36: Adam(lr, betas=(beta1,0.999)),
+ * eps 1e-8, no weight decay, bias-corrected like torch.optim.Adam). gscale multiplies the gradient
+ * (1/world_size after the all-reduce). */
+int dcf_adam_step(float *params, const float *grads, float *m, float *v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int step, float gscale, dcf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCF_HIP_H */

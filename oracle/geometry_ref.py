@@ -134,7 +134,11 @@ def voxelization_projection(pts, cfg, crt, max_num_pc=None, voxel_mode="compat",
     g = grid_constants(cfg)
     pin, _ = range_filter(pts, g["lim"])
     grid, ids = voxelize(pin, g["aff"], g["dims"], voxel_mode, want_ids=True)
-    uv, xyz, _ = project(pin, crt, cfg["image_height"], cfg["image_width"], proj_mode)
+    if proj_mode == "compat":   # (sic) u against image_height, v against image_width: :202-205
+        ulim, vlim = cfg["image_height"], cfg["image_width"]
+    else:                       # "correct": u < W, v < H, depth > 0
+        ulim, vlim = cfg["image_width"], cfg["image_height"]
+    uv, xyz, _ = project(pin, crt, ulim, vlim, proj_mode)
     mp = cfg["max_num_pc"] if max_num_pc is None else max_num_pc
     n = uv.shape[0]
     if n > mp:

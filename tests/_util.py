@@ -1,0 +1,47 @@
+"""Shared helpers for the GPU parity tests (test infrastructure)."""
+import importlib
+import os
+
+import numpy as np
+import torch
+import yaml
+
+PKG = "deep_continuous_fusion_for_multi-sensor_3d_object_detection_amd"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pkg(sub=None):
+    return importlib.import_module(PKG + ("." + sub if sub else ""))
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+def golden_cfg(z):
+    return yaml.safe_load(str(z["cfg_yaml"]))
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    det = pkg("detfill")
+    return torch.from_numpy(det.uniform(tuple(shape), seed, lo, hi))
+
+
+def to_dev(x_nchw, dtype):
+    """NCHW fp32 CPU -> NHWC device tensor of the compute dtype."""
+    t = x_nchw.permute(0, 2, 3, 1).contiguous().cuda()
+    return t.to(torch.bfloat16) if dtype == 1 else t
+
+
+def from_dev(y_nhwc):
+    return y_nhwc.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def q(x, dtype):
+    """Quantise a CPU fp32 tensor the way the device stores it."""
+    return x.to(torch.bfloat16).float() if dtype == 1 else x
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))

@@ -1,0 +1,143 @@
+"""GPU parity: geometry kernels (through the C ABI) against the oracle and the golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from _util import golden_cfg, load_golden, pkg
+from oracle import geometry_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _spec(cfg):
+    return pkg("ops").GridSpec(cfg)
+
+
+@pytest.mark.parametrize("case", ["two", "five", "n1k", "n10k"])
+def test_voxel_project_golden_bit_exact(case):
+    ops, H = pkg("ops"), pkg("_hip")
+    z = load_golden("geometry_carla.npz")
+    cfg = golden_cfg(z)
+    g = _spec(cfg)
+    pts = torch.from_numpy(z[case + "_pts"]).cuda()
+    grid = ops.voxelize(pts, g.lim, g.aff, g.dims, H.VOXEL_COMPAT).cpu().numpy()
+    want = np.zeros(grid.size, np.float32)
+    want[z[case + "_vox_idx"]] = z[case + "_vox_val"]
+    bad = np.flatnonzero(grid.reshape(-1).view(np.uint32) != want.view(np.uint32))
+    assert bad.size == 0, "voxel grid differs at %d voxels, first %s" % (bad.size, bad[:5])
+    uv, xyz, cnt, _ = ops.project_filter(pts, g.lim, z["crt"], cfg["image_height"], cfg["image_width"], n_out=cfg["max_num_pc"])
+    n = int(cnt.item())
+    assert n == int(z[case + "_n"])
+    assert np.array_equal(uv.cpu().numpy()[:n].view(np.uint32), z[case + "_uv"].view(np.uint32))
+    assert np.array_equal(xyz.cpu().numpy()[:n].view(np.uint32), z[case + "_xyz"].view(np.uint32))
+    assert not uv.cpu().numpy()[n:].any() and not xyz.cpu().numpy()[n:].any()  # zero padding of :263-266
+    # trunc'd voxel ids of the in-range points (debug BEV image path, :258, :269-272)
+    pin, src, c2 = ops.range_filter(pts, g.lim)
+    m = int(c2.item())
+    assert m == z[case + "_ids"].shape[1]
+    ref_in, ref_src = geometry_ref.range_filter(z[case + "_pts"], g.lim)
+    assert np.array_equal(pin.cpu().numpy()[:m], ref_in) and np.array_equal(src.cpu().numpy()[:m], ref_src)
+
+
+def test_voxel_workspace_returned_zero_and_reusable():
+    ops, H = pkg("ops"), pkg("_hip")
+    z = load_golden("geometry_carla.npz")
+    cfg = golden_cfg(z)
+    g = _spec(cfg)
+    Cz, L, W = g.dims
+    ws = torch.zeros((2, Cz * L * W), dtype=torch.int32, device="cuda")
+    pts = torch.from_numpy(z["n10k_pts"]).cuda()
+    a = ops.voxelize(pts, g.lim, g.aff, g.dims, H.VOXEL_COMPAT, ws)
+    assert int(ws.abs().sum().item()) == 0
+    b = ops.voxelize(pts, g.lim, g.aff, g.dims, H.VOXEL_COMPAT, ws)
+    assert torch.equal(a, b)
+
+
+def test_voxel_accum_mode_and_empty_inputs():
+    ops, H = pkg("ops"), pkg("_hip")
+    z = load_golden("geometry_carla.npz")
+    cfg = golden_cfg(z)
+    g = _spec(cfg)
+    pts = z["n10k_pts"]
+    pin, _ = geometry_ref.range_filter(pts, g.lim)
+    ref = geometry_ref.voxelize(pin, g.aff, g.dims, "accum")
+    got = ops.voxelize(torch.from_numpy(pts).cuda(), g.lim, g.aff, g.dims, H.VOXEL_ACCUM).cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-5          # atomics: order differs, values agree
+    assert abs(got.sum() - pin.shape[0]) < 1e-2    # trilinear weights sum to 1 per point
+    empty = torch.zeros((0, 3), device="cuda")
+    assert float(ops.voxelize(empty, g.lim, g.aff, g.dims, H.VOXEL_COMPAT).abs().sum()) == 0.0
+    uv, xyz, cnt, _ = ops.project_filter(empty, g.lim, z["crt"], 480, 640, n_out=16)
+    assert int(cnt.item()) == 0
+    far = torch.full((100, 3), 500.0, device="cuda")   # everything out of range
+    _, _, cnt, _ = ops.project_filter(far, g.lim, z["crt"], 480, 640)
+    assert int(cnt.item()) == 0
+
+
+def test_full_size_100k_points_vs_oracle():
+    """BASELINE full size: 100k-point cloud on the KITTI-scale grid, bit-exact against the C oracle."""
+    ops, H, det = pkg("ops"), pkg("_hip"), pkg("detfill")
+    cfg = golden_cfg(load_golden("geometry_carla.npz"))
+    cfg.update(dict(voxel_length=704, voxel_width=800, lidar_x_max=70.4, lidar_y_min=-40.0, lidar_y_max=40.0,
+                    image_height=375, image_width=1242, max_num_pc=100000))
+    g = _spec(cfg)
+    crt = pkg("data_import_carla").kitti_like_crt()
+    pts = det.synthetic_points(100000, (0.0, 70.4, -40.0, 40.0, -2.4, 0.8), seed=5)
+    ref_grid, ref_pc, ref_uv, ref_n, _ = geometry_ref.voxelization_projection(pts, cfg, crt, proj_mode="correct")
+    d = torch.from_numpy(pts).cuda()
+    grid = ops.voxelize(d, g.lim, g.aff, g.dims, H.VOXEL_COMPAT)
+    assert np.array_equal(grid.cpu().numpy().view(np.uint32), ref_grid.view(np.uint32))
+    uv, xyz, cnt, _ = ops.project_filter(d, g.lim, crt, 1242, 375, H.PROJ_CORRECT)
+    n = int(cnt.item())
+    assert n == ref_n and n > 1000
+    assert np.array_equal(uv.cpu().numpy()[:n].view(np.uint32), ref_uv[:n].view(np.uint32))
+    assert np.array_equal(xyz.cpu().numpy()[:n].view(np.uint32), ref_pc[:n].view(np.uint32))
+
+
+@pytest.mark.parametrize("K", [1, 3, 5])
+@pytest.mark.parametrize("stride", [2, 4, 16])
+def test_knn_bit_exact_vs_bruteforce(K, stride):
+    ops = pkg("ops")
+    z = load_golden("geometry_carla.npz")
+    cfg = golden_cfg(z)
+    g = _spec(cfg)
+    xyz = z["n10k_xyz"]
+    h, w = cfg["voxel_length"] // stride, cfg["voxel_width"] // stride
+    if stride == 2:   # keep the brute-force oracle in seconds: crop the BEV to a window near the sensor
+        h, w = 96, 128
+    ref = geometry_ref.knn_bev(xyz, K, h, w, stride, g.aff)
+    d = torch.from_numpy(xyz).cuda()
+    cnt = torch.tensor([xyz.shape[0]], dtype=torch.int32, device="cuda")
+    got = ops.knn_bev(d, cnt, K, h, w, stride, g.aff).cpu().numpy()
+    bad = np.argwhere(got != ref)
+    assert bad.shape[0] == 0, "KNN differs at %d entries, first %s got %s ref %s" % (
+        bad.shape[0], bad[:3].tolist(), got[tuple(bad[0])] if bad.size else None, ref[tuple(bad[0])] if bad.size else None)
+
+
+def test_knn_edge_cases():
+    ops = pkg("ops")
+    z = load_golden("geometry_carla.npz")
+    cfg = golden_cfg(z)
+    g = _spec(cfg)
+    h, w, s, K = 48, 32, 8, 3
+    xyz = z["n1k_xyz"]
+    d = torch.from_numpy(np.ascontiguousarray(xyz)).cuda()
+    # count < K  -> -1 padding ; count == 0 -> all -1 ; rows past count are ignored
+    for n in (0, 1, 2):
+        cnt = torch.tensor([n], dtype=torch.int32, device="cuda")
+        got = ops.knn_bev(d, cnt, K, h, w, s, g.aff).cpu().numpy()
+        assert np.array_equal(got, geometry_ref.knn_bev(xyz[:n], K, h, w, s, g.aff))
+    # radius cut
+    cnt = torch.tensor([xyz.shape[0]], dtype=torch.int32, device="cuda")
+    for rmax in (0.5, 3.0, 40.0):
+        got = ops.knn_bev(d, cnt, K, h, w, s, g.aff, rmax=rmax).cpu().numpy()
+        assert np.array_equal(got, geometry_ref.knn_bev(xyz, K, h, w, s, g.aff, rmax=rmax)), rmax
+    # duplicates: identical points must come out in index order (tie-break on index)
+    dup = np.repeat(xyz[:5], 4, axis=0)
+    cnt = torch.tensor([dup.shape[0]], dtype=torch.int32, device="cuda")
+    got = ops.knn_bev(torch.from_numpy(dup).cuda(), cnt, 5, h, w, s, g.aff).cpu().numpy()
+    assert np.array_equal(got, geometry_ref.knn_bev(dup, 5, h, w, s, g.aff))
+    # a single far cluster: every pixel must still find it (coarse-ring phase)
+    far = (xyz[:8] * 0 + np.array([68.0, 28.0, -1.0], np.float32) + np.arange(8, dtype=np.float32)[:, None] * 0.01).astype(np.float32)
+    cnt = torch.tensor([8], dtype=torch.int32, device="cuda")
+    got = ops.knn_bev(torch.from_numpy(far).cuda(), cnt, 3, h, w, s, g.aff).cpu().numpy()
+    assert np.array_equal(got, geometry_ref.knn_bev(far, 3, h, w, s, g.aff))
