@@ -1,0 +1,151 @@
+"""GPU parity: MFMA implicit-GEMM convolution (fwd / dgrad / wgrad) through the C ABI against
+torch's fp32 CPU convolution.  fp32 path: 1e-4 relative; bf16 path: inputs pre-rounded to bf16,
+fp32 accumulate, 1e-2 relative to the output's max (output rounding to bf16)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import from_dev, pkg, q, rel_err, rnd, to_dev
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 2e-4, 1: 1.2e-2}
+
+# (B, H, W, Cin, Cout, k, stride)  -- covers every tile dispatch (Cout%128, %64, %32; row bytes %128 or %64)
+SHAPES = [
+    (1, 16, 16, 32, 32, 3, 1),
+    (2, 17, 13, 32, 64, 3, 2),
+    (1, 12, 20, 64, 128, 3, 1),
+    (2, 10, 10, 128, 192, 3, 2),
+    (1, 9, 11, 96, 160, 3, 1),
+    (1, 8, 8, 192, 256, 1, 1),
+    (2, 14, 10, 64, 96, 1, 2),
+    (1, 24, 16, 256, 192, 1, 1),
+    (1, 40, 52, 32, 32, 3, 1),
+]
+
+
+def _mk(shape, dtype, seed):
+    B, Hh, W, Cin, Cout, k, s = shape
+    x = q(rnd((B, Cin, Hh, W), seed), dtype)
+    w = q(rnd((Cout, Cin, k, k), seed + 1, -0.2, 0.2), dtype)
+    return x, w
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv_fwd(shape, dtype):
+    ops = pkg("ops")
+    B, Hh, W, Cin, Cout, k, s = shape
+    pad = k // 2
+    x, w = _mk(shape, dtype, 11)
+    shift = rnd((Cout,), 5)
+    ref_lin = F.conv2d(x, w, None, s, pad)
+    res = q(rnd(tuple(ref_lin.shape), 6), dtype)
+    xd, wd = to_dev(x, dtype), to_dev(w, dtype)   # weights [Cout][kh][kw][Cin]
+    # plain
+    y = ops.conv2d_fwd(dtype, xd, wd, None, None, k, k, s, pad, False, Cout)
+    e = rel_err(from_dev(y), ref_lin)
+    assert e < TOL[dtype], "plain conv rel err %g" % e
+    # fused epilogue: shift + residual + relu
+    y2 = ops.conv2d_fwd(dtype, xd, wd, shift.cuda(), to_dev(res, dtype), k, k, s, pad, True, Cout)
+    ref2 = torch.relu(ref_lin + shift.view(1, -1, 1, 1) + res)
+    e2 = rel_err(from_dev(y2), ref2)
+    assert e2 < TOL[dtype], "fused conv rel err %g" % e2
+    assert float(from_dev(y2).min()) >= 0.0
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv_dgrad(shape, dtype):
+    ops = pkg("ops")
+    B, Hh, W, Cin, Cout, k, s = shape
+    pad = k // 2
+    x, w = _mk(shape, dtype, 21)
+    x.requires_grad_(True)
+    y = F.conv2d(x, w, None, s, pad)
+    gy = q(rnd(tuple(y.shape), 22), dtype)
+    y.backward(gy)
+    wt = w.permute(1, 2, 3, 0).contiguous().cuda()          # [Cin][kh][kw][Cout]
+    wt = wt.to(torch.bfloat16) if dtype == 1 else wt
+    gx = ops.conv2d_dgrad(dtype, to_dev(gy, dtype), wt, None, (B, Hh, W, Cin), k, k, s, pad)
+    e = rel_err(from_dev(gx), x.grad)
+    assert e < TOL[dtype], "dgrad rel err %g" % e
+    res = q(rnd((B, Cin, Hh, W), 23), dtype)
+    gx2 = ops.conv2d_dgrad(dtype, to_dev(gy, dtype), wt, to_dev(res, dtype), (B, Hh, W, Cin), k, k, s, pad)
+    e2 = rel_err(from_dev(gx2), x.grad + res)
+    assert e2 < TOL[dtype], "dgrad+res rel err %g" % e2
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv_wgrad(shape, dtype):
+    ops = pkg("ops")
+    B, Hh, W, Cin, Cout, k, s = shape
+    pad = k // 2
+    x, w = _mk(shape, dtype, 31)
+    w.requires_grad_(True)
+    y = F.conv2d(x, w, None, s, pad)
+    gy = q(rnd(tuple(y.shape), 32), dtype)
+    y.backward(gy)
+    Ho, Wo = y.shape[-2:]
+    ns = ops.conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, k, k)
+    assert ns >= 4 and ns % 4 == 0
+    slabs = torch.full((ns, Cout, k, k, Cin), float("nan"), device="cuda")
+    ops.conv2d_wgrad(dtype, to_dev(x, dtype), to_dev(gy, dtype), slabs, ns, k, k, s, pad)
+    G = slabs.sum(0).cpu().permute(0, 3, 1, 2)                  # -> [Cout,Cin,kh,kw]
+    assert torch.isfinite(G).all(), "wgrad left unwritten slab entries"
+    e = rel_err(G, w.grad)
+    assert e < (2e-4 if dtype == 0 else 2e-3), "wgrad rel err %g" % e
+    # fixed-order slabs: bitwise reproducible
+    slabs2 = torch.zeros_like(slabs)
+    ops.conv2d_wgrad(dtype, to_dev(x, dtype), to_dev(gy, dtype), slabs2, ns, k, k, s, pad)
+    assert torch.equal(slabs, slabs2)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_stem7x7(dtype):
+    """7x7/2 RGB stem on the NHWC4+halo image against conv2d(x/255, w, stride 2, pad 3)."""
+    ops, det = pkg("ops"), pkg("detfill")
+    B, Hh, W, Cout = 2, 38, 50, 64
+    img = torch.from_numpy(det.synthetic_image(Hh, W, 3)).unsqueeze(0).repeat(B, 1, 1, 1).contiguous()
+    img[1] = torch.flip(img[1], dims=[2])
+    w = q(rnd((Cout, 3, 7, 7), 41, -0.2, 0.2), dtype)
+    xf = q(img.float() / 255.0, dtype)
+    ref = F.conv2d(xf, w, None, 2, 3)
+    w8 = torch.zeros(Cout, 7, 8, 4)
+    w8[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    wd = w8.cuda().to(torch.bfloat16) if dtype == 1 else w8.cuda()
+    img4 = ops.image_to_nhwc4(img.cuda(), dtype)
+    y = ops.stem7x7_fwd(dtype, img4, wd, None, False, Cout, Hh, W)
+    e = rel_err(from_dev(y), ref)
+    assert e < TOL[dtype], "stem fwd rel err %g" % e
+    # wgrad
+    wv = w.clone().requires_grad_(True)
+    out = F.conv2d(xf, wv, None, 2, 3)
+    gy = q(rnd(tuple(out.shape), 42), dtype)
+    out.backward(gy)
+    ns = ops.conv2d_wgrad_splits(B, out.shape[2], out.shape[3], 32, Cout, 7, 1)
+    slabs = torch.zeros((ns, Cout, 7, 8, 4), device="cuda")
+    ops.stem7x7_wgrad(dtype, img4, to_dev(gy, dtype), slabs, ns, Hh, W)
+    G = slabs.sum(0).cpu()[:, :, :7, :3].permute(0, 3, 1, 2)
+    e = rel_err(G, wv.grad)
+    assert e < (2e-4 if dtype == 0 else 3e-3), "stem wgrad rel err %g" % e
+
+
+def test_conv_full_size_layer_linearity():
+    """BASELINE-size check without a CPU reference: conv is linear, so conv(a*x1 + x2) == a*conv(x1) + conv(x2)
+    on a full KITTI-scale layer1 tensor (fp32 path), and bf16 agrees with fp32 to bf16 precision."""
+    ops = pkg("ops")
+    B, Hh, W, C = 1, 704, 800, 32
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x1 = torch.rand((B, Hh, W, C), device="cuda", generator=g) - 0.5
+    x2 = torch.rand((B, Hh, W, C), device="cuda", generator=g) - 0.5
+    w = (torch.rand((C, 3, 3, C), device="cuda", generator=g) - 0.5) * 0.2
+    y1 = ops.conv2d_fwd(0, x1, w, None, None, 3, 3, 1, 1, False, C)
+    y2 = ops.conv2d_fwd(0, x2, w, None, None, 3, 3, 1, 1, False, C)
+    y3 = ops.conv2d_fwd(0, (2.0 * x1 + x2).contiguous(), w, None, None, 3, 3, 1, 1, False, C)
+    assert float((y3 - (2.0 * y1 + y2)).abs().max()) < 1e-4
+    yb = ops.conv2d_fwd(1, x1.bfloat16(), w.bfloat16(), None, None, 3, 3, 1, 1, False, C).float()
+    yr = ops.conv2d_fwd(0, x1.bfloat16().float(), w.bfloat16().float(), None, None, 3, 3, 1, 1, False, C)
+    assert float((yb - yr).abs().max() / yr.abs().max()) < 1e-2

@@ -80,7 +80,7 @@ def test_full_size_100k_points_vs_oracle():
     cfg.update(dict(voxel_length=704, voxel_width=800, lidar_x_max=70.4, lidar_y_min=-40.0, lidar_y_max=40.0,
                     image_height=375, image_width=1242, max_num_pc=100000))
     g = _spec(cfg)
-    crt = pkg("data_import_carla").kitti_like_crt()
+    crt = pkg("calib").kitti_like_crt()
     pts = det.synthetic_points(100000, (0.0, 70.4, -40.0, 40.0, -2.4, 0.8), seed=5)
     ref_grid, ref_pc, ref_uv, ref_n, _ = geometry_ref.voxelization_projection(pts, cfg, crt, proj_mode="correct")
     d = torch.from_numpy(pts).cuda()
