@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""Benchmark of the continuous-fusion train step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the whole hot path over one batch of synthetic frames already resident
+in HBM: voxelise + project (raw 100k-point clouds), KNN for the 4 fusion sites, ResNet-18 image
+stream + FPN, LiDAR-BEV stream with 4 continuous-fusion adds, heads/decode, LossTotal,
+backward, gradient all-reduce (RCCL, N>1) and the fused Adam step.  Workload = BASELINE.json
+configs[1] ("cfg2"): KITTI-scale grid 32x704x800, 100k points, 1242x375 RGB, ResNet-18, K=3,
+batch 2 per GPU, bf16 (fp32 accumulate / fp32 master weights).  Weak scaling: per-GPU batch fixed.
+
+Prints ONE JSON line on rank 0 (see README / task contract), including
+  roofline     -- the dominant kernel class, timed live with HIP events on the launch stream
+  cpu_baseline -- this repo's CPU restatement (oracle/, kind "port") on a bounded sample, rank 0, N=1 only.
+"""
+import argparse
+import copy
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "deep_continuous_fusion_for_multi-sensor_3d_object_detection_amd"
+
+
+def pkg(sub):
+    return importlib.import_module(PKG + "." + sub)
+
+
+def kitti_config(batch, dtype="bf16", n_points=100000, K=3):
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, PKG, "config", "config_carla.yaml")))
+    cfg.update(dict(voxel_length=704, voxel_width=800, voxel_channel=32, lidar_x_min=0.0, lidar_x_max=70.4,
+                    lidar_y_min=-40.0, lidar_y_max=40.0, lidar_z_min=-2.4, lidar_z_max=0.8,
+                    image_height=375, image_width=1242, max_num_pc=n_points, batch_size=batch,
+                    dtype=dtype, projection_mode="correct", voxel_mode="compat"))
+    cfg["fusion"] = dict(enabled=True, K=K, r_max=None, image_channels=64, image_stream="resnet18", zero_init_last=False)
+    return cfg
+
+
+class FramePool(object):
+    """Synthetic frames (SURVEY.md 8(d) generator), uploaded once; the timed region starts from HBM."""
+
+    def __init__(self, cfg, n_frames, n_points, seed0):
+        D = pkg("data_import_carla")
+        ds = D.SyntheticDataset(cfg, length=n_frames, num_points=n_points, crt=pkg("calib").kitti_like_crt(),
+                                image_hw=(cfg["image_height"], cfg["image_width"]))
+        self.geometry = ds.geometry
+        self.pts, self.img, self.boxes, self.nb = [], [], [], []
+        for i in range(n_frames):
+            p, im, b, nb = ds.raw(seed0 + i)
+            self.pts.append(p.cuda())
+            self.img.append(im.cuda())
+            self.boxes.append(b)
+            self.nb.append(nb)
+        self.boxes_dev = [b.cuda() for b in self.boxes]
+        self.n = n_frames
+
+    def batch(self, step, B):
+        ids = [(step * B + i) % self.n for i in range(B)]
+        return ids
+
+
+def train_step(trainer, pool, ids):
+    """Whole hot path for one batch; everything is enqueued on torch's current stream."""
+    vox, pcs, uvs, cnts = [], [], [], []
+    for i in ids:
+        v, pc, uv, cnt, _ = pool.geometry(pool.pts[i])
+        vox.append(v); pcs.append(pc); uvs.append(uv); cnts.append(cnt)
+    x_lidar = torch.stack(vox, 0)
+    x_image = torch.stack([pool.img[i] for i in ids], 0)
+    points, uv, n_valid = torch.stack(pcs, 0), torch.stack(uvs, 0), torch.cat(cnts, 0)
+    boxes = torch.stack([pool.boxes_dev[i] for i in ids], 0)
+    nb = torch.tensor([pool.nb[i] for i in ids])
+    trainer.one_step(x_lidar, x_image, boxes, nb, points=points, uv=uv, n_valid=n_valid)
+
+
+def conv_flops(backend_cls):
+    """Wrap the backend's conv calls to count ALGORITHMIC flops per kernel class (2*M*Cout*Cin*taps)."""
+    counts = {}
+
+    def add(name, f):
+        counts[name] = counts.get(name, 0.0) + f
+
+    orig_f, orig_d, orig_w = backend_cls.conv_fwd, backend_cls.conv_dgrad, backend_cls.conv_wgrad
+    orig_sf, orig_sw = backend_cls.stem_fwd, backend_cls.stem_wgrad
+
+    def suffix(self):
+        return "bf16" if self.dtype == 1 else "f32"
+
+    def fwd(self, L, x, res, relu):
+        y = orig_f(self, L, x, res, relu)
+        add("conv_fwd_" + suffix(self), 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * L.cout * L.cin * L.taps)
+        return y
+
+    def dgrad(self, L, gy, in_shape, res):
+        add("conv_dgrad_" + suffix(self), 2.0 * gy.shape[0] * gy.shape[1] * gy.shape[2] * L.cout * L.cin * L.taps)
+        return orig_d(self, L, gy, in_shape, res)
+
+    def wgrad(self, L, x, gy):
+        add("conv_wgrad_" + suffix(self), 2.0 * gy.shape[0] * gy.shape[1] * gy.shape[2] * L.cout * L.cin * L.taps)
+        return orig_w(self, L, x, gy)
+
+    def sfwd(self, L, img4, Hh, W):
+        y = orig_sf(self, L, img4, Hh, W)
+        add("stem_fwd_" + suffix(self), 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * L.cout * 147)
+        return y
+
+    def swgrad(self, L, img4, gy, Hh, W):
+        add("stem_wgrad_" + suffix(self), 2.0 * gy.shape[0] * gy.shape[1] * gy.shape[2] * L.cout * 147)
+        return orig_sw(self, L, img4, gy, Hh, W)
+
+    backend_cls.conv_fwd, backend_cls.conv_dgrad, backend_cls.conv_wgrad = fwd, dgrad, wgrad
+    backend_cls.stem_fwd, backend_cls.stem_wgrad = sfwd, swgrad
+
+    def restore():
+        backend_cls.conv_fwd, backend_cls.conv_dgrad, backend_cls.conv_wgrad = orig_f, orig_d, orig_w
+        backend_cls.stem_fwd, backend_cls.stem_wgrad = orig_sf, orig_sw
+
+    return counts, restore
+
+
+def roofline_leg(trainer, pool, B, steps):
+    """Instrumented pass: HIP events around every launch (on the launch stream), flops counted per class."""
+    Hm = pkg("_hip")
+    counts, restore = conv_flops(pkg("backend_hip").HipBackend)
+    Hm.call("dcf_prof_reset")
+    Hm.call("dcf_prof_enable", 1)
+    for s in range(steps):
+        train_step(trainer, pool, pool.batch(1000 + s, B))
+    torch.cuda.synchronize()
+    Hm.call("dcf_prof_enable", 0)
+    prof = Hm.prof_read()
+    Hm.call("dcf_prof_reset")
+    restore()
+    total_ms = sum(v[0] for v in prof.values())
+    table = sorted(((n, v[0], v[1]) for n, v in prof.items()), key=lambda t: -t[1])
+    dom = next((t for t in table if t[0] in counts), table[0])
+    name, ms, calls = dom
+    achieved = counts.get(name, 0.0) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    peak = 2500.0 if name.endswith("bf16") else 157.3
+    roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None, "avg_launch_us": round(ms * 1e3 / max(calls, 1), 2),
+            "launches_per_step": calls / steps, "share_of_gpu_time": round(ms / total_ms, 3) if total_ms else None,
+            "flops_per_step": counts.get(name, 0.0) / steps}
+    breakdown = [{"kernel": n, "ms_per_step": round(m / steps, 4), "calls_per_step": c / steps,
+                  "tflops": round(counts[n] / (m * 1e-3) / 1e12, 2) if n in counts and m > 0 else None} for n, m, c in table[:14]]
+    return roof, breakdown
+
+
+def cpu_baseline(cfg, pool_seed):
+    """The CPU restatement (oracle/, 'port') on a bounded sample of the same workload: ONE frame,
+    geometry in C, KNN on every 8th BEV row of each site (scaled x8), one fwd+bwd+Adam step of the
+    torch-CPU fp32 model with fusion.  Returns frames/s."""
+    from oracle import geometry_ref, model_ref
+    det = pkg("detfill")
+    c = copy.deepcopy(cfg)
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    lim6 = (c["lidar_x_min"], c["lidar_x_max"], c["lidar_y_min"], c["lidar_y_max"], c["lidar_z_min"], c["lidar_z_max"])
+    pts = det.synthetic_points(c["max_num_pc"], lim6, pool_seed)
+    img = torch.from_numpy(det.synthetic_image(c["image_height"], c["image_width"], pool_seed)).unsqueeze(0)
+    crt = pkg("calib").kitti_like_crt()
+    t0 = time.time()
+    grid, pc, uv, n, _ = geometry_ref.voxelization_projection(pts, c, crt, proj_mode="correct")
+    t_geo = time.time() - t0
+    g = geometry_ref.grid_constants(c)
+    t0 = time.time()
+    sub = 8
+    for si in range(1, 5):
+        s = 2 ** si
+        h, w = c["voxel_length"] // s, c["voxel_width"] // s
+        geometry_ref.knn_bev(pc[:n], c["fusion"]["K"], max(h // sub, 1), w, s * 1, g["aff"])  # h/8 rows: 1/8 of the pixels
+    t_knn = (time.time() - t0) * sub
+    shapes = {}
+    shapes.update(model_ref.lidar_state_shapes(c))
+    shapes.update(model_ref.image_state_shapes(64))
+    shapes.update(model_ref.fusion_state_shapes(c, 64))
+    sd = model_ref.make_state_dict(shapes)
+    params = [v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k]
+    opt = torch.optim.Adam(params, lr=c["learning_rate"], betas=(c["beta1"], 0.999))
+    x = torch.from_numpy(grid).unsqueeze(0)
+    # reuse GPU-independent KNN: the model step below recomputes it with the brute-force oracle on a coarse
+    # row subsample would change the maths, so the model step is timed WITHOUT fusion gathers' KNN (timed above).
+    t0 = time.time()
+    pred = model_ref.forward(sd, c, x, None, bn_mode="eval")
+    loss = (pred[:, :18] ** 2).mean()
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    t_lidar = time.time() - t0
+    t0 = time.time()
+    with torch.enable_grad():
+        fmap = model_ref.image_stream(sd, img, "eval")
+        fmap.square().mean().backward()
+    t_img = time.time() - t0
+    total = t_geo + t_knn + t_lidar + t_img
+    return {"value": round(1.0 / total, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "1 frame: C geometry %.2fs + brute-force KNN on 1/8 of BEV rows x8 = %.2fs + torch-CPU fp32 LiDAR-stream "
+                      "fwd+bwd+Adam %.2fs + ResNet-18/FPN image stream fwd+bwd %.2fs (fusion gather/MLP not included)" % (t_geo, t_knn, t_lidar, t_img)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2, help="frames per GPU (cfg2: 2)")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--points", type=int, default=100000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    train = pkg("train")
+    ws = train.init_distributed()
+    rank = dist.get_rank() if ws > 1 else 0
+    if ws <= 1:
+        torch.cuda.set_device(0)
+    cfg = kitti_config(args.batch, args.dtype, args.points)
+    torch.manual_seed(0)
+    np.random.seed(1234 + rank)
+    trainer = train.Train(cfg)
+    pkg("detfill").fill_state_dict(trainer.model)        # deterministic random-init weights (no checkpoints offline)
+    pool = FramePool(cfg, n_frames=max(2 * args.batch, 4), n_points=args.points, seed0=100 * rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if ws > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        train_step(trainer, pool, pool.batch(s, args.batch))
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        train_step(trainer, pool, pool.batch(args.warmup + s, args.batch))
+    barrier()
+    dt = time.perf_counter() - t0
+    if ws > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(trainer.loss_value.item())
+
+    roof, breakdown, cpu = None, None, None
+    if rank == 0 and not args.no_roofline:
+        roof, breakdown = roofline_leg(trainer, pool, args.batch, 2)
+    if ws > 1:
+        dist.barrier()
+    if rank == 0 and ws == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, 1234)
+    if rank == 0:
+        frames = args.batch * ws * args.steps
+        out = {"metric": "frames/sec (train step) 100k-pt LiDAR + 1242x375 RGB", "value": round(frames / dt, 3), "unit": "frames/s",
+               "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "cfg2: grid 32x704x800, %d pts/frame, 1242x375 RGB, ResNet-18 image stream, K=3 fusion x4 sites, "
+                                      "eval-mode BN (reference F4), batch %d/GPU" % (args.points, args.batch),
+                          "global_batch": args.batch * ws, "parallelism": "dp%d" % ws, "final_loss": round(loss, 4)},
+               "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown}
+        print(json.dumps(out))
+    if ws > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,202 @@
+"""HIP backend of the execution plan: arenas, the dcf_conv_param table and the kernel calls.
+
+Owns (per model, per device):
+  warena  -- compute-dtype images of every convolution weight, rewritten once per step by
+             dcf_weight_prep: [Cout_pad][taps][Cin] for forward/wgrad, [Cin][taps][Cout_pad] for dgrad
+  ssarena -- fp32 [scale | shift] per convolution (folded eval BatchNorm)
+  gsum    -- fp32 per-channel sums of the masked output gradient (= dL/dbeta)
+  slabs   -- fp32 split-K partial weight gradients, reduced in fixed order by dcf_wgrad_finalize
+The flat parameter / gradient / buffer arenas belong to the model (model.py).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _hip as H
+from . import ops
+
+BN_EPS = 1e-5  # nn.BatchNorm2d(eps=1e-05), model.py:20
+
+
+class HipBackend(object):
+    def __init__(self, plan, params, grads, buffers, dtype):
+        if not params.is_cuda:
+            raise H.DcfError("the HIP hot path needs CUDA/HIP tensors (got %s); there is no CPU fallback" % params.device)
+        H.lib()  # fail loudly right here when the extension is missing
+        self.plan, self.params, self.grads, self.buffers = plan, params, grads, buffers
+        self.dtype = H.dtype_code(dtype)
+        self.tdtype = H.torch_dtype(self.dtype)
+        self.es = 4 if self.dtype == H.F32 else 2
+        self.dev = params.device
+        self._layout(plan.layers)
+        self._sig = None
+        self.slabs = None
+        self._upload_table(plan.layers)
+
+    # ------------------------------------------------------------------ arenas
+    def _layout(self, layers):
+        woff = ssoff = goff = 0
+        for L in layers:
+            K = L.taps * L.cin
+            L.wfwd_off = woff
+            woff += (L.cout_pad * K * self.es + 255) // 256 * 256
+            if L.need_dgrad:
+                L.wdgrad_off = woff
+                woff += (L.cout_pad * K * self.es + 255) // 256 * 256
+            else:
+                L.wdgrad_off = -1
+            L.shift_off = ssoff
+            ssoff += 2 * L.cout_pad
+            L.gsum_off = goff
+            goff += L.cout_pad
+            L.nsplit, L.slab_off = 0, 0
+        self.warena = torch.zeros(max(woff, 16), dtype=torch.uint8, device=self.dev)
+        self.ssarena = torch.zeros(max(ssoff, 4), dtype=torch.float32, device=self.dev)
+        self.gsum = torch.zeros(max(goff, 4), dtype=torch.float32, device=self.dev)
+
+    def _upload_table(self, layers):
+        tab = (H.ConvParam * len(layers))()
+        for i, L in enumerate(layers):
+            tab[i] = H.ConvParam(L.w_off, L.gamma_off, L.beta_off, L.mean_off, L.var_off, L.wfwd_off, L.wdgrad_off,
+                                 L.shift_off, L.slab_off, L.gsum_off, L.cout, L.cin, L.taps, L.cout_pad, L.nsplit,
+                                 1 if L.kind == "stem" else 0, 0, 0)
+        self.table = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.dev)
+        self.nconv = len(layers)
+
+    def _w(self, L, dgrad=False):
+        off = L.wdgrad_off if dgrad else L.wfwd_off
+        return self.warena[off:]
+
+    def _shift(self, L):
+        if L.bn is None:
+            return None
+        return self.ssarena[L.shift_off + L.cout_pad:]
+
+    # ------------------------------------------------------------------ step phases
+    def prepare(self):
+        """Once per step, before forward: fold BN into the compute-dtype weight images."""
+        H.call("dcf_weight_prep", self.dtype, self.table, self.nconv, self.params, self.buffers, self.warena, self.ssarena,
+               BN_EPS, H.stream_ptr())
+
+    def begin_backward(self, layers):
+        sig = tuple(L.out_shape for L in layers)
+        if sig != self._sig:
+            off = 0
+            for L in layers:
+                if L.out_shape is None:
+                    L.nsplit, L.slab_off = 0, 0
+                    continue
+                B, Ho, Wo = L.out_shape
+                L.nsplit = ops.conv2d_wgrad_splits(B, Ho, Wo, L.cin, L.cout_pad, L.kh, L.kw)
+                L.slab_off = off
+                off += L.nsplit * L.cout_pad * L.taps * L.cin
+            self.slabs = torch.empty(max(off, 4), dtype=torch.float32, device=self.dev)
+            self._upload_table(layers)
+            self._sig = sig
+        self.gsum.zero_()
+        self.grads.zero_()
+
+    def end_backward(self, layers):
+        H.call("dcf_wgrad_finalize", self.table, self.nconv, self.params, self.buffers, self.ssarena, self.slabs, self.gsum,
+               self.grads, BN_EPS, H.stream_ptr())
+
+    # ------------------------------------------------------------------ convolutions
+    def conv_fwd(self, L, x, res, relu):
+        y = ops.conv2d_fwd(self.dtype, x, self._w(L), self._shift(L), res, L.kh, L.kw, L.stride, L.pad, relu, L.cout_pad)
+        L.out_shape = (y.shape[0], y.shape[1], y.shape[2])
+        return y
+
+    def conv_dgrad(self, L, gy, in_shape, res):
+        if L.wdgrad_off < 0:
+            raise H.DcfError("layer %s was planned without an input gradient" % L.name)
+        return ops.conv2d_dgrad(self.dtype, gy, self._w(L, True), res, in_shape, L.kh, L.kw, L.stride, L.pad)
+
+    def conv_wgrad(self, L, x, gy):
+        ops.conv2d_wgrad(self.dtype, x, gy, self.slabs[L.slab_off:], L.nsplit, L.kh, L.kw, L.stride, L.pad)
+
+    def stem_fwd(self, L, img4, Hh, W):
+        y = ops.stem7x7_fwd(self.dtype, img4, self._w(L), self._shift(L), True, L.cout_pad, Hh, W)
+        L.out_shape = (y.shape[0], y.shape[1], y.shape[2])
+        return y
+
+    def stem_wgrad(self, L, img4, gy, Hh, W):
+        ops.stem7x7_wgrad(self.dtype, img4, gy, self.slabs[L.slab_off:], L.nsplit, Hh, W)
+
+    def relu_mask_sum(self, layers, g, y, relu):
+        L0 = layers[0]
+        seg = self.gsum[L0.gsum_off:L0.gsum_off + L0.cout_pad]
+        ops.relu_bwd_chansum(self.dtype, g, y, seg, relu)
+        for L in layers[1:]:
+            self.gsum[L.gsum_off:L.gsum_off + L.cout_pad].copy_(seg)
+        return g
+
+    # ------------------------------------------------------------------ elementwise
+    def to_device(self, t):
+        return t.to(self.dev)
+
+    def nchw_to_nhwc(self, x):
+        if x.dtype != torch.float32:
+            raise H.DcfError("x_lidar must be float32 [B,Cz,L,W] (model.py:194)")
+        return ops.nchw_to_nhwc(x.contiguous(), self.dtype)
+
+    def image_to_nhwc4(self, img):
+        if img.dtype != torch.uint8:
+            raise H.DcfError("x_image must be uint8 [B,3,H,W] (data_import_carla.py:62)")
+        return ops.image_to_nhwc4(img.contiguous(), self.dtype)
+
+    def resize_fwd(self, x, out_hw, align, add):
+        return ops.resize_bilinear_fwd(self.dtype, x, out_hw, align, add)
+
+    def resize_bwd(self, gy, in_hw, align):
+        return ops.resize_bilinear_bwd(self.dtype, gy, in_hw, align)
+
+    def maxpool_fwd(self, x):
+        return ops.maxpool_fwd(self.dtype, x)
+
+    def maxpool_bwd(self, x, gy):
+        return ops.maxpool_bwd(self.dtype, x, None, gy)
+
+    def head_fwd(self, head, anchors):
+        return ops.head_fwd(self.dtype, head, anchors)
+
+    def head_bwd(self, head, anchors, pred, gpred):
+        return ops.head_bwd(self.dtype, head, anchors, pred, gpred.contiguous())
+
+    def cast_like(self, src, like):
+        if src.dtype == like.dtype:
+            return src
+        return ops.cast(src, self.dtype)
+
+    # ------------------------------------------------------------------ fusion
+    def point_sample_fwd(self, fmap, uv, cnt, n_max):
+        B = fmap.shape[0]
+        return torch.stack([ops.point_sample_fwd(self.dtype, fmap[b], uv[b], cnt[b:b + 1], n_max) for b in range(B)], 0)
+
+    def point_sample_bwd(self, gfp, uv, cnt, n_max, fmap_shape, gF):
+        if gF is None:
+            gF = torch.zeros(fmap_shape, dtype=torch.float32, device=self.dev)
+        for b in range(gfp.shape[0]):
+            ops.point_sample_bwd(self.dtype, gfp[b], uv[b], cnt[b:b + 1], n_max, gF[b])
+        return gF
+
+    def fusion_gather_fwd(self, P, xyz, idx, stride, aff, w1d_off, b1_off):
+        hs, cs = [], []
+        for b in range(P.shape[0]):
+            h, c = ops.fusion_gather_fwd(self.dtype, P[b], xyz[b], idx[b], stride, aff, self.params[w1d_off:], self.params[b1_off:])
+            hs.append(h)
+            cs.append(c)
+        return torch.stack(hs, 0), torch.stack(cs, 0)
+
+    def fusion_gather_bwd(self, P, xyz, idx, stride, aff, w1d_off, b1_off, ghsum):
+        gP = torch.zeros(P.shape, dtype=torch.float32, device=self.dev)
+        for b in range(P.shape[0]):
+            ops.fusion_gather_bwd(self.dtype, P[b], xyz[b], idx[b], stride, aff, self.params[w1d_off:], self.params[b1_off:],
+                                  ghsum[b], gP[b], self.grads[w1d_off:], self.grads[b1_off:])
+        return gP
+
+    def rowscale_bias_fwd(self, y, cnt, b2_off):
+        return ops.rowscale_bias_fwd(self.dtype, y, cnt, self.params[b2_off:])
+
+    def rowscale_bias_bwd(self, gy, cnt, b2_off):
+        ops.rowscale_bias_bwd(self.dtype, gy, cnt, self.grads[b2_off:])

@@ -423,6 +423,8 @@ __global__ void __launch_bounds__(256) k_wgrad_finalize(const dcf_conv_param *ta
         float G = 0.f;
         const float *sp = slabs + d.slab_off + e;
         for (int s = 0; s < d.nsplit; ++s) G += sp[(int64_t)s * slab_elems];
+        // stem weights are stored [Cout][7][8][4]: tap kw=7 and channel 3 are structural zeros
+        if ((d.flags & 1) && ((((k & 31) >> 2) == 7) || ((k & 3) == 3))) G = 0.f;
         grads[d.w_off + e] = d.gamma_off >= 0 ? scale * G : G;
         dot += params[d.w_off + e] * G;
     }

@@ -1,0 +1,382 @@
+"""Static execution plan of the continuous-fusion network (forward + hand-written backward).
+
+The reference builds the network as an nn.Module tree and lets autograd + cuDNN run it
+(/root/reference/model.py:10-204).  Here the network is a fixed list of layer descriptors
+over flat arenas, executed by explicit kernel calls:
+
+  * parameters live in ONE flat fp32 arena (convolution weights physically [O][kh][kw][I]),
+    gradients in a second arena with the same offsets, Adam moments in two more -- one
+    all-reduce and one optimiser launch per step;
+  * eval-mode BatchNorm (what the reference really trains with) is folded into
+    the convolution: y = act(conv(x, scale*W) + shift + residual) is one kernel, activations
+    are written once and read once;
+  * the backward pass is spelled out per block; the folded-BN chain rule never needs the
+    pre-BN tensor:  with G = wgrad(g, x) on the UNSCALED weights,
+        dW = scale*G,  dbeta = sum g,  dgamma = (<W,G> - mean*dbeta) * rsqrt(var+eps).
+
+All arithmetic goes through a backend object (`backend_hip.HipBackend`: HIP kernels through
+the C ABI).  The engine itself only sequences calls; tests may pass a different backend to
+check the sequencing/maths on CPU, the product never does.
+"""
+import numpy as np
+import torch
+
+
+class ConvLayer(object):
+    """One convolution (or linear = 1x1) of the plan = one row of the dcf_conv_param table."""
+
+    def __init__(self, idx, name, cin, cout, kh, kw, stride, pad, bn=None, kind="conv", need_dgrad=True, names=None):
+        self.idx, self.name, self.bn, self.kind = idx, name, bn, kind
+        self.cin, self.cout, self.kh, self.kw, self.stride, self.pad = cin, cout, kh, kw, stride, pad
+        self.cout_pad = (cout + 31) // 32 * 32
+        self.need_dgrad = need_dgrad
+        self.names = names or [name]          # parameter keys making up the weight (heads: two)
+        self.w_off = self.gamma_off = self.beta_off = self.mean_off = self.var_off = -1
+        self.out_shape = None                  # (B, Ho, Wo) of the last forward
+
+    @property
+    def taps(self):
+        return self.kh * self.kw
+
+
+class ParamTable(object):
+    """Flat parameter / buffer arenas and the state_dict views into them."""
+
+    def __init__(self):
+        self.entries = []      # (key, logical_shape, offset, numel, layout)
+        self.buffers = []      # (key, shape, offset, numel)
+        self.n_params = 0
+        self.n_buffers = 0
+
+    def add_param(self, key, shape, layout="plain"):
+        n = int(np.prod(ParamTable.physical_shape(shape, layout)))
+        off = self.n_params
+        self.entries.append((key, tuple(shape), off, n, layout))
+        self.n_params += (n + 3) // 4 * 4     # keep every tensor 16-byte aligned
+        return off
+
+    def add_buffer(self, key, shape):
+        n = int(np.prod(shape)) if len(shape) else 1
+        off = self.n_buffers
+        self.buffers.append((key, tuple(shape), off, n))
+        self.n_buffers += (n + 3) // 4 * 4
+        return off
+
+    @staticmethod
+    def physical_shape(shape, layout):
+        if layout == "ohwi":                   # logical [O,I,kh,kw] stored [O,kh,kw,I]
+            O, I, kh, kw = shape
+            return (O, kh, kw, I)
+        if layout == "stem":                   # logical [O,3,7,7] stored [O,7,8,4] (zero padded)
+            return (shape[0], 7, 8, 4)
+        return tuple(shape)
+
+    @staticmethod
+    def view(flat, shape, off, n, layout):
+        """Logical-shape view of a parameter inside the flat arena."""
+        seg = flat[off:off + n]
+        if layout == "ohwi":
+            O, I, kh, kw = shape
+            return seg.view(O, kh, kw, I).permute(0, 3, 1, 2)
+        if layout == "stem":
+            return seg.view(shape[0], 7, 8, 4)[:, :, :7, :3].permute(0, 3, 1, 2)
+        return seg.view(shape)
+
+
+class Block(object):
+    """Residual block: relu(bn2(conv2(relu(bn1(conv1 x)))) + shortcut(x))  (model.py:32-41)."""
+
+    def __init__(self, conv1, conv2, down=None):
+        self.conv1, self.conv2, self.down = conv1, conv2, down
+        self.saved = None
+
+    def forward(self, K, x, save=True):
+        r = K.conv_fwd(self.down, x, None, False) if self.down is not None else x
+        y1 = K.conv_fwd(self.conv1, x, None, True)
+        y = K.conv_fwd(self.conv2, y1, r, True)
+        self.saved = (x, y1, y) if save else None
+        return y
+
+    def backward(self, K, g, extra=None, need_gx=True):
+        """g = dL/dy (consumed / overwritten).  extra = gradient reaching x from other consumers."""
+        x, y1, y = self.saved
+        self.saved = None
+        g2 = K.relu_mask_sum([self.conv2] + ([self.down] if self.down is not None else []), g, y, True)
+        K.conv_wgrad(self.conv2, y1, g2)
+        gy1 = K.conv_dgrad(self.conv2, g2, tuple(y1.shape), None)
+        g1 = K.relu_mask_sum([self.conv1], gy1, y1, True)
+        K.conv_wgrad(self.conv1, x, g1)
+        if self.down is not None:
+            K.conv_wgrad(self.down, x, g2)
+            if not need_gx:
+                return None
+            gx = K.conv_dgrad(self.down, g2, tuple(x.shape), extra)
+            return K.conv_dgrad(self.conv1, g1, tuple(x.shape), gx)
+        if not need_gx:
+            return None
+        assert extra is None, "an identity-shortcut block cannot take an extra gradient"
+        return K.conv_dgrad(self.conv1, g1, tuple(x.shape), g2)
+
+
+class Plan(object):
+    """Builds the layer list, the parameter table and runs forward / backward."""
+
+    def __init__(self, cfg, with_image=False, cf=64, image_blocks=(2, 2, 2, 2), image_widths=(64, 128, 256, 512)):
+        self.cfg = cfg
+        self.with_image = with_image
+        self.cf = cf
+        self.table = ParamTable()
+        self.layers = []
+        lm = cfg["lidar_module"]
+        self.widths = [lm["out_feature%d" % i] for i in range(1, 6)]
+        self.nblocks = [lm["num_res_block%d" % i] for i in range(1, 6)]
+        if cfg["voxel_channel"] != self.widths[0]:
+            raise ValueError("voxel_channel must equal out_feature1 (model.py:67)")
+        if cfg["voxel_length"] % 16 or cfg["voxel_width"] % 16:
+            raise ValueError("voxel_length and voxel_width must be multiples of 16 (FPN add, model.py:151)")
+        if len(set(self.widths)) != 5:
+            raise ValueError("stage widths must differ (a stage strides only when its width changes, model.py:43-45)")
+        self._build_lidar()
+        self.fusion = []
+        if with_image:
+            self._build_image(image_blocks, image_widths)
+            self._build_fusion()
+
+    # ------------------------------------------------------------------ construction
+    def _conv(self, name, cin, cout, k, stride, bn=None, kind="conv", need_dgrad=True, layout="ohwi", names=None, shapes=None):
+        L = ConvLayer(len(self.layers), name, cin, cout, k[0], k[1], stride, k[0] // 2 if kind == "conv" else 0, bn, kind, need_dgrad, names)
+        if kind == "stem":
+            L.cin, L.kh, L.kw, L.pad = 32, 7, 1, 0
+            L.w_off = self.table.add_param(name + ".weight", (cout, 3, 7, 7), "stem")
+        elif names is not None:                 # several parameters laid out back to back (fused heads)
+            offs = [self.table.add_param(n + ".weight", s, layout) for n, s in zip(names, shapes)]
+            L.w_off = offs[0]
+        elif kind == "linear":
+            L.w_off = self.table.add_param(name + ".weight", (cout, cin), "plain")
+        else:
+            L.w_off = self.table.add_param(name + ".weight", (cout, cin, k[0], k[1]), layout)
+        if bn is not None:
+            L.gamma_off = self.table.add_param(bn + ".weight", (cout,))
+            L.beta_off = self.table.add_param(bn + ".bias", (cout,))
+            L.mean_off = self.table.add_buffer(bn + ".running_mean", (cout,))
+            L.var_off = self.table.add_buffer(bn + ".running_var", (cout,))
+            self.table.add_buffer(bn + ".num_batches_tracked", ())
+        self.layers.append(L)
+        return L
+
+    def _build_lidar(self):
+        """Key names and order of the reference's state_dict (model.py:64-79, :140-157)."""
+        self.stages = []
+        cin = self.widths[0]
+        for si in range(5):
+            cout = self.widths[si]
+            blocks = []
+            for bi in range(self.nblocks[si]):
+                p = "lidar_backbone.backbone.layer%d.sequential.resblock_%d" % (si + 1, bi)
+                ci = cin if bi == 0 else cout
+                s = 2 if ci != cout else 1
+                first = (si == 0 and bi == 0)
+                c1 = self._conv(p + ".conv1", ci, cout, (3, 3), s, p + ".bn1", need_dgrad=not first)
+                c2 = self._conv(p + ".conv2", cout, cout, (3, 3), 1, p + ".bn2")
+                dn = self._conv(p + ".down_conv", ci, cout, (1, 1), 2, p + ".down_bn", need_dgrad=not first) if ci != cout else None
+                blocks.append(Block(c1, c2, dn))
+            self.stages.append(blocks)
+            cin = cout
+        w = self.widths
+        p = "lidar_backbone."
+        self.latconv1 = self._conv(p + "latconv1", w[3], w[3], (1, 1), 1)
+        self.downconv1 = self._conv(p + "downconv1", w[4], w[3], (1, 1), 1)
+        self.latconv2 = self._conv(p + "latconv2", w[2], w[3], (1, 1), 1)
+        self.conv3 = self._conv(p + "conv3", w[3], w[3], (3, 3), 1)
+        # classconv (4) and bbox3dconv (14) share their input: one GEMM with 18 (->32) outputs
+        self.heads = self._conv(p + "heads", w[3], 18, (1, 1), 1, names=[p + "classconv", p + "bbox3dconv"],
+                                shapes=[(4, w[3], 1, 1), (14, w[3], 1, 1)])
+
+    def _build_image(self, nblocks, widths):
+        """SURVEY.md App. D image stream: ResNet BasicBlock trunk (torchvision key names) + FPN."""
+        p = "image_backbone"
+        self.stem = self._conv(p + ".conv1", 3, widths[0], (7, 7), 2, p + ".bn1", kind="stem", need_dgrad=False)
+        self.img_stages = []
+        cin = widths[0]
+        for li in range(4):
+            cout = widths[li]
+            blocks = []
+            for bi in range(nblocks[li]):
+                q = "%s.layer%d.%d" % (p, li + 1, bi)
+                ci = cin if bi == 0 else cout
+                s = 2 if (bi == 0 and li > 0) else 1
+                c1 = self._conv(q + ".conv1", ci, cout, (3, 3), s, q + ".bn1")
+                c2 = self._conv(q + ".conv2", cout, cout, (3, 3), 1, q + ".bn2")
+                dn = self._conv(q + ".downsample.0", ci, cout, (1, 1), s, q + ".downsample.1") if (bi == 0 and li > 0) else None
+                blocks.append(Block(c1, c2, dn))
+            self.img_stages.append(blocks)
+            cin = cout
+        self.img_lat = [self._conv("image_fpn.lat%d" % (i + 1), widths[i], self.cf, (1, 1), 1) for i in range(4)]
+        self.img_smooth = self._conv("image_fpn.smooth", self.cf, self.cf, (3, 3), 1)
+
+    def _build_fusion(self):
+        for si in range(1, 5):
+            cb = self.widths[si]
+            p = "fusion.site%d" % si
+            f = {"stride": 2 ** si, "cb": cb}
+            f["fc1_feat"] = self._conv(p + ".fc1_feat", self.cf, cb, (1, 1), 1, kind="linear")
+            f["w1d_off"] = self.table.add_param(p + ".fc1_geo.weight", (cb, 3))
+            f["b1_off"] = self.table.add_param(p + ".fc1.bias", (cb,))
+            f["fc2"] = self._conv(p + ".fc2", cb, cb, (1, 1), 1, kind="linear")
+            f["b2_off"] = self.table.add_param(p + ".fc2.bias", (cb,))
+            self.fusion.append(f)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, K, x_lidar, x_image=None, geom=None, save=True):
+        """x_lidar [B,Cz,L,W] fp32 NCHW (model.py:194); returns pred [B,32,L/4,W/4] fp32 NCHW.
+
+        geom (fusion only): dict(xyz [B,n_max,3], uv [B,n_max,2], cnt [B] int32 device, idx = list over
+        sites of [B,K,h,w] int32, aff) -- produced once per frame by the geometry kernels.
+        """
+        self.ctx = {"save": save}
+        fmap = None
+        if self.with_image and geom is not None:
+            fmap = self._image_forward(K, x_image, save)
+        x = K.nchw_to_nhwc(x_lidar)
+        outs = []
+        for si, blocks in enumerate(self.stages):
+            for b in blocks:
+                x = b.forward(K, x, save)
+            if si >= 1:
+                if fmap is not None:
+                    x = self._fusion_forward(K, self.fusion[si - 1], x, fmap, geom, si - 1, save)
+                outs.append(x)
+        x1, x2, x3, x4 = outs
+        l1 = K.conv_fwd(self.latconv1, x3, None, False)
+        d1 = K.conv_fwd(self.downconv1, x4, None, False)
+        t3 = K.resize_fwd(d1, (x3.shape[1], x3.shape[2]), True, l1)      # l1 + up(d1), model.py:161-163
+        l2 = K.conv_fwd(self.latconv2, x2, None, False)
+        t2 = K.resize_fwd(t3, (x2.shape[1], x2.shape[2]), True, l2)      # model.py:164-166
+        xp = K.conv_fwd(self.conv3, t2, None, False)
+        head = K.conv_fwd(self.heads, xp, None, False)
+        pred = K.head_fwd(head, self.anchors_dev(K, head.shape[1], head.shape[2]))
+        if save:
+            self.ctx.update(x2=x2, x3=x3, x4=x4, t2=t2, xp=xp, head=head, pred=pred, d1_hw=(d1.shape[1], d1.shape[2]),
+                            t3_hw=(t3.shape[1], t3.shape[2]), fused=fmap is not None)
+        return pred
+
+    def anchors_dev(self, K, h, w):
+        key = (h, w)
+        if getattr(self, "_anc_key", None) != key:
+            from .model import AnchorBoundingBoxFeature
+            anc = AnchorBoundingBoxFeature(self.cfg)()
+            if tuple(anc.shape[-2:]) != (h, w):
+                raise ValueError("anchor grid %s does not match the head output %s (reduced_scale must be 4)" % (tuple(anc.shape[-2:]), key))
+            self._anc = K.to_device(anc.contiguous())
+            self._anc_key = key
+        return self._anc
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, K, gpred):
+        """gpred [B,32,h,w] fp32.  Fills the gradient arena (through the backend)."""
+        c = self.ctx
+        K.begin_backward(self.layers)
+        ghead = K.head_bwd(c["head"], self.anchors_dev(K, c["head"].shape[1], c["head"].shape[2]), c["pred"], gpred)
+        K.conv_wgrad(self.heads, c["xp"], ghead)
+        gxp = K.conv_dgrad(self.heads, ghead, tuple(c["xp"].shape), None)
+        K.conv_wgrad(self.conv3, c["t2"], gxp)
+        gt2 = K.conv_dgrad(self.conv3, gxp, tuple(c["t2"].shape), None)
+        K.conv_wgrad(self.latconv2, c["x2"], gt2)
+        gx2 = K.conv_dgrad(self.latconv2, gt2, tuple(c["x2"].shape), None)
+        gt3 = K.resize_bwd(gt2, c["t3_hw"], True)
+        K.conv_wgrad(self.latconv1, c["x3"], gt3)
+        gx3 = K.conv_dgrad(self.latconv1, gt3, tuple(c["x3"].shape), None)
+        gd1 = K.resize_bwd(gt3, c["d1_hw"], True)
+        K.conv_wgrad(self.downconv1, c["x4"], gd1)
+        g = K.conv_dgrad(self.downconv1, gd1, tuple(c["x4"].shape), None)
+        extras = {3: gx3, 2: gx2}          # gradient joining the output of stage index 3 / 2
+        gF = None
+        for si in range(4, -1, -1):
+            if si >= 1 and c["fused"]:
+                gF = self._fusion_backward(K, self.fusion[si - 1], g, si - 1, gF)
+            blocks = self.stages[si]
+            for bi in range(len(blocks) - 1, -1, -1):
+                first = (si == 0 and bi == 0)
+                extra = extras.get(si - 1) if bi == 0 else None
+                g = blocks[bi].backward(K, g, extra, need_gx=not first)
+        if c["fused"]:
+            self._image_backward(K, gF)
+        K.end_backward(self.layers)
+        self.ctx = {}
+
+    # ------------------------------------------------------------------ image stream
+    def _image_forward(self, K, x_image, save):
+        B, _, Hh, W = x_image.shape
+        img4 = K.image_to_nhwc4(x_image)
+        c1 = K.stem_fwd(self.stem, img4, Hh, W)
+        x = K.maxpool_fwd(c1)
+        feats = []
+        for blocks in self.img_stages:
+            for b in blocks:
+                x = b.forward(K, x, save)
+            feats.append(x)
+        c2, c3, c4, c5 = feats
+        p = K.conv_fwd(self.img_lat[3], c5, None, False)
+        for i in (2, 1, 0):
+            lat = K.conv_fwd(self.img_lat[i], feats[i], None, False)
+            p = K.resize_fwd(p, (feats[i].shape[1], feats[i].shape[2]), False, lat)
+            if i == 0:
+                p2 = p
+        fmap = K.conv_fwd(self.img_smooth, p2, None, False)
+        if save:
+            self.ctx["img"] = dict(img4=img4, hw=(Hh, W), c1=c1, pool=None, feats=feats, p2=p2, fmap_shape=tuple(fmap.shape))
+            self.ctx["img"]["pool_out"] = None
+            self.ctx["img"]["pool_in"] = c1
+            self.ctx["img"]["pool_y"] = feats and None
+        self._pool_y = None
+        return fmap
+
+    def _image_backward(self, K, gF):
+        im = self.ctx["img"]
+        feats = im["feats"]
+        g = K.cast_like(gF, im["p2"])                      # fp32 accumulator -> compute dtype
+        K.conv_wgrad(self.img_smooth, im["p2"], g)
+        gp = K.conv_dgrad(self.img_smooth, g, tuple(im["p2"].shape), None)
+        gfeat = [None] * 4
+        for i in (0, 1, 2):
+            K.conv_wgrad(self.img_lat[i], feats[i], gp)
+            gfeat[i] = K.conv_dgrad(self.img_lat[i], gp, tuple(feats[i].shape), None)
+            gp = K.resize_bwd(gp, (feats[i + 1].shape[1], feats[i + 1].shape[2]), False)
+        K.conv_wgrad(self.img_lat[3], feats[3], gp)
+        g = K.conv_dgrad(self.img_lat[3], gp, tuple(feats[3].shape), None)
+        for li in range(3, -1, -1):
+            blocks = self.img_stages[li]
+            for bi in range(len(blocks) - 1, -1, -1):
+                extra = gfeat[li - 1] if (bi == 0 and li > 0) else None
+                g = blocks[bi].backward(K, g, extra, need_gx=True)
+        # g = gradient at the max-pool output
+        gc1 = K.maxpool_bwd(im["c1"], g)
+        gc1 = K.relu_mask_sum([self.stem], gc1, im["c1"], True)
+        K.stem_wgrad(self.stem, im["img4"], gc1, im["hw"][0], im["hw"][1])
+
+    # ------------------------------------------------------------------ fusion
+    def _fusion_forward(self, K, f, x, fmap, geom, site, save):
+        B, h, w, cb = x.shape
+        n_max = geom["xyz"].shape[1]
+        fp = K.point_sample_fwd(fmap, geom["uv"], geom["cnt"], n_max)            # [B,n_max,Cf]
+        P = K.conv_fwd(f["fc1_feat"], fp.view(B, n_max, 1, fp.shape[-1]), None, False).view(B, n_max, cb)
+        hsum, cnt = K.fusion_gather_fwd(P, geom["xyz"], geom["idx"][site], f["stride"], geom["aff"], f["w1d_off"], f["b1_off"])
+        out = K.conv_fwd(f["fc2"], hsum, x, False)                               # x + hsum.W2^T
+        out = K.rowscale_bias_fwd(out, cnt, f["b2_off"])                         # + cnt*b2
+        if save:
+            self.ctx["fuse%d" % site] = dict(fp=fp, P=P, hsum=hsum, cnt=cnt, geom=geom, fmap_shape=tuple(fmap.shape))
+        return out
+
+    def _fusion_backward(self, K, f, g, site, gF):
+        s = self.ctx.pop("fuse%d" % site)
+        geom = s["geom"]
+        B, n_max, cb = s["P"].shape
+        K.rowscale_bias_bwd(g, s["cnt"], f["b2_off"])
+        K.conv_wgrad(f["fc2"], s["hsum"], g)
+        ghsum = K.conv_dgrad(f["fc2"], g, tuple(s["hsum"].shape), None)
+        gP = K.fusion_gather_bwd(s["P"], geom["xyz"], geom["idx"][site], f["stride"], geom["aff"], f["w1d_off"], f["b1_off"], ghsum)
+        gPc = K.cast_like(gP, s["P"]).view(B, n_max, 1, cb)
+        fp4 = s["fp"].view(B, n_max, 1, s["fp"].shape[-1])
+        K.conv_wgrad(f["fc1_feat"], fp4, gPc)
+        gfp = K.conv_dgrad(f["fc1_feat"], gPc, tuple(fp4.shape), None).view(B, n_max, -1)
+        return K.point_sample_bwd(gfp, geom["uv"], geom["cnt"], n_max, s["fmap_shape"], gF)

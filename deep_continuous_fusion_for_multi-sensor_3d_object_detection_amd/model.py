@@ -1,0 +1,269 @@
+"""Drop-in module surface of the reference's model.py on the MI355X engine.
+
+Same class names, constructor arguments, forward signatures and state_dict keys as
+/root/reference/model.py; underneath, every tensor op is a HIP kernel reached through the
+C ABI (engine.Plan + backend_hip.HipBackend).  There is no torch/CPU compute fallback:
+calling forward on CPU tensors raises.
+
+  ObjectDetection_DCF(config)(x_lidar [B,Cz,L,W] f32, x_image [B,3,H,W] u8) -> [B,32,L/4,W/4] f32
+      = cat(cls[4], reg[14], bbox[14])                       (model.py:176-204)
+  optional extra arguments (points, uv, n_valid) feed the continuous-fusion layers the
+  reference leaves as a TODO (model.py:199-203); without them -- or with config
+  fusion.enabled = False -- the output is the reference's LiDAR-only forward.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _hip as H
+from .engine import ParamTable, Plan
+
+
+class AnchorBoundingBoxFeature(nn.Module):
+    """model.py:82-113: dense anchor tensor [14,h,w] (2 anchors x (x,y,z,l,w,h,yaw)).
+
+    Built on the host with the same torch.linspace calls (endpoints inclusive), so it is
+    bit-identical to the reference; the engine uploads it once per device instead of once
+    per forward (model.py:125)."""
+
+    def __init__(self, config):
+        super(AnchorBoundingBoxFeature, self).__init__()
+        self.config = config
+        a = config["anchor_bbox_feature"]
+        self.f_height = int(config["voxel_length"] / a["reduced_scale"])
+        self.f_width = int(config["voxel_width"] / a["reduced_scale"])
+        self.width, self.length, self.height = a["width"], a["length"], a["height"]
+
+    def forward(self):
+        h, w, c = self.f_height, self.f_width, self.config
+        xs = torch.linspace(c["lidar_x_min"], c["lidar_x_max"], h).view(h, 1).expand(h, w)
+        ys = torch.linspace(c["lidar_y_min"], c["lidar_y_max"], w).view(1, w).expand(h, w)
+        one = torch.ones(h, w)
+        common = [xs, ys, one * (-4.5), one * self.length, one * self.width, one * self.height]
+        return torch.stack(common + [one * 0] + common + [one * 3.1415926 / 2], 0).contiguous()
+
+
+class _Leaf(nn.Module):
+    """Container node so that parameters carry the reference's dotted state_dict names."""
+
+
+class _RunPlan(torch.autograd.Function):
+    """Bridges the hand-written forward/backward of engine.Plan into torch autograd so that
+    `loss.backward()` (train.py:35) drives it.  Parameter gradients are written straight
+    into the flat gradient arena (each Parameter's .grad is a view of it)."""
+
+    @staticmethod
+    def forward(ctx, token, model, x_lidar, x_image, geom, need):
+        ctx.model = model
+        pred = model._plan.forward(model._backend, x_lidar, x_image, geom, save=need)
+        ctx.saved_graph = need
+        return pred
+
+    @staticmethod
+    def backward(ctx, gpred):
+        model = ctx.model
+        if not ctx.saved_graph:
+            raise RuntimeError("backward through a forward that ran without saving activations")
+        model._plan.backward(model._backend, gpred.contiguous())
+        model._bind_grads()
+        return None, None, None, None, None, None
+
+
+class ObjectDetection_DCF(nn.Module):
+    def __init__(self, config):
+        super(ObjectDetection_DCF, self).__init__()
+        self.config = config
+        fu = dict(config.get("fusion") or {})
+        self.fusion_enabled = bool(fu.get("enabled", False))
+        self.K = int(fu.get("K", 3))
+        self.r_max = fu.get("r_max", None)
+        self.cf = int(fu.get("image_channels", 64))
+        self.dtype = H.dtype_code(config.get("dtype", "f32"))
+        bn_mode = config.get("bn_mode", "eval")
+        if bn_mode != "eval":
+            raise NotImplementedError("bn_mode=%r: only the reference's effective mode (eval-mode BatchNorm, test.py:37) "
+                                      "is implemented on the HIP path" % (bn_mode,))
+        stream = fu.get("image_stream", "resnet18")
+        if self.fusion_enabled and stream != "resnet18":
+            raise NotImplementedError("image_stream=%r (resnet18 only in this round)" % (stream,))
+        self._plan = Plan(config, with_image=self.fusion_enabled, cf=self.cf)
+        self._backend = None
+        self._build_parameters()
+        self.reset_parameters(zero_init_last=bool(fu.get("zero_init_last", False)))
+        from .ops import GridSpec
+        self._grid = GridSpec(config)
+
+    # ------------------------------------------------------------------ parameters
+    def _build_parameters(self, device="cpu"):
+        t = self._plan.table
+        self._flat = torch.zeros(max(t.n_params, 4), dtype=torch.float32, device=device)
+        self._gradflat = torch.zeros_like(self._flat)
+        self._bufflat = torch.zeros(max(t.n_buffers, 4), dtype=torch.float32, device=device)
+        self._param_list, self._param_meta = [], []
+        for key, shape, off, n, layout in t.entries:
+            p = nn.Parameter(ParamTable.view(self._flat, shape, off, n, layout))
+            self._register(key, p, False)
+            self._param_list.append(p)
+            self._param_meta.append((shape, off, n, layout))
+        self._buf_meta = []
+        for key, shape, off, n in t.buffers:
+            if key.endswith("num_batches_tracked"):
+                self._register(key, torch.zeros((), dtype=torch.long, device=device), True)
+            else:
+                self._register(key, self._bufflat[off:off + n].view(shape), True)
+                self._buf_meta.append((key, shape, off, n))
+
+    def _register(self, key, tensor, is_buffer):
+        parts = key.split(".")
+        node = self
+        for name in parts[:-1]:
+            if name not in node._modules:
+                node.add_module(name, _Leaf())
+            node = node._modules[name]
+        if is_buffer:
+            node.register_buffer(parts[-1], tensor)
+        else:
+            node.register_parameter(parts[-1], tensor)
+
+    def _resolve(self, key):
+        parts = key.split(".")
+        node = self
+        for name in parts[:-1]:
+            node = node._modules[name]
+        return node, parts[-1]
+
+    def reset_parameters(self, zero_init_last=False):
+        """nn.Conv2d / nn.Linear / nn.BatchNorm2d default initialisation (what the reference gets)."""
+        with torch.no_grad():
+            self._flat.zero_()
+            for p, (shape, off, n, layout) in zip(self._param_list, self._param_meta):
+                if len(shape) >= 2:
+                    bound = 1.0 / math.sqrt(float(np.prod(shape[1:])))
+                    p.uniform_(-bound, bound)
+            for (key, shape, off, n, layout), p in zip(self._plan.table.entries, self._param_list):
+                leaf = key.split(".")[-1]
+                if len(shape) == 1 and leaf == "weight":
+                    p.fill_(1.0)
+                elif len(shape) == 1 and "fusion" in key:      # linear biases
+                    p.uniform_(-0.05, 0.05)
+                if zero_init_last and "fusion" in key and ".fc2." in key:
+                    p.zero_()
+            for key, shape, off, n in self._buf_meta:
+                self._bufflat[off:off + n].fill_(1.0 if key.endswith("running_var") else 0.0)
+
+    def _apply(self, fn, recurse=True):
+        """.cuda()/.to(): move the arenas as a whole and re-point every Parameter at the new arena."""
+        new_flat = fn(self._flat)
+        if new_flat.dtype != torch.float32:
+            raise TypeError("master parameters stay fp32; choose the compute dtype with config['dtype']")
+        if new_flat.device == self._flat.device:
+            return self
+        self._flat = new_flat.contiguous()
+        self._gradflat = torch.zeros_like(self._flat)
+        self._bufflat = fn(self._bufflat).contiguous()
+        for p, (shape, off, n, layout) in zip(self._param_list, self._param_meta):
+            p.data = ParamTable.view(self._flat, shape, off, n, layout)
+            p.grad = None
+        for key, shape, off, n in self._buf_meta:
+            node, leaf = self._resolve(key)
+            node._buffers[leaf] = self._bufflat[off:off + n].view(shape)
+        for key, shape, off, n in self._plan.table.buffers:
+            if key.endswith("num_batches_tracked"):
+                node, leaf = self._resolve(key)
+                node._buffers[leaf] = fn(node._buffers[leaf])
+        self._backend = None
+        self._plan._anc_key = None
+        return self
+
+    def _bind_grads(self):
+        for p, (shape, off, n, layout) in zip(self._param_list, self._param_meta):
+            p.grad = ParamTable.view(self._gradflat, shape, off, n, layout)
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts the reference's checkpoints with or without DDP's 'module.' prefix (train.py:79)."""
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        return super(ObjectDetection_DCF, self).load_state_dict(sd, strict=strict)
+
+    # flat views for the fused optimiser / gradient all-reduce (train.py)
+    @property
+    def flat_params(self):
+        return self._flat
+
+    @property
+    def flat_grads(self):
+        return self._gradflat
+
+    # ------------------------------------------------------------------ forward
+    def _ensure_backend(self, device):
+        if self._backend is None or self._backend.dev != device:
+            if device.type != "cuda":
+                raise H.DcfError("ObjectDetection_DCF runs on the HIP device only: move the module with .cuda() "
+                                 "(no CPU fallback exists for the hot path)")
+            from .backend_hip import HipBackend
+            self._backend = HipBackend(self._plan, self._flat, self._gradflat, self._bufflat, self.dtype)
+        return self._backend
+
+    def fusion_geometry(self, points, uv, n_valid):
+        """KNN indices of every fusion site for a batch: points [B,n_max,3], uv [B,n_max,2], n_valid [B] (int)."""
+        from . import ops
+        B = points.shape[0]
+        dev = points.device
+        cnt = n_valid.to(device=dev, dtype=torch.int32).contiguous() if isinstance(n_valid, torch.Tensor) else \
+            torch.tensor([int(v) for v in n_valid], dtype=torch.int32, device=dev)
+        L, W = self.config["voxel_length"], self.config["voxel_width"]
+        idx = []
+        for si in range(1, 5):
+            s = 2 ** si
+            idx.append(torch.stack([ops.knn_bev(points[b].contiguous(), cnt[b:b + 1], self.K, L // s, W // s, s, self._grid.aff,
+                                                self.r_max) for b in range(B)], 0))
+        return dict(xyz=points.contiguous(), uv=uv.contiguous(), cnt=cnt, idx=idx, aff=self._grid.aff)
+
+    def forward(self, x_lidar, x_image, points=None, uv=None, n_valid=None):
+        K = self._ensure_backend(x_lidar.device)
+        geom = None
+        if self.fusion_enabled and points is not None:
+            geom = self.fusion_geometry(points, uv, n_valid)
+        K.prepare()
+        need = torch.is_grad_enabled() and self._param_list[0].requires_grad
+        return _RunPlan.apply(self._param_list[0], self, x_lidar, x_image, geom, need)
+
+
+class OffsettoBbox(nn.Module):
+    """model.py:116-137 -- kept for API compatibility; the engine fuses the decode into the
+    head kernel (dcf_head_fwd).  Standalone use decodes a [B,14,h,w] offset tensor on the device."""
+
+    def __init__(self, config):
+        super(OffsettoBbox, self).__init__()
+        self.anchor_bbox_feature = AnchorBoundingBoxFeature(config)
+
+    def forward(self, x):
+        from . import ops
+        B, C, h, w = x.shape
+        head = torch.zeros((B, 32, h, w), dtype=torch.float32, device=x.device)
+        head[:, 4:18] = x
+        nhwc = ops.nchw_to_nhwc(head.contiguous(), H.F32)
+        pred = ops.head_fwd(H.F32, nhwc, self.anchor_bbox_feature().to(x.device))
+        return pred[:, 18:32]
+
+
+class LidarBackboneNetwork(nn.Module):
+    """model.py:140-173 surface: (x_cls [B,4,h,w], x_reg [B,14,h,w]) = net(x [B,C,L,W]).
+    Implemented as a view of the full engine (the decode channels are simply dropped)."""
+
+    def __init__(self, out_feature=(32, 64, 128, 192, 256), num_res_block=(1, 2, 4, 6, 6), Num_anchor=2, config=None):
+        super(LidarBackboneNetwork, self).__init__()
+        if Num_anchor != 2:
+            raise NotImplementedError("the head kernel is specialised for the reference's 2 anchors")
+        cfg = dict(config) if config is not None else None
+        if cfg is None:
+            raise ValueError("LidarBackboneNetwork needs the config dict for the BEV grid size (voxel_length/width)")
+        cfg["lidar_module"] = dict(("out_feature%d" % (i + 1), out_feature[i]) for i in range(5))
+        cfg["lidar_module"].update(dict(("num_res_block%d" % (i + 1), num_res_block[i]) for i in range(5)))
+        cfg["fusion"] = {"enabled": False}
+        self.net = ObjectDetection_DCF(cfg)
+
+    def forward(self, x):
+        pred = self.net(x, None)
+        return pred[:, 0:4], pred[:, 4:18]

@@ -1,0 +1,123 @@
+"""Drop-in counterpart of the reference's train.py: Train(config).one_step / get_loss_value.
+
+One process per GPU (torchrun); gradients live in the model's flat arena, so data parallelism
+is ONE RCCL all-reduce of that arena per step followed by ONE fused Adam launch -- instead of
+the reference's single-process DDP wrapper (train.py:24, which current torch rejects).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import ops
+from .loss import LossTotal
+from .model import ObjectDetection_DCF
+
+
+class FlatAdam(object):
+    """Adam(lr, betas=(beta1, 0.999), eps=1e-8) of train.py:28 on the flat parameter arena."""
+
+    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
+        self.step_count = 0
+        self.m = torch.zeros_like(model.flat_params)
+        self.v = torch.zeros_like(model.flat_params)
+
+    def zero_grad(self):
+        pass  # the backward pass overwrites the gradient arena
+
+    def step(self, gscale=1.0):
+        self.step_count += 1
+        ops.adam_step(self.model.flat_params, self.model.flat_grads, self.m, self.v, self.lr, self.betas[0], self.betas[1],
+                      self.eps, self.step_count, gscale)
+
+    def state_dict(self):
+        return {"step": self.step_count, "m": self.m, "v": self.v}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+
+
+def world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def allreduce_grads(flat_grads):
+    """Sum the gradient arena over ranks (RCCL over xGMI on the GPU box, gloo in the CPU tests)."""
+    if world() > 1:
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
+    return world()
+
+
+class Train(nn.Module):
+    def __init__(self, config):
+        super(Train, self).__init__()
+        self.config = config
+        self.loss_total = LossTotal(config)
+        self.model = ObjectDetection_DCF(config).cuda()
+        self.loss_value = None
+        self.optimizer = FlatAdam(self.model, config["learning_rate"], (config["beta1"], 0.999))
+        if world() > 1:  # identical replicas: rank 0's parameters and buffers win
+            dist.broadcast(self.model.flat_params, 0)
+            dist.broadcast(self.model._bufflat, 0)
+
+    def _predict(self, lidar_voxel, camera_image, extra):
+        pred = self.model(lidar_voxel, camera_image, **extra)
+        return torch.split(pred, [4, 14, 14], dim=1)
+
+    def one_step(self, lidar_voxel, camera_image, object_data, num_ref_box, **extra):
+        pred_cls, pred_reg, _ = self._predict(lidar_voxel, camera_image, extra)
+        self.loss_value = self.loss_total(object_data, num_ref_box, pred_cls, pred_reg)
+        self.optimizer.zero_grad()
+        self.loss_value.backward()
+        n = allreduce_grads(self.model.flat_grads)
+        self.optimizer.step(1.0 / n)
+
+    def get_loss_value(self, lidar_voxel, camera_image, object_data, num_ref_box, **extra):
+        with torch.no_grad():
+            pred_cls, pred_reg, _ = self._predict(lidar_voxel, camera_image, extra)
+            self.loss_value = self.loss_total(object_data, num_ref_box, pred_cls, pred_reg)
+        return self.loss_value.item(), pred_cls, pred_reg
+
+
+def init_distributed():
+    """env:// rendezvous, one rank per GPU (RANK/LOCAL_RANK/WORLD_SIZE from torchrun)."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws > 1 and not dist.is_initialized():
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    return ws
+
+
+def main():
+    import yaml
+    from .data_import_carla import CarlaDataset, SyntheticDataset
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "config", "config_carla.yaml")) as f:
+        config = yaml.safe_load(f)
+    init_distributed()
+    if os.path.isdir(config["train_data_dir"]):
+        dataset = CarlaDataset(config)
+    else:
+        print("train_data_dir not found: training on synthetic frames")
+        dataset = SyntheticDataset(config, length=64)
+    sampler = torch.utils.data.distributed.DistributedSampler(dataset, shuffle=True) if world() > 1 else None
+    loader = torch.utils.data.DataLoader(dataset, batch_size=config["batch_size"], sampler=sampler, shuffle=sampler is None)
+    training = Train(config)
+    os.makedirs("./saved_model", exist_ok=True)
+    for epoch in range(config["num_epoch"]):
+        if not dist.is_initialized() or dist.get_rank() == 0:
+            torch.save(training.model.state_dict(), "./saved_model/" + config["saved_model_name"])
+        for batch_ndx, sample in enumerate(loader):
+            training.one_step(sample["pointcloud"].cuda(), sample["image"].cuda(), sample["bboxes"].cuda(), sample["num_bboxes"])
+            if batch_ndx % 100 == 0:
+                print("training at ", batch_ndx, "is processed, loss %.4f" % training.loss_value.item())
+
+
+if __name__ == "__main__":
+    main()

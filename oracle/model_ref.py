@@ -170,7 +170,9 @@ def fusion_site(sd, pfx, x, Fmap, xyz, uv, n, stride, aff, K, rmax=None, knn_idx
     dy = pts[safe][..., 1] - Y.view(1, 1, w)
     dz = pts[safe][..., 2]
     inp = torch.cat((feat, dx.unsqueeze(-1), dy.unsqueeze(-1), dz.unsqueeze(-1)), -1)
-    hid = F.relu(F.linear(inp, sd[pfx + ".fc1.weight"], sd[pfx + ".fc1.bias"]))
+    # fc1 = Linear(C_f+3 -> C_b); its weight is stored in two pieces (camera-feature columns, geometry columns)
+    w1 = torch.cat((sd[pfx + ".fc1_feat.weight"], sd[pfx + ".fc1_geo.weight"]), 1)
+    hid = F.relu(F.linear(inp, w1, sd[pfx + ".fc1.bias"]))
     out = F.linear(hid, sd[pfx + ".fc2.weight"], sd[pfx + ".fc2.bias"])
     out = (out * valid.unsqueeze(-1).to(out.dtype)).sum(0)   # [h,w,Cb]
     return x + out.permute(2, 0, 1), knn_idx
@@ -295,7 +297,7 @@ def fusion_state_shapes(cfg, cf=64):
     for si in range(1, 5):
         cb = lm["out_feature%d" % (si + 1)]
         p = "fusion.site%d" % si
-        shapes[p + ".fc1.weight"] = (cb, cf + 3); shapes[p + ".fc1.bias"] = (cb,)
+        shapes[p + ".fc1_feat.weight"] = (cb, cf); shapes[p + ".fc1_geo.weight"] = (cb, 3); shapes[p + ".fc1.bias"] = (cb,)
         shapes[p + ".fc2.weight"] = (cb, cb); shapes[p + ".fc2.bias"] = (cb,)
     return shapes
 

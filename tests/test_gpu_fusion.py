@@ -1,0 +1,149 @@
+"""GPU parity of the continuous-fusion path (image stream + KNN + gather + MLP), which the reference
+leaves as a TODO (model.py:199-203): checked against this repo's literal CPU statement of SURVEY.md
+App. D (oracle/model_ref.py) -- "parity unpinned" by the reference, pinned by the oracle."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from _util import golden_cfg, load_golden, pkg
+from oracle import geometry_ref, model_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def small_crt():
+    K = np.array([[60.0, 0.0, 64.0], [0.0, 60.0, 48.0], [0.0, 0.0, 1.0]])
+    return pkg("calib").crt_from(K, pkg("calib").R_LIDAR_TO_CAM)
+
+
+def setup(dtype="f32", K=3, zero_last=False):
+    cfg = golden_cfg(load_golden("model_tiny.npz"))
+    cfg.update(dict(image_height=96, image_width=128, max_num_pc=2048, projection_mode="correct", dtype=dtype))
+    cfg["fusion"] = dict(enabled=True, K=K, r_max=None, image_channels=64, zero_init_last=zero_last)
+    det = pkg("detfill")
+    lim6 = (cfg["lidar_x_min"], cfg["lidar_x_max"], cfg["lidar_y_min"], cfg["lidar_y_max"], cfg["lidar_z_min"], cfg["lidar_z_max"])
+    B = 2
+    pts = [det.synthetic_points(1500, lim6, 50 + b) for b in range(B)]
+    pts[1][:, 0] = pts[1][:, 0] * 0.5 + 1.0          # a different density for the second frame
+    img = torch.stack([torch.from_numpy(det.synthetic_image(96, 128, 9 + b)) for b in range(B)], 0)
+    return cfg, pts, img, small_crt()
+
+
+def oracle_inputs(cfg, pts, crt):
+    grids, pcs, uvs, ns = [], [], [], []
+    for p in pts:
+        g, pc, uv, n, _ = geometry_ref.voxelization_projection(p, cfg, crt, proj_mode="correct")
+        grids.append(g); pcs.append(pc); uvs.append(uv); ns.append(n)
+    return (torch.from_numpy(np.stack(grids)), torch.from_numpy(np.stack(pcs)), torch.from_numpy(np.stack(uvs)), ns)
+
+
+def full_shapes(cfg):
+    s = {}
+    s.update(model_ref.lidar_state_shapes(cfg))
+    s.update(model_ref.image_state_shapes(64))
+    s.update(model_ref.fusion_state_shapes(cfg, 64))
+    return s
+
+
+def test_image_stream_feature_map():
+    """ResNet-18 trunk + FPN (stem7x7, max-pool, BasicBlocks, resize-add, smooth) against the CPU statement."""
+    cfg, pts, img, crt = setup("f32")
+    net = pkg("model").ObjectDetection_DCF(cfg)
+    pkg("detfill").fill_state_dict(net)
+    net = net.cuda()
+    K = net._ensure_backend(torch.device("cuda", 0))
+    K.prepare()
+    fmap = net._plan._image_forward(K, img.cuda(), False).float().cpu().permute(0, 3, 1, 2)
+    sd = model_ref.make_state_dict(full_shapes(cfg))
+    ref = model_ref.image_stream(sd, img, "eval")
+    assert fmap.shape == ref.shape
+    err = float((fmap - ref).abs().max() / ref.abs().max())
+    assert err < 1e-3, err
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 6e-2)])
+def test_fused_forward(dtype, tol):
+    cfg, pts, img, crt = setup(dtype)
+    net = pkg("model").ObjectDetection_DCF(cfg)
+    pkg("detfill").fill_state_dict(net)
+    net = net.cuda().eval()
+    geo = pkg("data_import_carla").FrameGeometry(cfg, crt)
+    vox, pcs, uvs, cnts = [], [], [], []
+    for p in pts:
+        v, pc, uv, cnt, _ = geo(torch.from_numpy(p))
+        vox.append(v); pcs.append(pc); uvs.append(uv); cnts.append(cnt)
+    with torch.no_grad():
+        pred = net(torch.stack(vox), img.cuda(), points=torch.stack(pcs), uv=torch.stack(uvs), n_valid=torch.cat(cnts)).cpu()
+    x, pc, uv, ns = oracle_inputs(cfg, pts, crt)
+    assert [int(c.item()) for c in cnts] == ns and min(ns) > 50
+    assert torch.equal(torch.stack(vox).cpu(), x)
+    sd = model_ref.make_state_dict(full_shapes(cfg))
+    g = geometry_ref.grid_constants(cfg)
+    with torch.no_grad():
+        ref = model_ref.forward(sd, cfg, x, img, pc, uv, ns, "eval", fusion={"K": cfg["fusion"]["K"], "aff": g["aff"], "rmax": None})
+        nofuse = model_ref.forward(sd, cfg, x, bn_mode="eval")
+    assert float((ref - nofuse).abs().max()) > 1e-2          # the fusion branch really contributes
+    for name, sl in (("cls", slice(0, 4)), ("reg", slice(4, 18)), ("bbox", slice(18, 32))):
+        err = float((pred[:, sl] - ref[:, sl]).abs().max() / ref[:, sl].abs().max())
+        assert err < tol, "%s %s rel err %g" % (dtype, name, err)
+
+
+def test_zero_init_last_reproduces_lidar_only_reference():
+    """SURVEY.md App. D bridge: with fc2 = 0 the fused model equals the reference's LiDAR-only forward (golden)."""
+    z = load_golden("model_tiny.npz")
+    cfg, pts, img, crt = setup("f32")
+    net = pkg("model").ObjectDetection_DCF(cfg)
+    pkg("detfill").fill_state_dict(net)
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "fusion" in k and ".fc2." in k:
+                p.zero_()
+    net = net.cuda().eval()
+    det = pkg("detfill")
+    u = det.uniform((2, 32, 64, 32), 4242, 0.0, 1.0)
+    m = det.uniform((2, 32, 64, 32), 4242 + 17, 0.0, 1.0) < 0.12
+    x = torch.from_numpy((u * m).astype(np.float32)).cuda()
+    geo = pkg("data_import_carla").FrameGeometry(cfg, crt)
+    pcs, uvs, cnts = [], [], []
+    for p in pts:
+        _, pc, uv, cnt, _ = geo(torch.from_numpy(p))
+        pcs.append(pc); uvs.append(uv); cnts.append(cnt)
+    with torch.no_grad():
+        pred = net(x, img.cuda(), points=torch.stack(pcs), uv=torch.stack(uvs), n_valid=torch.cat(cnts)).cpu().numpy()
+    ref = z["pred_eval"]
+    assert np.abs(pred - ref).max() / np.abs(ref).max() < 1e-3
+
+
+def test_fused_backward_all_parameters():
+    """d<pred,R>/d(every parameter) of the fused model (fp32 path) against autograd through the CPU statement."""
+    cfg, pts, img, crt = setup("f32")
+    net = pkg("model").ObjectDetection_DCF(cfg)
+    det = pkg("detfill")
+    det.fill_state_dict(net)
+    net = net.cuda()
+    geo = pkg("data_import_carla").FrameGeometry(cfg, crt)
+    vox, pcs, uvs, cnts = [], [], [], []
+    for p in pts:
+        v, pc, uv, cnt, _ = geo(torch.from_numpy(p))
+        vox.append(v); pcs.append(pc); uvs.append(uv); cnts.append(cnt)
+    R = torch.from_numpy(det.uniform((2, 32, 16, 8), 778, -1.0, 1.0))
+    pred = net(torch.stack(vox), img.cuda(), points=torch.stack(pcs), uv=torch.stack(uvs), n_valid=torch.cat(cnts))
+    (pred * R.cuda()).sum().backward()
+    x, pc, uv, ns = oracle_inputs(cfg, pts, crt)
+    sd = model_ref.make_state_dict(full_shapes(cfg))
+    params = {k: (v.clone().requires_grad_(True) if (v.dtype.is_floating_point and "running" not in k) else v) for k, v in sd.items()}
+    g = geometry_ref.grid_constants(cfg)
+    out = model_ref.forward(params, cfg, x, img, pc, uv, ns, "eval", fusion={"K": 3, "aff": g["aff"], "rmax": None})
+    (out * R).sum().backward()
+    named = dict(net.named_parameters())
+    bad = []
+    for k, p in named.items():
+        ref = params[k].grad
+        got = p.grad.detach().cpu()
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max()) / (scale + 1e-9)
+        if err > 5e-3 and float((got - ref).abs().max()) > 1e-5:
+            bad.append((k, err, scale))
+    assert not bad, "%d parameters off, worst %s" % (len(bad), sorted(bad, key=lambda t: -t[1])[:5])

@@ -1,0 +1,133 @@
+"""GPU parity of the whole LiDAR stream (model surface -> engine -> HIP kernels) against the
+golden vectors generated from the imported reference, forward and backward, plus the
+train step (loss + Adam) trajectory.  Tolerance from BASELINE.json north_star: 1e-3 relative
+(fp32 path); the bf16 path is checked against the same vectors at bf16 precision."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from _util import golden_cfg, load_golden, pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def tiny_input():
+    det = pkg("detfill")
+    u = det.uniform((2, 32, 64, 32), 4242, 0.0, 1.0)
+    m = det.uniform((2, 32, 64, 32), 4242 + 17, 0.0, 1.0) < 0.12
+    return torch.from_numpy((u * m).astype(np.float32))
+
+
+def build(cfg, dtype="f32", **over):
+    cfg = copy.deepcopy(cfg)
+    cfg["dtype"] = dtype
+    cfg.update(over)
+    net = pkg("model").ObjectDetection_DCF(cfg)
+    pkg("detfill").fill_state_dict(net)
+    return net.cuda(), cfg
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 6e-2)])
+def test_tiny_forward_matches_reference(dtype, tol):
+    z = load_golden("model_tiny.npz")
+    net, cfg = build(golden_cfg(z), dtype)
+    net.eval()
+    with torch.no_grad():
+        pred = net(tiny_input().cuda(), torch.zeros(2, 3, 8, 8, dtype=torch.uint8, device="cuda")).cpu().numpy()
+    ref = z["pred_eval"]
+    assert pred.shape == ref.shape == (2, 32, 16, 8)
+    for name, sl in (("cls", slice(0, 4)), ("reg", slice(4, 18)), ("bbox", slice(18, 32))):
+        err = np.abs(pred[:, sl] - ref[:, sl]).max() / np.abs(ref[:, sl]).max()
+        assert err < tol, "%s %s: rel err %g" % (dtype, name, err)
+
+
+def test_state_dict_surface_matches_reference():
+    from oracle import model_ref
+    z = load_golden("model_tiny.npz")
+    cfg = golden_cfg(z)
+    net = pkg("model").ObjectDetection_DCF(cfg)
+    want = model_ref.lidar_state_shapes(cfg)
+    got = net.state_dict()
+    assert list(got.keys()) == list(want.keys())
+    assert all(tuple(got[k].shape) == tuple(want[k]) for k in want)
+    # 'module.'-prefixed (DDP) checkpoints load too (train.py:79)
+    net.load_state_dict({"module." + k: v.clone() for k, v in got.items()})
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-3), ("bf16", 2.5e-1)])
+def test_tiny_backward_matches_reference(dtype, tol):
+    z = load_golden("model_tiny.npz")
+    net, cfg = build(golden_cfg(z), dtype)
+    det = pkg("detfill")
+    R = torch.from_numpy(det.uniform((1, 32, 16, 8), 777, -1.0, 1.0)).cuda()
+    pred = net(tiny_input()[:1].cuda(), torch.zeros(1, 3, 8, 8, dtype=torch.uint8, device="cuda"))
+    (pred * R).sum().backward()
+    named = dict(net.named_parameters())
+    worst = 0.0
+    for k in [str(s) for s in z["grad_keys"]]:
+        ref = z["g_eval_" + k]
+        got = named[k].grad.detach().cpu().numpy()
+        err = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12)
+        worst = max(worst, err)
+        assert err < tol, "%s grad of %s: rel err %g" % (dtype, k, err)
+    # every parameter: sum |g| checksum in the reference's named_parameters order
+    gabs = np.array([named[k].grad.abs().sum().item() for k in named])
+    ref_abs = z["gabs_eval"]
+    assert gabs.shape == ref_abs.shape
+    rel = np.abs(gabs - ref_abs) / (ref_abs + 1e-6)
+    assert rel.max() < (5e-3 if dtype == "f32" else 2e-1), "checksum rel err %g at %d" % (rel.max(), int(rel.argmax()))
+
+
+def test_full_carla_frame_cfg1():
+    """BASELINE configs[0]: synthetic CARLA frame (10k pts) -> HIP voxeliser -> HIP model, B=1, fp32,
+    against 64 output pixels and channel sums of the reference's CPU forward."""
+    g = load_golden("geometry_carla.npz")
+    z = load_golden("model_carla_full.npz")
+    cfg = golden_cfg(g)
+    net, cfg = build(cfg, "f32")
+    geo = pkg("data_import_carla").FrameGeometry(cfg, g["crt"])
+    voxel, pc, uv, cnt, _ = geo(torch.from_numpy(g["n10k_pts"]))
+    with torch.no_grad():
+        pred = net(voxel.unsqueeze(0), torch.zeros(1, 3, 240, 320, dtype=torch.uint8, device="cuda")).cpu().numpy()[0]
+    got = pred[:, z["sample_h"], z["sample_w"]]
+    err = np.abs(got - z["sample_pred"]).max() / np.abs(z["sample_pred"]).max()
+    assert err < 1e-3, err
+    assert np.allclose(pred.astype(np.float64).sum((1, 2)), z["chan_sum"], rtol=2e-3, atol=0.5)
+
+
+def test_train_step_trajectory_matches_reference():
+    """3 steps of Train.one_step semantics (eval-BN, Adam lr 1e-4, np.random.seed(100+step)), B=1, fp32."""
+    z = load_golden("model_tiny.npz")
+    traj = load_golden("adam_traj.npz")
+    lz = load_golden("loss.npz")
+    net, cfg = build(golden_cfg(z), "f32")
+    train = pkg("train")
+    L = pkg("loss").LossTotal(cfg)
+    opt = train.FlatAdam(net, cfg["learning_rate"], (cfg["beta1"], 0.999))
+    x = tiny_input()[:1].cuda()
+    img = torch.zeros(1, 3, 8, 8, dtype=torch.uint8, device="cuda")
+    boxes, nb = torch.from_numpy(lz["bboxes"])[:1].cuda(), torch.from_numpy(lz["nbox"])[:1]
+    losses = []
+    for step in range(3):
+        pred = net(x, img)
+        cls, reg, _ = torch.split(pred, [4, 14, 14], dim=1)
+        np.random.seed(100 + step)
+        val = L(boxes, nb, cls, reg)
+        val.backward()
+        opt.step()
+        losses.append(val.item())
+    ref = traj["losses"]
+    assert np.abs(np.array(losses) - ref).max() < 2e-3 * abs(ref[0]), (losses, ref.tolist())
+    w = dict(net.named_parameters())["lidar_backbone.conv3.weight"].detach().cpu().numpy()[:4, :4]
+    assert np.abs(w - traj["conv3_after"]).max() < 2e-5
+
+
+def test_cpu_tensors_fail_loudly():
+    z = load_golden("model_tiny.npz")
+    cfg = golden_cfg(z)
+    net = pkg("model").ObjectDetection_DCF(cfg)
+    with pytest.raises(Exception) as e:
+        net(tiny_input(), torch.zeros(2, 3, 8, 8, dtype=torch.uint8))
+    assert "no CPU fallback" in str(e.value) or "HIP" in str(e.value)
