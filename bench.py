@@ -165,7 +165,7 @@ def cpu_baseline(cfg, pool_seed):
     from oracle import geometry_ref, model_ref
     det = pkg("detfill")
     c = copy.deepcopy(cfg)
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, 32)        # more threads than this oversubscribes oneDNN on these shapes
     torch.set_num_threads(threads)
     lim6 = (c["lidar_x_min"], c["lidar_x_max"], c["lidar_y_min"], c["lidar_y_max"], c["lidar_z_min"], c["lidar_z_max"])
     pts = det.synthetic_points(c["max_num_pc"], lim6, pool_seed)
@@ -192,18 +192,22 @@ def cpu_baseline(cfg, pool_seed):
     x = torch.from_numpy(grid).unsqueeze(0)
     # reuse GPU-independent KNN: the model step below recomputes it with the brute-force oracle on a coarse
     # row subsample would change the maths, so the model step is timed WITHOUT fusion gathers' KNN (timed above).
-    t0 = time.time()
-    pred = model_ref.forward(sd, c, x, None, bn_mode="eval")
-    loss = (pred[:, :18] ** 2).mean()
-    opt.zero_grad()
-    loss.backward()
-    opt.step()
-    t_lidar = time.time() - t0
-    t0 = time.time()
-    with torch.enable_grad():
-        fmap = model_ref.image_stream(sd, img, "eval")
-        fmap.square().mean().backward()
-    t_img = time.time() - t0
+    t_lidar = t_img = 1e30
+    for rep in range(2):                           # second repetition excludes oneDNN primitive creation
+        t0 = time.time()
+        pred = model_ref.forward(sd, c, x, None, bn_mode="eval")
+        loss = (pred[:, :18] ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        t_lidar = min(t_lidar, time.time() - t0)
+        t0 = time.time()
+        with torch.enable_grad():
+            fmap = model_ref.image_stream(sd, img, "eval")
+            fmap.square().mean().backward()
+        t_img = min(t_img, time.time() - t0)
+        if t_lidar + t_img > 20.0:
+            break
     total = t_geo + t_knn + t_lidar + t_img
     return {"value": round(1.0 / total, 4), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": "1 frame: C geometry %.2fs + brute-force KNN on 1/8 of BEV rows x8 = %.2fs + torch-CPU fp32 LiDAR-stream "
