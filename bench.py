@@ -80,7 +80,7 @@ def train_step(trainer, pool, ids):
     x_lidar = torch.stack(vox, 0)
     x_image = torch.stack([pool.img[i] for i in ids], 0)
     points, uv, n_valid = torch.stack(pcs, 0), torch.stack(uvs, 0), torch.cat(cnts, 0)
-    boxes = torch.stack([pool.boxes_dev[i] for i in ids], 0)
+    boxes = torch.stack([pool.boxes[i] for i in ids], 0)          # CPU, as a DataLoader would hand them over
     nb = torch.tensor([pool.nb[i] for i in ids])
     trainer.one_step(x_lidar, x_image, boxes, nb, points=points, uv=uv, n_valid=n_valid)
 

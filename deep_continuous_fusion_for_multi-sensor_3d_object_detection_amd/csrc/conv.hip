@@ -240,10 +240,15 @@ int launch_igemm(const ConvArgs &a, hipStream_t s, const char *name)
         DCF_LAUNCH(name, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR>), grid, dim3(256), 0, s, a)); \
         return DCF_OK;                                                                                              \
     } while (0)
-    if (a.Cn % 128 == 0) {
+    // tile choice: the biggest tile that still gives the chip >= ~2 workgroups per CU
+    const int64_t want_blocks = 256;
+    auto blocks = [&](int bn, int bm) { return (int64_t)cdiv(a.M, bm) * (a.Cn / bn); };
+    if (a.Cn % 128 == 0 && blocks(128, 128) >= want_blocks) {
         if (kb128) DCF_IGEMM(128, 2, 2, 2, 2); else DCF_IGEMM(64, 2, 2, 2, 2);
-    } else if (a.Cn % 64 == 0) {
+    } else if (a.Cn % 64 == 0 && blocks(64, 128) >= want_blocks) {
         if (kb128) DCF_IGEMM(128, 2, 1, 1, 4); else DCF_IGEMM(64, 2, 1, 1, 4);
+    } else if (a.Cn % 64 == 0) {          // small M: 64x64 tiles give the most workgroups
+        if (kb128) DCF_IGEMM(128, 1, 1, 2, 2); else DCF_IGEMM(64, 1, 1, 2, 2);
     } else {
         if (kb128) DCF_IGEMM(128, 1, 1, 1, 4); else DCF_IGEMM(64, 1, 1, 1, 4);
     }
@@ -470,9 +475,13 @@ extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout,
     wgrad_tiles(Cin, Cout, TM, TN);
     const int tiles = cdiv(Cout, TM * 32) * cdiv(Cin, TN * 32) * kh * kw;
     const int64_t M = (int64_t)B * Ho * Wo;
-    int64_t want = cdiv(3072, tiles);                 // ~12 waves per CU in total
-    int64_t maxs = (M + 127) / 128;                   // at least 4 stages of 32 pixels per split
+    int64_t want = cdiv(2048, tiles);                 // ~8 waves per CU in total
+    int64_t maxs = (M + 255) / 256;                   // at least 8 stages of 32 pixels per split
     if (want > maxs) want = maxs;
+    // keep each layer's slab arena small: it is written once and re-read by dcf_wgrad_finalize
+    const int64_t slab_bytes = (int64_t)cdiv(Cout, 32) * 32 * kh * kw * Cin * 4;
+    const int64_t cap = (16ll << 20) / slab_bytes;
+    if (want > cap) want = cap;
     if (want < 1) want = 1;
     return (int)((want + 3) / 4 * 4);
 }

@@ -334,95 +334,100 @@ struct TopK {
     }
 };
 
+// One wave per 8x8 tile of BEV pixels (= one coarse block of the cell grid): all 64 lanes walk the
+// SAME cells / coarse rings, so control flow is wave-uniform and every candidate point is one scalar
+// (broadcast) load; only the K-best insertion is per lane.
+//   phase A: the 12x12 cell window around the tile (every lane's fine rings 0..2 are inside it)
+//   phase B: coarse block rings around the tile for lanes whose neighbourhood is sparse
+// A lane stops as soon as every unvisited point is provably farther than its K-th candidate.
 template <int K>
 __global__ void __launch_bounds__(256) k_knn_search(const int *count, int n_max, KnnGrid g, const int *cellstart,
                                                     const float4 *sorted, float rmax2, int *out)
 {
-    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= g.h * g.w) return;
-    const int i = pix / g.w, j = pix % g.w;
+    const int lane = threadIdx.x & 63;
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (tile >= g.h8 * g.w8) return;
+    const int TI = tile / g.w8, TJ = tile - TI * g.w8;
+    const int i = TI * 8 + (lane >> 3), j = TJ * 8 + (lane & 7);
+    const bool inside = (i < g.h) && (j < g.w);
     const float s = (float)g.stride;
     const float X = __fdiv_rn(__fsub_rn(__fmul_rn((float)i + 0.5f, s), g.xo), g.xs);
     const float Y = __fdiv_rn(__fsub_rn(__fmul_rn((float)j + 0.5f, s), g.yo), g.ys);
-    const float cwx = s / g.xs, cwy = s / g.ys;       // metric size of one cell
+    const float cwx = s / g.xs, cwy = s / g.ys;
     const float cwmin = fminf(cwx, cwy);
     const int n = min(*count, n_max);
 
     TopK<K> top;
     top.clear();
-    bool done = (n == 0);
+    bool done = !inside;
 
-    auto scan_range = [&](int b, int e) {
+    auto scan_range = [&](int b, int e, bool take) {
         for (int p = b; p < e; ++p) {
-            const float4 q = sorted[p];
+            const float4 q = sorted[p];                       // wave-uniform address
             const float dx = __fsub_rn(q.x, X), dy = __fsub_rn(q.y, Y);
             const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
-            if (rmax2 >= 0.0f && d2 > rmax2) continue;
-            top.insert(d2, __float_as_int(q.z));
+            if (take && !(rmax2 >= 0.0f && d2 > rmax2)) top.insert(d2, __float_as_int(q.z));
         }
     };
 
-    // ---- phase A: fine rings 0..2 around the pixel's own cell
-    constexpr int RA = 2;
-    if (!done) {
-        for (int r = 0; r <= RA && !done; ++r) {
-            for (int a = -r; a <= r; ++a) {
-                const int ci = i + a;
-                if (ci < 0 || ci >= g.h) continue;
-                const bool edge = (a == -r || a == r);
-                for (int b = -r; b <= r; b += (edge ? 1 : 2 * r)) {
-                    const int cj = j + b;
-                    if (cj >= 0 && cj < g.w) {
-                        const int key = cell_key(ci, cj, g);
-                        scan_range(cellstart[key], cellstart[key + 1]);
-                    }
-                    if (r == 0) break;
-                }
+    if (n > 0) {
+        // ---- phase A: rows 8TI-2 .. 8TI+9, three column segments (one per coarse block column)
+        const int H8 = g.h8 * 8, W8 = g.w8 * 8;
+        for (int ci = max(TI * 8 - 2, 0); ci <= min(TI * 8 + 9, H8 - 1); ++ci) {
+            for (int seg = 0; seg < 3; ++seg) {
+                int c0 = TJ * 8 + (seg == 0 ? -2 : (seg == 1 ? 0 : 8));
+                int c1 = TJ * 8 + (seg == 0 ? -1 : (seg == 1 ? 7 : 9));
+                c0 = max(c0, 0); c1 = min(c1, W8 - 1);
+                if (c0 > c1) continue;
+                scan_range(cellstart[cell_key(ci, c0, g)], cellstart[cell_key(ci, c1, g) + 1], !done);
             }
-            // every unvisited point is farther than (r+0.5) cells (1 mm safety margin)
-            const float bound = ((float)r + 0.5f) * cwmin - 1e-3f;
-            if (top.full() && top.kth() < bound * bound) done = true;
+        }
+        {
+            const float bound = 2.5f * cwmin - 1e-3f;         // every unvisited point is >= 2.5 cells away
+            if (!done && top.full() && top.kth() < bound * bound) done = true;
             if (rmax2 >= 0.0f && bound > 0.f && bound * bound > rmax2) done = true;
         }
-    }
-    // ---- phase B: coarse 8x8-block rings (restart: visiting order does not matter)
-    if (!done) {
-        top.clear();
-        const int I = i >> 3, J = j >> 3;
-        const int Rmax = max(g.h8, g.w8);
-        for (int R = 0; R <= Rmax && !done; ++R) {
-            for (int a = -R; a <= R; ++a) {
-                const int bi = I + a;
-                if (bi < 0 || bi >= g.h8) continue;
-                const bool edge = (a == -R || a == R);
-                for (int b = -R; b <= R; b += (edge ? 1 : 2 * R)) {
-                    const int bj = J + b;
-                    if (bj >= 0 && bj < g.w8) {
-                        const int k0 = (bi * g.w8 + bj) << 6;
-                        const int ps = cellstart[k0], pe = cellstart[k0 + 64];
-                        if (pe > ps) {
-                            bool visit = true;
-                            if (top.full()) {  // prune by the block's metric bounding box
-                                const float lox = ((float)(bi * 8) * s - g.xo) / g.xs, hix = ((float)(bi * 8 + 8) * s - g.xo) / g.xs;
-                                const float loy = ((float)(bj * 8) * s - g.yo) / g.ys, hiy = ((float)(bj * 8 + 8) * s - g.yo) / g.ys;
-                                const float ddx = fmaxf(0.f, fmaxf(lox - X, X - hix) - 1e-3f);
-                                const float ddy = fmaxf(0.f, fmaxf(loy - Y, Y - hiy) - 1e-3f);
-                                visit = (ddx * ddx + ddy * ddy) <= top.kth();
+        // ---- phase B: coarse rings (lanes still searching restart; order of visits does not matter)
+        if (!__all(done)) {
+            if (!done) top.clear();
+            const int Rmax = max(g.h8, g.w8);
+            for (int R = 0; R <= Rmax; ++R) {
+                for (int a = -R; a <= R; ++a) {
+                    const int bi = TI + a;
+                    if (bi < 0 || bi >= g.h8) continue;
+                    const bool edge = (a == -R || a == R);
+                    for (int b = -R; b <= R; b += (edge ? 1 : 2 * R)) {
+                        const int bj = TJ + b;
+                        if (bj >= 0 && bj < g.w8) {
+                            const int k0 = (bi * g.w8 + bj) << 6;
+                            const int ps = cellstart[k0], pe = cellstart[k0 + 64];
+                            if (pe > ps) {
+                                bool visit = !done;
+                                if (visit && top.full()) {  // prune by the block's metric bounding box
+                                    const float lox = ((float)(bi * 8) * s - g.xo) / g.xs, hix = ((float)(bi * 8 + 8) * s - g.xo) / g.xs;
+                                    const float loy = ((float)(bj * 8) * s - g.yo) / g.ys, hiy = ((float)(bj * 8 + 8) * s - g.yo) / g.ys;
+                                    const float ddx = fmaxf(0.f, fmaxf(lox - X, X - hix) - 1e-3f);
+                                    const float ddy = fmaxf(0.f, fmaxf(loy - Y, Y - hiy) - 1e-3f);
+                                    visit = (ddx * ddx + ddy * ddy) <= top.kth();
+                                }
+                                if (__any(visit)) scan_range(ps, pe, visit);
                             }
-                            if (visit) scan_range(ps, pe);
                         }
+                        if (R == 0) break;
                     }
-                    if (R == 0) break;
                 }
+                const float bound = (8.0f * (float)R + 0.5f) * cwmin - 1e-3f;
+                if (!done && top.full() && top.kth() < bound * bound) done = true;
+                if (rmax2 >= 0.0f && bound > 0.f && bound * bound > rmax2) done = true;
+                if (__all(done)) break;
             }
-            const float bound = (8.0f * (float)R + 0.5f) * cwmin - 1e-3f;
-            if (top.full() && top.kth() < bound * bound) done = true;
-            if (rmax2 >= 0.0f && bound * bound > rmax2) done = true;
         }
     }
-    const int hw = g.h * g.w;
+    if (inside) {
+        const int hw = g.h * g.w, pix = i * g.w + j;
 #pragma unroll
-    for (int q = 0; q < K; ++q) out[q * hw + pix] = (q < top.cnt) ? top.id[q] : -1;
+        for (int q = 0; q < K; ++q) out[q * hw + pix] = (q < top.cnt) ? top.id[q] : -1;
+    }
 }
 
 }  // namespace
@@ -543,8 +548,7 @@ extern "C" int dcf_knn_bev(const float *xyz, const int32_t *count_dev, int n_max
         const int nb = cdiv(n_max, 256);
         DCF_LAUNCH("knn_fill", s, hipLaunchKernelGGL(k_knn_fill, dim3(nb), dim3(256), 0, s, xyz, count_dev, n_max, pkey, cursor, sorted));
     }
-    const int npix = h * w;
-    const int nbp = cdiv(npix, 256);
+    const int nbp = cdiv(g.h8 * g.w8, 4);   // one wave per 8x8 pixel tile
 #define KNN_CASE(KK)                                                                                                     \
     case KK:                                                                                                             \
         DCF_LAUNCH("knn_search", s, hipLaunchKernelGGL(k_knn_search<KK>, dim3(nbp), dim3(256), 0, s, count_dev, n_max, g, \

@@ -66,49 +66,81 @@ class LossTotal(nn.Module):
         return positives, negatives, regress, owner
 
     # ------------------------------------------------------------------ device-side terms
-    @staticmethod
-    def _ce(score2, pos, neg, dev):
-        n = torch.tensor(neg, dtype=torch.long, device=dev)
-        out = F.cross_entropy(score2[:, n[:, 0], n[:, 1]].t(), torch.zeros(len(neg), dtype=torch.long, device=dev))
-        if len(pos) > 0:
-            p = torch.tensor(pos, dtype=torch.long, device=dev)
-            out = F.cross_entropy(score2[:, p[:, 0], p[:, 1]].t(), torch.ones(len(pos), dtype=torch.long, device=dev)) + out
-        return out
-
-    @staticmethod
-    def _smooth_l1(box, pred, anc):
-        """loss.py:144-165: encode the box against every anchor of the window, mean Smooth-L1."""
-        N = anc.shape[0]
-        ref = box[:7].view(1, 1, 7)
-        diag = torch.sqrt(anc[:, :, 3:4] ** 2 + anc[:, :, 4:5] ** 2)
-        d = ref[:, :, 6] - anc[:, :, 6]
-        target = torch.cat(((ref[:, :, 0:2] - anc[:, :, 0:2]) / diag, (ref[:, :, 2:3] - anc[:, :, 2:3]) / anc[:, :, 5:6],
-                            torch.log(ref[:, :, 3:6] / anc[:, :, 3:6]), torch.atan2(torch.sin(d), torch.cos(d)).unsqueeze(-1)), -1)
-        return F.smooth_l1_loss(pred.reshape(N, 2, 7), target, reduction="none").sum() * (1.0 / (N * 14))
+    def _stage(self, ints, floats, dev):
+        """One pinned staging buffer per kind: all index lists / boxes of the step go up in two async copies,
+        so the host never waits for the device while it builds the loss."""
+        if dev.type != "cuda":
+            return torch.tensor(ints, dtype=torch.long), torch.tensor(floats, dtype=torch.float32)
+        ni, nf = max(len(ints), 1), max(len(floats), 1)
+        st = getattr(self, "_stage_buf", None)
+        if st is None or st[0].numel() < ni or st[1].numel() < nf:
+            st = [torch.empty(max(ni, 1 << 16), dtype=torch.long).pin_memory(), torch.empty(max(nf, 1 << 12), dtype=torch.float32).pin_memory(), None]
+            self._stage_buf = st
+        if st[2] is not None:
+            st[2].synchronize()          # the previous step's copies have long completed
+        st[0][:len(ints)] = torch.tensor(ints, dtype=torch.long)
+        st[1][:len(floats)] = torch.tensor(floats, dtype=torch.float32)
+        di = st[0][:ni].to(dev, non_blocking=True)
+        df = st[1][:nf].to(dev, non_blocking=True)
+        st[2] = torch.cuda.Event()
+        st[2].record()
+        return di, df
 
     def forward(self, reference_bboxes_batch, num_ref_bbox_batch, predicted_class_feature_batch, predicted_regress_feature_batch):
         cls, reg = predicted_class_feature_batch, predicted_regress_feature_batch
         dev = cls.device
         B = reference_bboxes_batch.shape[0]
         H, W = cls.shape[-2:]
-        anc = self.anchor_set.to(dev)
-        boxes_host = reference_bboxes_batch.detach().cpu()
-        total = torch.zeros(1, device=dev)
-        acc = torch.zeros(1, device=dev)
+        if getattr(self, "_anc_dev", None) is None or self._anc_dev.device != dev:
+            self._anc_dev = self.anchor_set.to(dev).reshape(2, 7, H * W)
+        anc = self._anc_dev
+        # pass CPU boxes (what a DataLoader yields) to avoid a device round trip
+        boxes_host = reference_bboxes_batch.detach().cpu() if reference_bboxes_batch.is_cuda else reference_bboxes_batch.detach()
+        # ---- host: target assignment for every sample, packed into flat lists
+        ints, floats, plan = [], [], []
         for b in range(B):
             nb = int(num_ref_bbox_batch[b])
             pos, neg, regress, owner = self.assign(boxes_host[b, :nb], H, W)
-            lc = self._ce(cls[b, 0:2], pos, neg, dev) + self._ce(cls[b, 2:4], pos, neg, dev)
+            rows, row_box, row_w = [], [], []
+            for k in range(nb):
+                for m in owner[k]:
+                    rows.append(regress[m][0] * W + regress[m][1])
+                    row_box.append(k)
+                    row_w.append(1.0 / (len(owner[k]) * 14))
+            o = len(ints)
+            ints += [p[0] * W + p[1] for p in pos] + [q[0] * W + q[1] for q in neg] + rows + row_box
+            of = len(floats)
+            floats += row_w + boxes_host[b, :nb, :7].reshape(-1).tolist()
+            plan.append((o, len(pos), len(neg), len(rows), of, nb))
+        di, df = self._stage(ints, floats, dev)
+        # ---- device: gathers + CE + Smooth-L1, vectorised per sample
+        total = torch.zeros(1, device=dev)
+        acc = torch.zeros(1, device=dev)
+        for b in range(B):
+            o, npos, nneg, nrow, of, nb = plan[b]
+            pos_i, neg_i = di[o:o + npos], di[o + npos:o + npos + nneg]
+            lc = torch.zeros(1, device=dev)
+            for a in range(2):                                   # per anchor: loss.py:64-65
+                sc = cls[b, 2 * a:2 * a + 2].reshape(2, H * W)
+                term = F.cross_entropy(sc[:, neg_i].t(), torch.zeros(nneg, dtype=torch.long, device=dev))
+                if npos > 0:
+                    term = F.cross_entropy(sc[:, pos_i].t(), torch.ones(npos, dtype=torch.long, device=dev)) + term
+                lc = lc + term
             lr = torch.zeros(1, device=dev)
-            if len(regress) > 0:
-                rp = torch.tensor(regress, dtype=torch.long, device=dev)
-                for k in range(nb):
-                    if len(owner[k]) == 0:
-                        continue
-                    sel = rp[owner[k]]
-                    pred = reg[b][:, sel[:, 0], sel[:, 1]].t()
-                    a = anc[:, :, sel[:, 0], sel[:, 1]].permute(2, 0, 1)
-                    lr = lr + self._smooth_l1(reference_bboxes_batch[b, k].to(dev), pred, a)
+            if nrow > 0:
+                rows = di[o + npos + nneg:o + npos + nneg + nrow]
+                rbox = di[o + npos + nneg + nrow:o + npos + nneg + 2 * nrow]
+                w_row = df[of:of + nrow]
+                boxes = df[of + nrow:of + nrow + nb * 7].reshape(nb, 7)
+                pred = reg[b].reshape(14, H * W)[:, rows].t().reshape(nrow, 2, 7)
+                an = anc[:, :, rows].permute(2, 0, 1)            # [nrow,2,7]
+                ref = boxes[rbox].unsqueeze(1)                   # [nrow,1,7]
+                diag = torch.sqrt(an[:, :, 3:4] ** 2 + an[:, :, 4:5] ** 2)
+                d = ref[:, :, 6] - an[:, :, 6]
+                target = torch.cat(((ref[:, :, 0:2] - an[:, :, 0:2]) / diag, (ref[:, :, 2:3] - an[:, :, 2:3]) / an[:, :, 5:6],
+                                    torch.log(ref[:, :, 3:6] / an[:, :, 3:6]), torch.atan2(torch.sin(d), torch.cos(d)).unsqueeze(-1)), -1)
+                per_row = F.smooth_l1_loss(pred, target, reduction="none").sum((1, 2))
+                lr = lr + (per_row * w_row).sum()                # = sum over boxes of the per-box mean (loss.py:163,186)
             total = lc + self.config["regress_loss_gain"] * lr
             acc = acc + total
         if self.reduction == "last":

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Per-shape micro-benchmark of the conv kernels (fwd / dgrad / wgrad) at the cfg2 shapes.
+Usage (GPU box): python tools/conv_bench.py [--dtype bf16] [--batch 2]"""
+import argparse, importlib, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "deep_continuous_fusion_for_multi-sensor_3d_object_detection_amd"
+ops = importlib.import_module(PKG + ".ops")
+
+# (name, H, W, Cin, Cout, k, stride, count)
+LIDAR = [("l1", 704, 800, 32, 32, 3, 1, 2), ("l2s", 704, 800, 32, 64, 3, 2, 1), ("l2d", 704, 800, 32, 64, 1, 2, 1),
+         ("l2", 352, 400, 64, 64, 3, 1, 3), ("l3s", 352, 400, 64, 128, 3, 2, 1), ("l3", 176, 200, 128, 128, 3, 1, 7),
+         ("l4s", 176, 200, 128, 192, 3, 2, 1), ("l4", 88, 100, 192, 192, 3, 1, 11), ("l5s", 88, 100, 192, 256, 3, 2, 1),
+         ("l5", 44, 50, 256, 256, 3, 1, 11), ("conv3", 176, 200, 192, 192, 3, 1, 1), ("lat2", 176, 200, 128, 192, 1, 1, 1),
+         ("heads", 176, 200, 192, 32, 1, 1, 1)]
+IMAGE = [("i1", 94, 311, 64, 64, 3, 1, 4), ("i2s", 94, 311, 64, 128, 3, 2, 1), ("i2", 47, 156, 128, 128, 3, 1, 3),
+         ("i3", 24, 78, 256, 256, 3, 1, 3), ("i4", 12, 39, 512, 512, 3, 1, 3)]
+
+
+def timeit(fn, iters=20):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--batch", type=int, default=2)
+    args = ap.parse_args()
+    dt = 1 if args.dtype == "bf16" else 0
+    td = torch.bfloat16 if dt == 1 else torch.float32
+    es = 2 if dt else 4
+    B = args.batch
+    tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+    print("%-6s %5s %5s %4s %4s k s |  fwd us  TF/s  GB/s | dgrad us  TF/s | wgrad us  TF/s  (x count)" % ("name", "H", "W", "Ci", "Co"))
+    for name, Hh, W, Ci, Co, k, s, cnt in LIDAR + IMAGE:
+        pad = k // 2
+        Ho, Wo = (Hh + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+        x = (torch.rand((B, Hh, W, Ci), device="cuda") - 0.5).to(td)
+        w = ((torch.rand((Co, k, k, Ci), device="cuda") - 0.5) * 0.1).to(td)
+        wt = w.permute(3, 1, 2, 0).contiguous()
+        gy = (torch.rand((B, Ho, Wo, Co), device="cuda") - 0.5).to(td)
+        ns = ops.conv2d_wgrad_splits(B, Ho, Wo, Ci, Co, k, k)
+        slabs = torch.empty((ns, Co, k, k, Ci), device="cuda")
+        fl = 2.0 * B * Ho * Wo * Co * Ci * k * k
+        byt = (x.numel() + gy.numel()) * es
+        tf = timeit(lambda: ops.conv2d_fwd(dt, x, w, None, None, k, k, s, pad, False, Co))
+        td_ = timeit(lambda: ops.conv2d_dgrad(dt, gy, wt, None, (B, Hh, W, Ci), k, k, s, pad))
+        tw = timeit(lambda: ops.conv2d_wgrad(dt, x, gy, slabs, ns, k, k, s, pad))
+        tot["fwd"] += tf * cnt; tot["dgrad"] += td_ * cnt; tot["wgrad"] += tw * cnt
+        print("%-6s %5d %5d %4d %4d %d %d | %7.1f %5.0f %5.0f | %7.1f %5.0f | %7.1f %5.0f  ns=%d (x%d)" % (
+            name, Hh, W, Ci, Co, k, s, tf * 1e6, fl / tf / 1e12, byt / tf / 1e9, td_ * 1e6, fl / td_ / 1e12, tw * 1e6, fl / tw / 1e12, ns, cnt))
+    print("weighted totals (ms):", {k: round(v * 1e3, 3) for k, v in tot.items()})
+
+
+if __name__ == "__main__":
+    main()
