@@ -41,6 +41,7 @@ struct ConvArgs {
     int kh, kw, stride, pad, relu;
     int M;
     int pixbytes;        // byte pitch between adjacent input pixels (= Ck*esize except for the stem)
+    unsigned xbytes, wbytes;  // sizes of the gathered tensor and of the weight image (buffer descriptors)
 };
 
 template <typename T> struct Mma;
@@ -89,8 +90,15 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
     const int rowbytes = a.Ck * ES;              // bytes of one pixel's channel vector
     const int cchunks = rowbytes / KB;
 
+    // Buffer descriptors: an offset past the end reads as zero, so padding / tile tails need no branches
+    // and all addressing is 32-bit (one VALU add per load in the K loop).
+    const __amdgpu_buffer_rsrc_t srcX = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srcW = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.wbytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFF00u;
+
     // per-thread gather bookkeeping for its X chunks (fixed over the K loop)
-    int xb[NLX], xh[NLX], xw[NLX], xoff[NLX];
+    int xb[NLX], xh[NLX], xw[NLX];
+    unsigned xoff[NLX], woff[NLW];
 #pragma unroll
     for (int i = 0; i < NLX; ++i) {
         const int c = tid + i * 256;
@@ -108,6 +116,11 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
             xb[i] = -1; xh[i] = 0; xw[i] = 0;
         }
     }
+#pragma unroll
+    for (int i = 0; i < NLW; ++i) {
+        const int c = tid + i * 256;
+        woff[i] = (NCW % 256 == 0 || c < NCW) ? (unsigned)(n0 + c / CPR) * (unsigned)(taps * rowbytes) + (c % CPR) * 16 : OOB;
+    }
 
     f32x16 acc[TN][TM];
 #pragma unroll
@@ -117,41 +130,33 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    uint4 rw[NLW], rx[NLX];
-    auto load_global = [&](int tap, int cc) {
-        const int ki = tap / a.kw, kj = tap - ki * a.kw;
-#pragma unroll
-        for (int i = 0; i < NLW; ++i) {
-            const int c = tid + i * 256;
-            if (NCW % 256 == 0 || c < NCW) {
-                const int row = c / CPR;
-                const char *p = a.w + ((size_t)(n0 + row) * taps + tap) * rowbytes + cc * KB + (c % CPR) * 16;
-                rw[i] = *reinterpret_cast<const uint4 *>(p);
-            }
-        }
+    unsigned pix[NLX];  // byte offset of this tap's source pixel (+ chunk), or OOB
+    auto set_tap = [&](int ki, int kj) {
 #pragma unroll
         for (int i = 0; i < NLX; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (xb[i] >= 0) {
-                int ih, iw;
-                bool ok;
-                if (TRANSPOSED) {
-                    const int th = xh[i] - ki, tw = xw[i] - kj;
-                    ok = (th >= 0) && (tw >= 0);
-                    if (a.stride == 2) { ok = ok && !((th | tw) & 1); ih = th >> 1; iw = tw >> 1; }
-                    else { ih = th; iw = tw; }
-                    ok = ok && (ih < a.Hi) && (iw < a.Wi);
-                } else {
-                    ih = xh[i] + ki; iw = xw[i] + kj;
-                    ok = (ih >= 0) && (ih < a.Hi) && (iw >= 0) && (iw < a.Wi);
-                }
-                if (ok) {
-                    const char *p = a.x + ((size_t)(xb[i] + ih * a.Wi + iw)) * a.pixbytes + cc * KB + xoff[i];
-                    v = *reinterpret_cast<const uint4 *>(p);
-                }
+            int ih, iw;
+            bool ok = xb[i] >= 0;
+            if (TRANSPOSED) {
+                const int th = xh[i] - ki, tw = xw[i] - kj;
+                ok = ok && (th >= 0) && (tw >= 0);
+                if (a.stride == 2) { ok = ok && !((th | tw) & 1); ih = th >> 1; iw = tw >> 1; }
+                else { ih = th; iw = tw; }
+                ok = ok && (ih < a.Hi) && (iw < a.Wi);
+            } else {
+                ih = xh[i] + ki; iw = xw[i] + kj;
+                ok = ok && (ih >= 0) && (ih < a.Hi) && (iw >= 0) && (iw < a.Wi);
             }
-            rx[i] = v;
+            pix[i] = ok ? (unsigned)(xb[i] + ih * a.Wi + iw) * (unsigned)a.pixbytes + xoff[i] : OOB;
         }
+    };
+    uint4 rw[NLW], rx[NLX];
+    auto load_global = [&](unsigned koff, unsigned ccoff) {
+#pragma unroll
+        for (int i = 0; i < NLW; ++i)
+            rw[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srcW, woff[i] == OOB ? OOB : woff[i] + koff, 0, 0));
+#pragma unroll
+        for (int i = 0; i < NLX; ++i)
+            rx[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srcX, pix[i] == OOB ? OOB : pix[i] + ccoff, 0, 0));
     };
     auto store_lds = [&]() {
 #pragma unroll
@@ -167,15 +172,21 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
     };
 
     const int nit = taps * cchunks;
-    int tap = 0, cc = 0;
+    int ki = 0, kj = 0, cc = 0;
+    set_tap(0, 0);
     load_global(0, 0);
     store_lds();
     __syncthreads();
     for (int it = 0; it < nit; ++it) {
-        int ntap = tap, ncc = cc + 1;
-        if (ncc == cchunks) { ncc = 0; ++ntap; }
         const bool more = (it + 1 < nit);
-        if (more) load_global(ntap, ncc);  // in flight under the MFMAs below
+        if (more) {                                   // next chunk's loads fly under the MFMAs below
+            if (++cc == cchunks) {
+                cc = 0;
+                if (++kj == a.kw) { kj = 0; ++ki; }
+                set_tap(ki, kj);
+            }
+            load_global((unsigned)(it + 1) * KB, (unsigned)cc * KB);
+        }
 #pragma unroll
         for (int ks = 0; ks < KB / 32; ++ks) {
             uint4 fa[TN], fb[TM];
@@ -195,7 +206,6 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
             store_lds();
             __syncthreads();
         }
-        tap = ntap; cc = ncc;
     }
 
     // epilogue: lane (pixel r, half h) holds channels 8q+4h+{0..3} of each 32-channel tile
@@ -269,6 +279,7 @@ struct WgArgs {
     int M, nsplit, per_split;  // per_split = pixels per split (multiple of PK)
     int co_tiles, ci_tiles;
     int pixbytes;              // byte pitch between adjacent x pixels (= Cin*esize except for the stem)
+    unsigned xbytes, gbytes;   // tensor sizes for the buffer descriptors
 };
 
 template <typename T, int TM, int TN>
@@ -311,32 +322,50 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgArgs a)
     const int coutA = min(TM * 32, a.Cout - co0) * ES;  // valid bytes of this tile's rows
     const int cinB = min(TN * 32, a.Cin - ci0) * ES;
 
+    // Buffer descriptors + per-lane row state: the stage loop below does no integer division and no
+    // 64-bit address arithmetic; rows past the end / padding taps read as zero through the range check.
+    const __amdgpu_buffer_rsrc_t srcG = __builtin_amdgcn_make_buffer_rsrc((void *)a.gy, 0, a.gbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srcX = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFF00u;
+    unsigned offA[NLA], offB[NLB];
+    int pA[NLA], pB[NLB], bB[NLB], ohB[NLB], owB[NLB];
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+        const int c = lane + i * 64;
+        const int off = (c % CA) * 16;
+        pA[i] = p_begin + c / CA;
+        offA[i] = off < coutA ? (unsigned)(co0 * ES + off) : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+        const int c = lane + i * 64;
+        const int off = (c % CB) * 16;
+        const int p = p_begin + c / CB;
+        pB[i] = p;
+        offB[i] = off < cinB ? (unsigned)(ci0 * ES + off) : OOB;
+        const int b = p / (a.Ho * a.Wo);
+        const int rem = p - b * (a.Ho * a.Wo);
+        bB[i] = b; ohB[i] = rem / a.Wo; owB[i] = rem - ohB[i] * a.Wo;
+    }
+
     for (int p0 = p_begin; p0 < p_end; p0 += PK) {
         uint4 ra[NLA], rb[NLB];
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
-            const int c = lane + i * 64;
-            const int row = c / CA, off = (c % CA) * 16;
-            const int p = p0 + row;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (p < p_end && off < coutA) v = *reinterpret_cast<const uint4 *>(a.gy + (size_t)p * rowA + co0 * ES + off);
-            ra[i] = v;
+            const bool ok = (pA[i] < p_end) && (offA[i] != OOB);
+            ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srcG, ok ? (unsigned)pA[i] * (unsigned)rowA + offA[i] : OOB, 0, 0));
+            pA[i] += PK;
         }
 #pragma unroll
         for (int i = 0; i < NLB; ++i) {
-            const int c = lane + i * 64;
-            const int row = c / CB, off = (c % CB) * 16;
-            const int p = p0 + row;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (p < p_end && off < cinB) {
-                const int b = p / (a.Ho * a.Wo);
-                const int rem = p - b * (a.Ho * a.Wo);
-                const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-                const int ih = oh * a.stride - a.pad + ki, iw = ow * a.stride - a.pad + kj;
-                if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
-                    v = *reinterpret_cast<const uint4 *>(a.x + ((size_t)(b * a.H + ih) * a.W + iw) * a.pixbytes + ci0 * ES + off);
-            }
-            rb[i] = v;
+            const int ih = ohB[i] * a.stride - a.pad + ki, iw = owB[i] * a.stride - a.pad + kj;
+            const bool ok = (pB[i] < p_end) && (offB[i] != OOB) && (ih >= 0) && (ih < a.H) && (iw >= 0) && (iw < a.W);
+            const unsigned vo = (unsigned)((bB[i] * a.H + ih) * a.W + iw) * (unsigned)a.pixbytes + offB[i];
+            rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srcX, ok ? vo : OOB, 0, 0));
+            pB[i] += PK;
+            owB[i] += PK;
+            while (owB[i] >= a.Wo) { owB[i] -= a.Wo; ++ohB[i]; }
+            while (ohB[i] >= a.Ho) { ohB[i] -= a.Ho; ++bB[i]; }
         }
         // previous stage's LDS reads have all been consumed by MFMAs issued before this
         // point in program order of the same wave; ds ops of one wave execute in order.
@@ -446,6 +475,9 @@ extern "C" int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const flo
     a.B = B; a.Hi = H; a.Wi = W; a.Ck = Cin; a.Ho = Ho; a.Wo = Wo; a.Cn = Cout;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.relu = relu; a.M = B * Ho * Wo;
     a.pixbytes = Cin * (dtype == DCF_F32 ? 4 : 2);
+    DCF_REQUIRE((int64_t)B * H * W * a.pixbytes < 0xFFFFFF00ll, "dcf_conv2d_fwd: tensor exceeds the 4 GiB buffer-descriptor range");
+    a.xbytes = (unsigned)((int64_t)B * H * W * a.pixbytes);
+    a.wbytes = (unsigned)((int64_t)Cout * kh * kw * a.pixbytes);
     if (dtype == DCF_F32) return launch_igemm<float, false>(a, S(stream), "conv_fwd_f32");
     return launch_igemm<bf16_t, false>(a, S(stream), "conv_fwd_bf16");
 }
@@ -463,6 +495,9 @@ extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const
     a.B = B; a.Hi = Ho; a.Wi = Wo; a.Ck = Cout; a.Ho = H; a.Wo = W; a.Cn = Cin;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.relu = 0; a.M = B * H * W;
     a.pixbytes = Cout * (dtype == DCF_F32 ? 4 : 2);
+    DCF_REQUIRE((int64_t)B * Ho * Wo * a.pixbytes < 0xFFFFFF00ll, "dcf_conv2d_dgrad: tensor exceeds the 4 GiB buffer-descriptor range");
+    a.xbytes = (unsigned)((int64_t)B * Ho * Wo * a.pixbytes);
+    a.wbytes = (unsigned)((int64_t)Cin * kh * kw * a.pixbytes);
     if (dtype == DCF_F32) return launch_igemm<float, true>(a, S(stream), "conv_dgrad_f32");
     return launch_igemm<bf16_t, true>(a, S(stream), "conv_dgrad_bf16");
 }
@@ -499,6 +534,9 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
     a.M = B * Ho * Wo; a.nsplit = nsplit;
     a.pixbytes = Cin * (dtype == DCF_F32 ? 4 : 2);
+    DCF_REQUIRE((int64_t)B * H * W * a.pixbytes < 0xFFFFFF00ll && (int64_t)a.M * Cout * 4 < 0xFFFFFF00ll, "dcf_conv2d_wgrad: tensor exceeds the 4 GiB buffer-descriptor range");
+    a.xbytes = (unsigned)((int64_t)B * H * W * a.pixbytes);
+    a.gbytes = (unsigned)((int64_t)a.M * Cout * (dtype == DCF_F32 ? 4 : 2));
     a.per_split = cdiv(cdiv(a.M, nsplit), 32) * 32;
     int TM, TN;
     wgrad_tiles(Cin, Cout, TM, TN);
@@ -536,6 +574,8 @@ extern "C" int dcf_stem7x7_fwd(int dtype, const void *img4, const void *w, const
     a.B = B; a.Hi = H + 6; a.Wi = W + 8; a.Ck = 32; a.Ho = Ho; a.Wo = Wo; a.Cn = Cout;
     a.kh = 7; a.kw = 1; a.stride = 2; a.pad = 0; a.relu = relu; a.M = B * Ho * Wo;
     a.pixbytes = 4 * (dtype == DCF_F32 ? 4 : 2);
+    a.xbytes = (unsigned)((int64_t)B * (H + 6) * (W + 8) * a.pixbytes);
+    a.wbytes = (unsigned)((int64_t)Cout * 7 * 32 * (dtype == DCF_F32 ? 4 : 2));
     if (dtype == DCF_F32) return launch_igemm<float, false>(a, S(stream), "stem_fwd_f32");
     return launch_igemm<bf16_t, false>(a, S(stream), "stem_fwd_bf16");
 }
@@ -550,6 +590,8 @@ extern "C" int dcf_stem7x7_wgrad(int dtype, const void *img4, const void *gy, fl
     a.kh = 7; a.kw = 1; a.stride = 2; a.pad = 0;
     a.M = B * Ho * Wo; a.nsplit = nsplit;
     a.pixbytes = 4 * (dtype == DCF_F32 ? 4 : 2);
+    a.xbytes = (unsigned)((int64_t)B * (H + 6) * (W + 8) * a.pixbytes);
+    a.gbytes = (unsigned)((int64_t)a.M * Cout * (dtype == DCF_F32 ? 4 : 2));
     a.per_split = cdiv(cdiv(a.M, nsplit), 32) * 32;
     const int TM = Cout >= 64 ? 2 : 1;
     a.co_tiles = cdiv(Cout, TM * 32);

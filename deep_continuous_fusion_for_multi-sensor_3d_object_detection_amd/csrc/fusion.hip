@@ -59,22 +59,23 @@ __device__ __forceinline__ void atomic_add4(float *p, float4 v, float w)
     atomicAdd(p + 0, v.x * w); atomicAdd(p + 1, v.y * w); atomicAdd(p + 2, v.z * w); atomicAdd(p + 3, v.w * w);
 }
 
+// One channel per lane: a wave-instruction's atomics then cover whole contiguous channel rows
+// (256 B per 64 channels), the shape the memory-side atomic units run at full rate on.
 template <typename T>
-__global__ void __launch_bounds__(256) k_point_sample_bwd(const T *gfp, int Hf, int Wf, int C4, const float *uv, const int *count, int n_max,
+__global__ void __launch_bounds__(256) k_point_sample_bwd(const T *gfp, int Hf, int Wf, int C, const float *uv, const int *count, int n_max,
                                                           float *gfmap)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int n = min(*count, n_max);
-    const int64_t p = e / C4;
+    const int64_t p = e / C;
     if (p >= n) return;
-    const int c = (int)(e - p * C4) * 4;
+    const int c = (int)(e - p * C);
     const Taps t = make_taps(uv[2 * p], uv[2 * p + 1], Hf, Wf);
-    const int C = C4 * 4;
-    const float4 g = ld4(gfp + e * 4);
-    atomic_add4(gfmap + ((int64_t)t.y0 * Wf + t.x0) * C + c, g, t.w00);
-    atomic_add4(gfmap + ((int64_t)t.y0 * Wf + t.x1) * C + c, g, t.w01);
-    atomic_add4(gfmap + ((int64_t)t.y1 * Wf + t.x0) * C + c, g, t.w10);
-    atomic_add4(gfmap + ((int64_t)t.y1 * Wf + t.x1) * C + c, g, t.w11);
+    const float g = DT<T>::ld(gfp + e);
+    atomicAdd(gfmap + ((int64_t)t.y0 * Wf + t.x0) * C + c, g * t.w00);
+    atomicAdd(gfmap + ((int64_t)t.y0 * Wf + t.x1) * C + c, g * t.w01);
+    atomicAdd(gfmap + ((int64_t)t.y1 * Wf + t.x0) * C + c, g * t.w10);
+    atomicAdd(gfmap + ((int64_t)t.y1 * Wf + t.x1) * C + c, g * t.w11);
 }
 
 struct FuseGeom {
@@ -126,56 +127,42 @@ __global__ void __launch_bounds__(256) k_fusion_gather_fwd(const T *P, const flo
     if (c == 0) cnt[p] = (float)nv;
 }
 
-// backward: thread t owns channel group t % C4 over a grid-stride loop of (pixel, group) items
+// backward: thread t owns channel t % C over a grid-stride loop of (pixel, channel) items, so the
+// scatter-add of one neighbour is one contiguous row segment per wave-instruction.
 template <typename T>
 __global__ void __launch_bounds__(256) k_fusion_gather_bwd(const T *P, const float *xyz, const int *idx, FuseGeom g, const float *w1d,
-                                                           const float *b1, int C4, const T *ghsum, float *gP, float *gw1d, float *gb1,
+                                                           const float *b1, int C, const T *ghsum, float *gP, float *gw1d, float *gb1,
                                                            int64_t stride)
 {
     extern __shared__ float sm[];  // [C][4]: gw1d x3, gb1
-    const int C = C4 * 4;
     for (int i = threadIdx.x; i < C * 4; i += blockDim.x) sm[i] = 0.f;
     __syncthreads();
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int hw = g.h * g.w;
-    const int64_t nvec = (int64_t)hw * C4;
+    const int64_t nel = (int64_t)hw * C;
     if (t < stride) {
-        const int c = (int)(t % C4) * 4;
-        float wd[4][3], bb[4], aw[4][3], ab[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            wd[q][0] = w1d[(c + q) * 3]; wd[q][1] = w1d[(c + q) * 3 + 1]; wd[q][2] = w1d[(c + q) * 3 + 2];
-            bb[q] = b1[c + q];
-            aw[q][0] = aw[q][1] = aw[q][2] = 0.f; ab[q] = 0.f;
-        }
-        for (int64_t e = t; e < nvec; e += stride) {
-            const int64_t p = e / C4;
+        const int c = (int)(t % C);
+        const float w0 = w1d[c * 3], w1 = w1d[c * 3 + 1], w2 = w1d[c * 3 + 2], bb = b1[c];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, ab = 0.f;
+        for (int64_t e = t; e < nel; e += stride) {
+            const int64_t p = e / C;
             float X, Y;
             pixel_centre(g, (int)(p / g.w), (int)(p % g.w), X, Y);
-            const float4 gv = ld4(ghsum + e * 4);
-            const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+            const float gg = DT<T>::ld(ghsum + e);
             for (int k = 0; k < g.K; ++k) {
                 const int id = idx[(int64_t)k * hw + p];
                 if (id < 0) continue;
                 const float dx = xyz[3 * id] - X, dy = xyz[3 * id + 1] - Y, dz = xyz[3 * id + 2];
-                const float4 pv = ld4(P + (int64_t)id * C + c);
-                const float pp[4] = {pv.x, pv.y, pv.z, pv.w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float pre = pp[q] + (wd[q][0] * dx + wd[q][1] * dy + wd[q][2] * dz) + bb[q];
-                    const float d = pre > 0.f ? gg[q] : 0.f;
-                    if (d != 0.f) atomicAdd(gP + (int64_t)id * C + c + q, d);
-                    aw[q][0] += d * dx; aw[q][1] += d * dy; aw[q][2] += d * dz; ab[q] += d;
-                }
+                const float pre = DT<T>::ld(P + (int64_t)id * C + c) + (w0 * dx + w1 * dy + w2 * dz) + bb;
+                const float d = pre > 0.f ? gg : 0.f;
+                if (d != 0.f) atomicAdd(gP + (int64_t)id * C + c, d);
+                a0 += d * dx; a1 += d * dy; a2 += d * dz; ab += d;
             }
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            atomicAdd(&sm[(c + q) * 4 + 0], aw[q][0]);
-            atomicAdd(&sm[(c + q) * 4 + 1], aw[q][1]);
-            atomicAdd(&sm[(c + q) * 4 + 2], aw[q][2]);
-            atomicAdd(&sm[(c + q) * 4 + 3], ab[q]);
-        }
+        atomicAdd(&sm[c * 4 + 0], a0);
+        atomicAdd(&sm[c * 4 + 1], a1);
+        atomicAdd(&sm[c * 4 + 2], a2);
+        atomicAdd(&sm[c * 4 + 3], ab);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < C; i += blockDim.x) {
@@ -206,8 +193,8 @@ extern "C" int dcf_point_sample_bwd(int dtype, const void *gfp, int Hf, int Wf, 
     DCF_REQUIRE(gfp && uv && count_dev && gfmap && Cf % 4 == 0, "dcf_point_sample_bwd: bad arguments");
     if (n_max == 0) return DCF_OK;
     hipStream_t s = S(stream);
-    const int64_t total = (int64_t)n_max * (Cf / 4);
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("point_sample_bwd", s, hipLaunchKernelGGL(k_point_sample_bwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)gfp, Hf, Wf, Cf / 4, uv, count_dev, n_max, gfmap)); })
+    const int64_t total = (int64_t)n_max * Cf;
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("point_sample_bwd", s, hipLaunchKernelGGL(k_point_sample_bwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)gfp, Hf, Wf, Cf, uv, count_dev, n_max, gfmap)); })
     return DCF_OK;
 }
 
@@ -232,11 +219,10 @@ extern "C" int dcf_fusion_gather_bwd(int dtype, const void *P, const float *xyz,
     FuseGeom g;
     g.h = h; g.w = w; g.stride = stride; g.K = K; g.xs = xs; g.xo = xo; g.ys = ys; g.yo = yo;
     hipStream_t s = S(stream);
-    const int C4 = Cb / 4;
-    const int64_t nvec = (int64_t)h * w * C4;
-    int64_t want = nvec < 128 * 1024 ? nvec : 128 * 1024;
-    if (want < C4) want = C4;
-    const int64_t stride_t = want / C4 * C4;
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("fusion_gather_bwd", s, hipLaunchKernelGGL(k_fusion_gather_bwd<T>, dim3(cdiv(stride_t, 256)), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, idx, g, w1d, b1, C4, (const T *)ghsum, gP, gw1d, gb1, stride_t)); })
+    const int64_t nel = (int64_t)h * w * Cb;
+    int64_t want = nel < 512 * 1024 ? nel : 512 * 1024;
+    if (want < Cb) want = Cb;
+    const int64_t stride_t = want / Cb * Cb;
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("fusion_gather_bwd", s, hipLaunchKernelGGL(k_fusion_gather_bwd<T>, dim3(cdiv(stride_t, 256)), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, idx, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, stride_t)); })
     return DCF_OK;
 }
