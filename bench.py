@@ -103,9 +103,9 @@ def conv_flops(backend_cls):
         add("conv_fwd_" + suffix(self), 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * L.cout * L.cin * L.taps)
         return y
 
-    def dgrad(self, L, gy, in_shape, res):
+    def dgrad(self, L, gy, in_shape, res, *more):
         add("conv_dgrad_" + suffix(self), 2.0 * gy.shape[0] * gy.shape[1] * gy.shape[2] * L.cout * L.cin * L.taps)
-        return orig_d(self, L, gy, in_shape, res)
+        return orig_d(self, L, gy, in_shape, res, *more)
 
     def wgrad(self, L, x, gy):
         add("conv_wgrad_" + suffix(self), 2.0 * gy.shape[0] * gy.shape[1] * gy.shape[2] * L.cout * L.cin * L.taps)

@@ -39,7 +39,7 @@ SIGNATURES = {
     "dcf_nchw_to_nhwc": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "dcf_image_to_nhwc4": (c_int, [c_int, P, P, c_int, c_int, c_int, P]),
     "dcf_conv2d_fwd": (c_int, [c_int, P, P, P, P, P] + [c_int] * 12 + [P]),
-    "dcf_conv2d_dgrad": (c_int, [c_int, P, P, P, P] + [c_int] * 11 + [P]),
+    "dcf_conv2d_dgrad": (c_int, [c_int, P, P, P, P, P, P] + [c_int] * 11 + [P]),
     "dcf_conv2d_wgrad_splits": (c_int, [c_int] * 7),
     "dcf_conv2d_wgrad": (c_int, [c_int, P, P, P, c_int] + [c_int] * 11 + [P]),
     "dcf_stem7x7_fwd": (c_int, [c_int, P, P, P, P] + [c_int] * 7 + [P]),

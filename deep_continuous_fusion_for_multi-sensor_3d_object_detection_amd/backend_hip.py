@@ -107,10 +107,19 @@ class HipBackend(object):
         L.out_shape = (y.shape[0], y.shape[1], y.shape[2])
         return y
 
-    def conv_dgrad(self, L, gy, in_shape, res):
+    def conv_dgrad(self, L, gy, in_shape, res, mask=None, sum_layers=None):
+        """mask / sum_layers: fused ReLU backward + dbeta sums of the layer(s) that produced the tensor gx belongs to."""
         if L.wdgrad_off < 0:
             raise H.DcfError("layer %s was planned without an input gradient" % L.name)
-        return ops.conv2d_dgrad(self.dtype, gy, self._w(L, True), res, in_shape, L.kh, L.kw, L.stride, L.pad)
+        seg = None
+        if sum_layers:
+            L0 = sum_layers[0]
+            seg = self.gsum[L0.gsum_off:L0.gsum_off + L0.cout_pad]
+        gx = ops.conv2d_dgrad(self.dtype, gy, self._w(L, True), res, in_shape, L.kh, L.kw, L.stride, L.pad, mask, seg)
+        if sum_layers:
+            for Lx in sum_layers[1:]:
+                self.gsum[Lx.gsum_off:Lx.gsum_off + Lx.cout_pad].copy_(seg)
+        return gx
 
     def conv_wgrad(self, L, x, gy):
         ops.conv2d_wgrad(self.dtype, x, gy, self.slabs[L.slab_off:], L.nsplit, L.kh, L.kw, L.stride, L.pad)

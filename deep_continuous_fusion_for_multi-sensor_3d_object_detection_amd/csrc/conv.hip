@@ -42,6 +42,8 @@ struct ConvArgs {
     int M;
     int pixbytes;        // byte pitch between adjacent input pixels (= Ck*esize except for the stem)
     unsigned xbytes, wbytes;  // sizes of the gathered tensor and of the weight image (buffer descriptors)
+    const char *mask;         // [M][Cn] or null: output *= (mask > 0)
+    float *gsum;              // [Cn] or null: += per-channel sums of the stored output
 };
 
 template <typename T> struct Mma;
@@ -208,9 +210,19 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
         }
     }
 
-    // epilogue: lane (pixel r, half h) holds channels 8q+4h+{0..3} of each 32-channel tile
+    // epilogue: lane (pixel r, half h) holds channels 8q+4h+{0..3} of each 32-channel tile.
+    //   v = acc + shift + res ; relu ; (dgrad only) v *= (mask > 0) i.e. the ReLU backward of the
+    //   layer that PRODUCED this tensor, and per-channel sums of the masked gradient (its dbeta).
     T *y = reinterpret_cast<T *>(a.y);
     const T *res = reinterpret_cast<const T *>(a.res);
+    const T *mask = reinterpret_cast<const T *>(a.mask);
+    float cs[TN][4][4];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cs[i][q][e] = 0.f;
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = m0 + (wm * TM + j) * 32 + r;
@@ -231,9 +243,38 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
                     v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                 }
                 if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (mask) {
+                    const float4 mm = ld4(mask + o);
+                    v.x = mm.x > 0.f ? v.x : 0.f; v.y = mm.y > 0.f ? v.y : 0.f;
+                    v.z = mm.z > 0.f ? v.z : 0.f; v.w = mm.w > 0.f ? v.w : 0.f;
+                }
                 st4(y + o, v);
+                if (a.gsum) {   // sum what was STORED (rounded to the compute dtype), like the standalone kernel
+                    const float4 w = DT<T>::size == 2 ? make_float4(bf2f(f2bf(v.x)), bf2f(f2bf(v.y)), bf2f(f2bf(v.z)), bf2f(f2bf(v.w))) : v;
+                    cs[i][q][0] += w.x; cs[i][q][1] += w.y; cs[i][q][2] += w.z; cs[i][q][3] += w.w;
+                }
             }
         }
+    }
+    if (a.gsum) {
+        // pixels of a wave tile sit on lanes r = 0..31: butterfly over the 5 low lane bits, then the
+        // WM waves that share these channels combine through LDS and one lane per channel adds to HBM.
+        float *sums = reinterpret_cast<float *>(lds);   // K loop is done: the staging buffer is free
+        for (int i = tid; i < BN; i += 256) sums[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = cs[i][q][e];
+#pragma unroll
+                    for (int o = 1; o < 32; o <<= 1) x += __shfl_xor(x, o, 64);
+                    if (r == 0) atomicAdd(&sums[(wn * TN + i) * 32 + 8 * q + 4 * h + e], x);
+                }
+        __syncthreads();
+        for (int i = tid; i < BN; i += 256) atomicAdd(a.gsum + n0 + i, sums[i]);
     }
 }
 
@@ -472,6 +513,7 @@ extern "C" int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const flo
     DCF_REQUIRE((int64_t)B * H * W * Cin < (1ll << 31) * 1, "dcf_conv2d_fwd: tensor too large for 32-bit pixel index");
     ConvArgs a;
     a.x = (const char *)x; a.w = (const char *)w; a.shift = shift; a.res = (const char *)res; a.y = (char *)y;
+    a.mask = nullptr; a.gsum = nullptr;
     a.B = B; a.Hi = H; a.Wi = W; a.Ck = Cin; a.Ho = Ho; a.Wo = Wo; a.Cn = Cout;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.relu = relu; a.M = B * Ho * Wo;
     a.pixbytes = Cin * (dtype == DCF_F32 ? 4 : 2);
@@ -482,7 +524,7 @@ extern "C" int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const flo
     return launch_igemm<bf16_t, false>(a, S(stream), "conv_fwd_bf16");
 }
 
-extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const void *res, void *gx,
+extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const void *res, const void *mask, float *gsum, void *gx,
                                 int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
                                 dcf_stream_t stream)
 {
@@ -492,6 +534,7 @@ extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const
     DCF_REQUIRE(gy && wt && gx, "dcf_conv2d_dgrad: null pointer");
     ConvArgs a;
     a.x = (const char *)gy; a.w = (const char *)wt; a.shift = nullptr; a.res = (const char *)res; a.y = (char *)gx;
+    a.mask = (const char *)mask; a.gsum = gsum;
     a.B = B; a.Hi = Ho; a.Wi = Wo; a.Ck = Cout; a.Ho = H; a.Wo = W; a.Cn = Cin;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.relu = 0; a.M = B * H * W;
     a.pixbytes = Cout * (dtype == DCF_F32 ? 4 : 2);
@@ -571,6 +614,7 @@ extern "C" int dcf_stem7x7_fwd(int dtype, const void *img4, const void *w, const
     DCF_REQUIRE(Ho == (H + 6 - 7) / 2 + 1 && Wo == (W + 6 - 7) / 2 + 1, "dcf_stem7x7_fwd: output size mismatch");
     ConvArgs a;
     a.x = (const char *)img4; a.w = (const char *)w; a.shift = shift; a.res = nullptr; a.y = (char *)y;
+    a.mask = nullptr; a.gsum = nullptr;
     a.B = B; a.Hi = H + 6; a.Wi = W + 8; a.Ck = 32; a.Ho = Ho; a.Wo = Wo; a.Cn = Cout;
     a.kh = 7; a.kw = 1; a.stride = 2; a.pad = 0; a.relu = relu; a.M = B * Ho * Wo;
     a.pixbytes = 4 * (dtype == DCF_F32 ? 4 : 2);

@@ -127,38 +127,58 @@ __global__ void __launch_bounds__(256) k_fusion_gather_fwd(const T *P, const flo
     if (c == 0) cnt[p] = (float)nv;
 }
 
-// backward: thread t owns channel t % C over a grid-stride loop of (pixel, channel) items, so the
-// scatter-add of one neighbour is one contiguous row segment per wave-instruction.
+// backward: a thread owns one channel of a RUN of consecutive BEV pixels.  Neighbouring pixels mostly
+// share their nearest points, so the per-slot (point id, partial sum) is kept in registers and flushed
+// with one atomic only when the id changes: in sparse regions thousands of same-address atomics
+// collapse into a few.  Each flush of a wave is one contiguous channel-row segment.
 template <typename T>
 __global__ void __launch_bounds__(256) k_fusion_gather_bwd(const T *P, const float *xyz, const int *idx, FuseGeom g, const float *w1d,
                                                            const float *b1, int C, const T *ghsum, float *gP, float *gw1d, float *gb1,
-                                                           int64_t stride)
+                                                           int chunk)
 {
     extern __shared__ float sm[];  // [C][4]: gw1d x3, gb1
     for (int i = threadIdx.x; i < C * 4; i += blockDim.x) sm[i] = 0.f;
     __syncthreads();
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int hw = g.h * g.w;
-    const int64_t nel = (int64_t)hw * C;
-    if (t < stride) {
-        const int c = (int)(t % C);
+    const int64_t group = t / C;
+    const int c = (int)(t - group * C);
+    const int64_t p_lo = group * chunk;
+    if (p_lo < hw) {
+        const int p_hi = (int)min((int64_t)hw, p_lo + chunk);
         const float w0 = w1d[c * 3], w1 = w1d[c * 3 + 1], w2 = w1d[c * 3 + 2], bb = b1[c];
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, ab = 0.f;
-        for (int64_t e = t; e < nel; e += stride) {
-            const int64_t p = e / C;
+        constexpr int KMAX = 8;
+        int cur_id[KMAX];
+        float cur_acc[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { cur_id[k] = -1; cur_acc[k] = 0.f; }
+        for (int p = (int)p_lo; p < p_hi; ++p) {
             float X, Y;
-            pixel_centre(g, (int)(p / g.w), (int)(p % g.w), X, Y);
-            const float gg = DT<T>::ld(ghsum + e);
-            for (int k = 0; k < g.K; ++k) {
-                const int id = idx[(int64_t)k * hw + p];
-                if (id < 0) continue;
-                const float dx = xyz[3 * id] - X, dy = xyz[3 * id + 1] - Y, dz = xyz[3 * id + 2];
-                const float pre = DT<T>::ld(P + (int64_t)id * C + c) + (w0 * dx + w1 * dy + w2 * dz) + bb;
-                const float d = pre > 0.f ? gg : 0.f;
-                if (d != 0.f) atomicAdd(gP + (int64_t)id * C + c, d);
-                a0 += d * dx; a1 += d * dy; a2 += d * dz; ab += d;
+            pixel_centre(g, p / g.w, p % g.w, X, Y);
+            const float gg = DT<T>::ld(ghsum + (int64_t)p * C + c);
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                if (k < g.K) {
+                    const int id = idx[(int64_t)k * hw + p];
+                    if (id != cur_id[k]) {
+                        if (cur_id[k] >= 0 && cur_acc[k] != 0.f) atomicAdd(gP + (int64_t)cur_id[k] * C + c, cur_acc[k]);
+                        cur_id[k] = id;
+                        cur_acc[k] = 0.f;
+                    }
+                    if (id >= 0) {
+                        const float dx = xyz[3 * id] - X, dy = xyz[3 * id + 1] - Y, dz = xyz[3 * id + 2];
+                        const float pre = DT<T>::ld(P + (int64_t)id * C + c) + (w0 * dx + w1 * dy + w2 * dz) + bb;
+                        const float d = pre > 0.f ? gg : 0.f;
+                        cur_acc[k] += d;
+                        a0 += d * dx; a1 += d * dy; a2 += d * dz; ab += d;
+                    }
+                }
             }
         }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (cur_id[k] >= 0 && cur_acc[k] != 0.f) atomicAdd(gP + (int64_t)cur_id[k] * C + c, cur_acc[k]);
         atomicAdd(&sm[c * 4 + 0], a0);
         atomicAdd(&sm[c * 4 + 1], a1);
         atomicAdd(&sm[c * 4 + 2], a2);
@@ -219,10 +239,11 @@ extern "C" int dcf_fusion_gather_bwd(int dtype, const void *P, const float *xyz,
     FuseGeom g;
     g.h = h; g.w = w; g.stride = stride; g.K = K; g.xs = xs; g.xo = xo; g.ys = ys; g.yo = yo;
     hipStream_t s = S(stream);
-    const int64_t nel = (int64_t)h * w * Cb;
-    int64_t want = nel < 512 * 1024 ? nel : 512 * 1024;
-    if (want < Cb) want = Cb;
-    const int64_t stride_t = want / Cb * Cb;
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("fusion_gather_bwd", s, hipLaunchKernelGGL(k_fusion_gather_bwd<T>, dim3(cdiv(stride_t, 256)), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, idx, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, stride_t)); })
+    DCF_REQUIRE(K <= 8, "dcf_fusion_gather_bwd: K must be <= 8");
+    const int64_t hw = (int64_t)h * w;
+    int chunk = (int)(hw * Cb / (256 * 1024));            // ~1024 workgroups
+    if (chunk < 16) chunk = 16;
+    const int64_t groups = (hw + chunk - 1) / chunk;
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("fusion_gather_bwd", s, hipLaunchKernelGGL(k_fusion_gather_bwd<T>, dim3(cdiv(groups * Cb, 256)), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, idx, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, chunk)); })
     return DCF_OK;
 }

@@ -430,6 +430,129 @@ __global__ void __launch_bounds__(256) k_knn_search(const int *count, int n_max,
     }
 }
 
+// Coarse sites (few pixels, many points per cell): one WAVE per pixel, lanes split the candidate
+// points of every visited cell range, each keeping a private K-best; the wave-wide K-best is then
+// extracted with K rounds of a 64-lane lexicographic (d2, index) min.  Same traversal and the same
+// termination bounds as the tile kernel, so the result is the same exact K-best.
+template <int K>
+__device__ __forceinline__ void wave_merge(const TopK<K> &mine, float (&gd)[K], int (&gi)[K], int &gcnt)
+{
+    TopK<K> t = mine;  // popped copy
+    gcnt = 0;
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        float d = t.d[0];
+        int id = t.id[0];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float od = __shfl_xor(d, o, 64);
+            const int oi = __shfl_xor(id, o, 64);
+            if (od < d || (od == d && oi < id)) { d = od; id = oi; }
+        }
+        gd[q] = d; gi[q] = id;
+        if (id != 0x7fffffff) ++gcnt;
+        if (t.id[0] == id && id != 0x7fffffff) {   // the winning lane pops its head (ids are unique)
+#pragma unroll
+            for (int k = 0; k + 1 < K; ++k) { t.d[k] = t.d[k + 1]; t.id[k] = t.id[k + 1]; }
+            t.d[K - 1] = 3.0e38f; t.id[K - 1] = 0x7fffffff;
+        }
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256) k_knn_search_wave(const int *count, int n_max, KnnGrid g, const int *cellstart,
+                                                         const float4 *sorted, float rmax2, int *out)
+{
+    const int lane = threadIdx.x & 63;
+    const int pix = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int hw = g.h * g.w;
+    if (pix >= hw) return;
+    const int i = pix / g.w, j = pix - i * g.w;
+    const float s = (float)g.stride;
+    const float X = __fdiv_rn(__fsub_rn(__fmul_rn((float)i + 0.5f, s), g.xo), g.xs);
+    const float Y = __fdiv_rn(__fsub_rn(__fmul_rn((float)j + 0.5f, s), g.yo), g.ys);
+    const float cwmin = fminf(s / g.xs, s / g.ys);
+    const int n = min(*count, n_max);
+
+    TopK<K> top;
+    top.clear();
+    float gd[K];
+    int gi[K];
+    int gcnt = 0;
+#pragma unroll
+    for (int q = 0; q < K; ++q) { gd[q] = 3.0e38f; gi[q] = 0x7fffffff; }
+
+    auto scan_range = [&](int b, int e) {
+        for (int p = b + lane; p < e; p += 64) {
+            const float4 q = sorted[p];
+            const float dx = __fsub_rn(q.x, X), dy = __fsub_rn(q.y, Y);
+            const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+            if (!(rmax2 >= 0.0f && d2 > rmax2)) top.insert(d2, __float_as_int(q.z));
+        }
+    };
+
+    bool done = (n == 0);
+    if (!done) {
+        const int H8 = g.h8 * 8, W8 = g.w8 * 8;
+        for (int ci = max(i - 2, 0); ci <= min(i + 2, H8 - 1); ++ci) {
+            // columns j-2..j+2 split at coarse-block boundaries (cells of one block row are contiguous keys)
+            int c0 = max(j - 2, 0);
+            const int cend = min(j + 2, W8 - 1);
+            while (c0 <= cend) {
+                const int c1 = min(cend, (c0 | 7));
+                scan_range(cellstart[cell_key(ci, c0, g)], cellstart[cell_key(ci, c1, g) + 1]);
+                c0 = c1 + 1;
+            }
+        }
+        wave_merge<K>(top, gd, gi, gcnt);
+        const float bound = 2.5f * cwmin - 1e-3f;
+        if (gcnt >= K && gd[K - 1] < bound * bound) done = true;
+        if (rmax2 >= 0.0f && bound > 0.f && bound * bound > rmax2) done = true;
+    }
+    if (!done) {
+        top.clear();
+        gcnt = 0;
+#pragma unroll
+        for (int q = 0; q < K; ++q) { gd[q] = 3.0e38f; gi[q] = 0x7fffffff; }
+        const int I = i >> 3, J = j >> 3;
+        const int Rmax = max(g.h8, g.w8);
+        for (int R = 0; R <= Rmax && !done; ++R) {
+            for (int a = -R; a <= R; ++a) {
+                const int bi = I + a;
+                if (bi < 0 || bi >= g.h8) continue;
+                const bool edge = (a == -R || a == R);
+                for (int b = -R; b <= R; b += (edge ? 1 : 2 * R)) {
+                    const int bj = J + b;
+                    if (bj >= 0 && bj < g.w8) {
+                        const int k0 = (bi * g.w8 + bj) << 6;
+                        const int ps = cellstart[k0], pe = cellstart[k0 + 64];
+                        if (pe > ps) {
+                            bool visit = true;
+                            if (gcnt >= K) {   // prune with the (possibly stale, hence conservative) wave-wide K-th
+                                const float lox = ((float)(bi * 8) * s - g.xo) / g.xs, hix = ((float)(bi * 8 + 8) * s - g.xo) / g.xs;
+                                const float loy = ((float)(bj * 8) * s - g.yo) / g.ys, hiy = ((float)(bj * 8 + 8) * s - g.yo) / g.ys;
+                                const float ddx = fmaxf(0.f, fmaxf(lox - X, X - hix) - 1e-3f);
+                                const float ddy = fmaxf(0.f, fmaxf(loy - Y, Y - hiy) - 1e-3f);
+                                visit = (ddx * ddx + ddy * ddy) <= gd[K - 1];
+                            }
+                            if (visit) scan_range(ps, pe);
+                        }
+                    }
+                    if (R == 0) break;
+                }
+            }
+            wave_merge<K>(top, gd, gi, gcnt);
+            const float bound = (8.0f * (float)R + 0.5f) * cwmin - 1e-3f;
+            if (gcnt >= K && gd[K - 1] < bound * bound) done = true;
+            if (rmax2 >= 0.0f && bound > 0.f && bound * bound > rmax2) done = true;
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) out[q * hw + pix] = (q < gcnt) ? gi[q] : -1;
+    }
+}
+
 }  // namespace
 
 // ================================================================== C ABI
@@ -549,10 +672,16 @@ extern "C" int dcf_knn_bev(const float *xyz, const int32_t *count_dev, int n_max
         DCF_LAUNCH("knn_fill", s, hipLaunchKernelGGL(k_knn_fill, dim3(nb), dim3(256), 0, s, xyz, count_dev, n_max, pkey, cursor, sorted));
     }
     const int nbp = cdiv(g.h8 * g.w8, 4);   // one wave per 8x8 pixel tile
+    const bool per_wave = (h * w <= 20000);   // coarse sites: one wave per pixel (lanes split the candidates)
+    const int nbw = cdiv(h * w, 4);
 #define KNN_CASE(KK)                                                                                                     \
     case KK:                                                                                                             \
-        DCF_LAUNCH("knn_search", s, hipLaunchKernelGGL(k_knn_search<KK>, dim3(nbp), dim3(256), 0, s, count_dev, n_max, g, \
-                                                       cellstart, sorted, rmax2, idx_out));                              \
+        if (per_wave)                                                                                                    \
+            DCF_LAUNCH("knn_search_wave", s, hipLaunchKernelGGL(k_knn_search_wave<KK>, dim3(nbw), dim3(256), 0, s, count_dev, n_max, g, \
+                                                                cellstart, sorted, rmax2, idx_out));                     \
+        else                                                                                                             \
+            DCF_LAUNCH("knn_search", s, hipLaunchKernelGGL(k_knn_search<KK>, dim3(nbp), dim3(256), 0, s, count_dev, n_max, g, \
+                                                           cellstart, sorted, rmax2, idx_out));                          \
         break;
     switch (K) {
         KNN_CASE(1) KNN_CASE(2) KNN_CASE(3) KNN_CASE(4) KNN_CASE(5) KNN_CASE(6) KNN_CASE(7) KNN_CASE(8)

@@ -97,25 +97,32 @@ class Block(object):
         self.saved = (x, y1, y) if save else None
         return y
 
-    def backward(self, K, g, extra=None, need_gx=True):
-        """g = dL/dy (consumed / overwritten).  extra = gradient reaching x from other consumers."""
+    def sum_layers(self):
+        return [self.conv2] + ([self.down] if self.down is not None else [])
+
+    def backward(self, K, g, extra=None, need_gx=True, g_masked=False, prev=None):
+        """g = dL/dy (consumed / overwritten).  extra = gradient reaching x from other consumers.
+        g_masked: the producer of g already applied this block's output ReLU mask and dbeta sums.
+        prev: the Block whose output is this block's input x -- its ReLU backward (mask by x, dbeta
+        sums) is then fused into the epilogue of the dgrad that produces gx."""
         x, y1, y = self.saved
         self.saved = None
-        g2 = K.relu_mask_sum([self.conv2] + ([self.down] if self.down is not None else []), g, y, True)
+        g2 = g if g_masked else K.relu_mask_sum(self.sum_layers(), g, y, True)
         K.conv_wgrad(self.conv2, y1, g2)
-        gy1 = K.conv_dgrad(self.conv2, g2, tuple(y1.shape), None)
-        g1 = K.relu_mask_sum([self.conv1], gy1, y1, True)
+        g1 = K.conv_dgrad(self.conv2, g2, tuple(y1.shape), None, y1, [self.conv1])   # fused mask(y1) + dbeta(bn1)
         K.conv_wgrad(self.conv1, x, g1)
+        pm = x if prev is not None else None
+        ps = prev.sum_layers() if prev is not None else None
         if self.down is not None:
             K.conv_wgrad(self.down, x, g2)
             if not need_gx:
                 return None
             gx = K.conv_dgrad(self.down, g2, tuple(x.shape), extra)
-            return K.conv_dgrad(self.conv1, g1, tuple(x.shape), gx)
+            return K.conv_dgrad(self.conv1, g1, tuple(x.shape), gx, pm, ps)
         if not need_gx:
             return None
         assert extra is None, "an identity-shortcut block cannot take an extra gradient"
-        return K.conv_dgrad(self.conv1, g1, tuple(x.shape), g2)
+        return K.conv_dgrad(self.conv1, g1, tuple(x.shape), g2, pm, ps)
 
 
 class Plan(object):
@@ -291,6 +298,7 @@ class Plan(object):
         g = K.conv_dgrad(self.downconv1, gd1, tuple(c["x4"].shape), None)
         extras = {3: gx3, 2: gx2}          # gradient joining the output of stage index 3 / 2
         gF = None
+        masked = False
         for si in range(4, -1, -1):
             if si >= 1 and c["fused"]:
                 gF = self._fusion_backward(K, self.fusion[si - 1], g, si - 1, gF)
@@ -298,7 +306,16 @@ class Plan(object):
             for bi in range(len(blocks) - 1, -1, -1):
                 first = (si == 0 and bi == 0)
                 extra = extras.get(si - 1) if bi == 0 else None
-                g = blocks[bi].backward(K, g, extra, need_gx=not first)
+                # the block feeding this one: same stage, or the previous stage's last block when no
+                # fusion site sits in between (the fusion backward needs the unmasked gradient)
+                if bi > 0:
+                    prev = blocks[bi - 1]
+                elif si > 0 and not (c["fused"] and si - 1 >= 1):
+                    prev = self.stages[si - 1][-1]
+                else:
+                    prev = None
+                g = blocks[bi].backward(K, g, extra, need_gx=not first, g_masked=masked, prev=prev)
+                masked = prev is not None
         if c["fused"]:
             self._image_backward(K, gF)
         K.end_backward(self.layers)
@@ -344,11 +361,14 @@ class Plan(object):
             gp = K.resize_bwd(gp, (feats[i + 1].shape[1], feats[i + 1].shape[2]), False)
         K.conv_wgrad(self.img_lat[3], feats[3], gp)
         g = K.conv_dgrad(self.img_lat[3], gp, tuple(feats[3].shape), None)
+        masked = False
         for li in range(3, -1, -1):
             blocks = self.img_stages[li]
             for bi in range(len(blocks) - 1, -1, -1):
                 extra = gfeat[li - 1] if (bi == 0 and li > 0) else None
-                g = blocks[bi].backward(K, g, extra, need_gx=True)
+                prev = blocks[bi - 1] if bi > 0 else (self.img_stages[li - 1][-1] if li > 0 else None)
+                g = blocks[bi].backward(K, g, extra, need_gx=True, g_masked=masked, prev=prev)
+                masked = prev is not None
         # g = gradient at the max-pool output
         gc1 = K.maxpool_bwd(im["c1"], g)
         gc1 = K.relu_mask_sum([self.stem], gc1, im["c1"], True)

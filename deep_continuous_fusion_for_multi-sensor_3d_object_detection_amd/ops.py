@@ -48,11 +48,11 @@ def conv2d_fwd(dtype, x, w, shift, res, kh, kw, stride, pad, relu, cout):
     return y
 
 
-def conv2d_dgrad(dtype, gy, wt, res, in_shape, kh, kw, stride, pad):
+def conv2d_dgrad(dtype, gy, wt, res, in_shape, kh, kw, stride, pad, mask=None, gsum=None):
     B, Hh, W, Cin = in_shape
     _, Ho, Wo, Cout = gy.shape
     gx = torch.empty((B, Hh, W, Cin), dtype=gy.dtype, device=gy.device)
-    H.call("dcf_conv2d_dgrad", dtype, gy, wt, res, gx, B, Hh, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, H.stream_ptr())
+    H.call("dcf_conv2d_dgrad", dtype, gy, wt, res, mask, gsum, gx, B, Hh, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, H.stream_ptr())
     return gx
 
 

@@ -95,8 +95,10 @@ int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const float *shift, 
                    int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
                    int relu, dcf_stream_t stream);
 /* Input gradient: gx [B,H,W,Cin] = conv_transpose(gy [B,Ho,Wo,Cout], wt) (+ res).
- * wt [Cin][kh][kw][Cout] (dtype) as produced by dcf_weight_prep. */
-int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const void *res, void *gx,
+ * wt [Cin][kh][kw][Cout] (dtype) as produced by dcf_weight_prep.
+ * Optional fused ReLU backward of the layer that produced x: mask (dtype, like gx) zeroes gx where
+ * mask <= 0, and gsum fp32 [Cin] += per-channel sums of the stored gx (that layer's dL/dbeta). */
+int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const void *res, const void *mask, float *gsum, void *gx,
                      int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
                      dcf_stream_t stream);
 /* Weight gradient, split over pixel ranges: slabs fp32 [nsplit][Cout][kh][kw][Cin] (plain stores,
