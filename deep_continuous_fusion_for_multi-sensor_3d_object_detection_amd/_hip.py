@@ -39,11 +39,11 @@ SIGNATURES = {
     "dcf_nchw_to_nhwc": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "dcf_image_to_nhwc4": (c_int, [c_int, P, P, c_int, c_int, c_int, P]),
     "dcf_conv2d_fwd": (c_int, [c_int, P, P, P, P, P] + [c_int] * 12 + [P]),
-    "dcf_conv2d_dgrad": (c_int, [c_int, P, P, P, P, P, P] + [c_int] * 11 + [P]),
+    "dcf_conv2d_dgrad": (c_int, [c_int, P, P, P, P, P] + [c_int] * 11 + [P]),
     "dcf_conv2d_wgrad_splits": (c_int, [c_int] * 7),
-    "dcf_conv2d_wgrad": (c_int, [c_int, P, P, P, c_int] + [c_int] * 11 + [P]),
+    "dcf_conv2d_wgrad": (c_int, [c_int, P, P, P, P, c_int] + [c_int] * 11 + [P]),
     "dcf_stem7x7_fwd": (c_int, [c_int, P, P, P, P] + [c_int] * 7 + [P]),
-    "dcf_stem7x7_wgrad": (c_int, [c_int, P, P, P, c_int] + [c_int] * 6 + [P]),
+    "dcf_stem7x7_wgrad": (c_int, [c_int, P, P, P, P, c_int] + [c_int] * 6 + [P]),
     "dcf_weight_prep": (c_int, [c_int, P, c_int, P, P, P, P, c_float, P]),
     "dcf_wgrad_finalize": (c_int, [P, c_int, P, P, P, P, P, P, c_float, P]),
     "dcf_relu_bwd_chansum": (c_int, [c_int, P, P, P, c_i64, c_int, c_int, P]),

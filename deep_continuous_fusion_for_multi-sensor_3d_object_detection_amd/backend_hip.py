@@ -36,7 +36,7 @@ class HipBackend(object):
 
     # ------------------------------------------------------------------ arenas
     def _layout(self, layers):
-        woff = ssoff = goff = 0
+        woff = ssoff = 0
         for L in layers:
             K = L.taps * L.cin
             L.wfwd_off = woff
@@ -48,12 +48,11 @@ class HipBackend(object):
                 L.wdgrad_off = -1
             L.shift_off = ssoff
             ssoff += 2 * L.cout_pad
-            L.gsum_off = goff
-            goff += L.cout_pad
+            L.gsum_off = 0
             L.nsplit, L.slab_off = 0, 0
         self.warena = torch.zeros(max(woff, 16), dtype=torch.uint8, device=self.dev)
         self.ssarena = torch.zeros(max(ssoff, 4), dtype=torch.float32, device=self.dev)
-        self.gsum = torch.zeros(max(goff, 4), dtype=torch.float32, device=self.dev)
+        self.gsum = None
 
     def _upload_table(self, layers):
         tab = (H.ConvParam * len(layers))()
@@ -82,19 +81,21 @@ class HipBackend(object):
     def begin_backward(self, layers):
         sig = tuple(L.out_shape for L in layers)
         if sig != self._sig:
-            off = 0
+            off = goff = 0
             for L in layers:
                 if L.out_shape is None:
-                    L.nsplit, L.slab_off = 0, 0
+                    L.nsplit, L.slab_off, L.gsum_off = 0, 0, 0
                     continue
                 B, Ho, Wo = L.out_shape
                 L.nsplit = ops.conv2d_wgrad_splits(B, Ho, Wo, L.cin, L.cout_pad, L.kh, L.kw)
                 L.slab_off = off
                 off += L.nsplit * L.cout_pad * L.taps * L.cin
+                L.gsum_off = goff                       # [nsplit][cout_pad] per-split sums of g (dbeta)
+                goff += L.nsplit * L.cout_pad
             self.slabs = torch.empty(max(off, 4), dtype=torch.float32, device=self.dev)
+            self.gsum = torch.zeros(max(goff, 4), dtype=torch.float32, device=self.dev)
             self._upload_table(layers)
             self._sig = sig
-        self.gsum.zero_()
         self.grads.zero_()
 
     def end_backward(self, layers):
@@ -107,22 +108,17 @@ class HipBackend(object):
         L.out_shape = (y.shape[0], y.shape[1], y.shape[2])
         return y
 
-    def conv_dgrad(self, L, gy, in_shape, res, mask=None, sum_layers=None):
-        """mask / sum_layers: fused ReLU backward + dbeta sums of the layer(s) that produced the tensor gx belongs to."""
+    def conv_dgrad(self, L, gy, in_shape, res, mask=None):
+        """mask: fused ReLU backward of the layer that produced the tensor gx belongs to."""
         if L.wdgrad_off < 0:
             raise H.DcfError("layer %s was planned without an input gradient" % L.name)
-        seg = None
-        if sum_layers:
-            L0 = sum_layers[0]
-            seg = self.gsum[L0.gsum_off:L0.gsum_off + L0.cout_pad]
-        gx = ops.conv2d_dgrad(self.dtype, gy, self._w(L, True), res, in_shape, L.kh, L.kw, L.stride, L.pad, mask, seg)
-        if sum_layers:
-            for Lx in sum_layers[1:]:
-                self.gsum[Lx.gsum_off:Lx.gsum_off + Lx.cout_pad].copy_(seg)
-        return gx
+        return ops.conv2d_dgrad(self.dtype, gy, self._w(L, True), res, in_shape, L.kh, L.kw, L.stride, L.pad, mask)
+
+    def _gs(self, L):
+        return self.gsum[L.gsum_off:] if L.bn is not None else None
 
     def conv_wgrad(self, L, x, gy):
-        ops.conv2d_wgrad(self.dtype, x, gy, self.slabs[L.slab_off:], L.nsplit, L.kh, L.kw, L.stride, L.pad)
+        ops.conv2d_wgrad(self.dtype, x, gy, self.slabs[L.slab_off:], L.nsplit, L.kh, L.kw, L.stride, L.pad, self._gs(L))
 
     def stem_fwd(self, L, img4, Hh, W):
         y = ops.stem7x7_fwd(self.dtype, img4, self._w(L), self._shift(L), True, L.cout_pad, Hh, W)
@@ -130,14 +126,11 @@ class HipBackend(object):
         return y
 
     def stem_wgrad(self, L, img4, gy, Hh, W):
-        ops.stem7x7_wgrad(self.dtype, img4, gy, self.slabs[L.slab_off:], L.nsplit, Hh, W)
+        ops.stem7x7_wgrad(self.dtype, img4, gy, self.slabs[L.slab_off:], L.nsplit, Hh, W, self._gs(L))
 
-    def relu_mask_sum(self, layers, g, y, relu):
-        L0 = layers[0]
-        seg = self.gsum[L0.gsum_off:L0.gsum_off + L0.cout_pad]
-        ops.relu_bwd_chansum(self.dtype, g, y, seg, relu)
-        for L in layers[1:]:
-            self.gsum[L.gsum_off:L.gsum_off + L.cout_pad].copy_(seg)
+    def relu_mask(self, g, y):
+        """g *= (y > 0) in place (the dbeta sums come out of the wgrad kernel)."""
+        ops.relu_bwd_chansum(self.dtype, g, y, None, True)
         return g
 
     # ------------------------------------------------------------------ elementwise

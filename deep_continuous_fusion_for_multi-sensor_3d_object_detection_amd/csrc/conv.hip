@@ -43,7 +43,6 @@ struct ConvArgs {
     int pixbytes;        // byte pitch between adjacent input pixels (= Ck*esize except for the stem)
     unsigned xbytes, wbytes;  // sizes of the gathered tensor and of the weight image (buffer descriptors)
     const char *mask;         // [M][Cn] or null: output *= (mask > 0)
-    float *gsum;              // [Cn] or null: += per-channel sums of the stored output
 };
 
 template <typename T> struct Mma;
@@ -211,18 +210,11 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
     }
 
     // epilogue: lane (pixel r, half h) holds channels 8q+4h+{0..3} of each 32-channel tile.
-    //   v = acc + shift + res ; relu ; (dgrad only) v *= (mask > 0) i.e. the ReLU backward of the
-    //   layer that PRODUCED this tensor, and per-channel sums of the masked gradient (its dbeta).
+    //   v = acc + shift + res ; relu ; (dgrad only) v *= (mask > 0), i.e. the ReLU backward of the
+    //   layer that PRODUCED this tensor (its dbeta sums come out of the wgrad kernel).
     T *y = reinterpret_cast<T *>(a.y);
     const T *res = reinterpret_cast<const T *>(a.res);
     const T *mask = reinterpret_cast<const T *>(a.mask);
-    float cs[TN][4][4];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) cs[i][q][e] = 0.f;
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = m0 + (wm * TM + j) * 32 + r;
@@ -249,32 +241,8 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
                     v.z = mm.z > 0.f ? v.z : 0.f; v.w = mm.w > 0.f ? v.w : 0.f;
                 }
                 st4(y + o, v);
-                if (a.gsum) {   // sum what was STORED (rounded to the compute dtype), like the standalone kernel
-                    const float4 w = DT<T>::size == 2 ? make_float4(bf2f(f2bf(v.x)), bf2f(f2bf(v.y)), bf2f(f2bf(v.z)), bf2f(f2bf(v.w))) : v;
-                    cs[i][q][0] += w.x; cs[i][q][1] += w.y; cs[i][q][2] += w.z; cs[i][q][3] += w.w;
-                }
             }
         }
-    }
-    if (a.gsum) {
-        // pixels of a wave tile sit on lanes r = 0..31: butterfly over the 5 low lane bits, then the
-        // WM waves that share these channels combine through LDS and one lane per channel adds to HBM.
-        float *sums = reinterpret_cast<float *>(lds);   // K loop is done: the staging buffer is free
-        for (int i = tid; i < BN; i += 256) sums[i] = 0.f;
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = cs[i][q][e];
-#pragma unroll
-                    for (int o = 1; o < 32; o <<= 1) x += __shfl_xor(x, o, 64);
-                    if (r == 0) atomicAdd(&sums[(wn * TN + i) * 32 + 8 * q + 4 * h + e], x);
-                }
-        __syncthreads();
-        for (int i = tid; i < BN; i += 256) atomicAdd(a.gsum + n0 + i, sums[i]);
     }
 }
 
@@ -315,6 +283,7 @@ struct WgArgs {
     const char *x;   // [B][H][W][Cin]
     const char *gy;  // [B][Ho][Wo][Cout]
     float *slabs;    // [nsplit][Cout][taps][Cin]
+    float *gsum;     // [nsplit][Cout] or null: per-split column sums of gy (= dL/dbeta of the folded BN)
     int B, H, W, Cin, Ho, Wo, Cout;
     int kh, kw, stride, pad;
     int M, nsplit, per_split;  // per_split = pixels per split (multiple of PK)
@@ -357,70 +326,72 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgArgs a)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
+    // The waves of (tap 0, ci-tile 0) also accumulate sum_p gy[p][co] from the gy fragments they hold
+    // anyway (a few VALU adds, no extra accumulator tile): dbeta falls out of the weight-gradient
+    // kernel, per split, bit-reproducibly.
+    const bool do_sum = (a.gsum != nullptr) && (tap == 0) && (cit == 0);
+    float fsum[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fsum[i] = 0.f;
+
     constexpr int CA = RA / 16, CB = RB / 16;       // 16-B chunks per row
     constexpr int NLA = PK * CA / 64, NLB = PK * CB / 64;
     const int rowA = a.Cout * ES;
     const int coutA = min(TM * 32, a.Cout - co0) * ES;  // valid bytes of this tile's rows
     const int cinB = min(TN * 32, a.Cin - ci0) * ES;
 
-    // Buffer descriptors + per-lane row state: the stage loop below does no integer division and no
-    // 64-bit address arithmetic; rows past the end / padding taps read as zero through the range check.
+    // Buffer descriptors + per-lane row state.  Lane l stages HALF of pixel row (l >> 1) of both tiles
+    // (NLA resp. NLB consecutive 16-byte chunks), so a lane carries one pixel coordinate and one byte
+    // offset per tile: the stage loop has no integer division, no 64-bit arithmetic and a handful of
+    // VALU ops per load.  Rows past the end / padding taps read as zero through the range check.
     const __amdgpu_buffer_rsrc_t srcG = __builtin_amdgcn_make_buffer_rsrc((void *)a.gy, 0, a.gbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t srcX = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
     constexpr unsigned OOB = 0xFFFFFF00u;
-    unsigned offA[NLA], offB[NLB];
-    int pA[NLA], pB[NLB], bB[NLB], ohB[NLB], owB[NLB];
-#pragma unroll
-    for (int i = 0; i < NLA; ++i) {
-        const int c = lane + i * 64;
-        const int off = (c % CA) * 16;
-        pA[i] = p_begin + c / CA;
-        offA[i] = off < coutA ? (unsigned)(co0 * ES + off) : OOB;
+    static_assert(NLA * 2 == CA && NLB * 2 == CB, "half a row per lane");
+    const int lrow = lane >> 1, lhalf = lane & 1;
+    int pcur = p_begin + lrow;                       // this lane's pixel of the current stage
+    unsigned voA = (unsigned)pcur * (unsigned)rowA + (unsigned)(co0 * ES + lhalf * NLA * 16);
+    int bB, ohB, owB;
+    {
+        const int b = pcur / (a.Ho * a.Wo);
+        const int rem = pcur - b * (a.Ho * a.Wo);
+        bB = b; ohB = rem / a.Wo; owB = rem - ohB * a.Wo;
     }
-#pragma unroll
-    for (int i = 0; i < NLB; ++i) {
-        const int c = lane + i * 64;
-        const int off = (c % CB) * 16;
-        const int p = p_begin + c / CB;
-        pB[i] = p;
-        offB[i] = off < cinB ? (unsigned)(ci0 * ES + off) : OOB;
-        const int b = p / (a.Ho * a.Wo);
-        const int rem = p - b * (a.Ho * a.Wo);
-        bB[i] = b; ohB[i] = rem / a.Wo; owB[i] = rem - ohB[i] * a.Wo;
-    }
+    const unsigned colB = (unsigned)(ci0 * ES + lhalf * NLB * 16);
+    const int tapH = ki - a.pad, tapW = kj - a.pad;
 
-    for (int p0 = p_begin; p0 < p_end; p0 += PK) {
-        uint4 ra[NLA], rb[NLB];
+    uint4 ra[NLA], rb[NLB];
+    auto load_stage = [&]() {
+        const bool live = pcur < p_end;
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
-            const bool ok = (pA[i] < p_end) && (offA[i] != OOB);
-            ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srcG, ok ? (unsigned)pA[i] * (unsigned)rowA + offA[i] : OOB, 0, 0));
-            pA[i] += PK;
+            const bool ok = live && ((lhalf * NLA + i) * 16 < coutA);
+            ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srcG, ok ? voA + i * 16 : OOB, 0, 0));
         }
+        const int ih = ohB * a.stride + tapH, iw = owB * a.stride + tapW;
+        const bool inimg = live && (ih >= 0) && (ih < a.H) && (iw >= 0) && (iw < a.W);
+        const unsigned voB = (unsigned)((bB * a.H + ih) * a.W + iw) * (unsigned)a.pixbytes + colB;
 #pragma unroll
         for (int i = 0; i < NLB; ++i) {
-            const int ih = ohB[i] * a.stride - a.pad + ki, iw = owB[i] * a.stride - a.pad + kj;
-            const bool ok = (pB[i] < p_end) && (offB[i] != OOB) && (ih >= 0) && (ih < a.H) && (iw >= 0) && (iw < a.W);
-            const unsigned vo = (unsigned)((bB[i] * a.H + ih) * a.W + iw) * (unsigned)a.pixbytes + offB[i];
-            rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srcX, ok ? vo : OOB, 0, 0));
-            pB[i] += PK;
-            owB[i] += PK;
-            while (owB[i] >= a.Wo) { owB[i] -= a.Wo; ++ohB[i]; }
-            while (ohB[i] >= a.Ho) { ohB[i] -= a.Ho; ++bB[i]; }
+            const bool ok = inimg && ((lhalf * NLB + i) * 16 < cinB);
+            rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srcX, ok ? voB + i * 16 : OOB, 0, 0));
         }
+        pcur += PK;
+        voA += (unsigned)(PK * rowA);
+        owB += PK;
+        while (owB >= a.Wo) { owB -= a.Wo; ++ohB; }
+        while (ohB >= a.Ho) { ohB -= a.Ho; ++bB; }
+    };
+    if (p_begin < p_end) load_stage();
+    for (int p0 = p_begin; p0 < p_end; p0 += PK) {
         // previous stage's LDS reads have all been consumed by MFMAs issued before this
         // point in program order of the same wave; ds ops of one wave execute in order.
 #pragma unroll
-        for (int i = 0; i < NLA; ++i) {
-            const int c = lane + i * 64;
-            *reinterpret_cast<uint4 *>(ldsA + (c / CA) * PA + (c % CA) * 16) = ra[i];
-        }
+        for (int i = 0; i < NLA; ++i) *reinterpret_cast<uint4 *>(ldsA + lrow * PA + (lhalf * NLA + i) * 16) = ra[i];
 #pragma unroll
-        for (int i = 0; i < NLB; ++i) {
-            const int c = lane + i * 64;
-            *reinterpret_cast<uint4 *>(ldsB + (c / CB) * PB + (c % CB) * 16) = rb[i];
-        }
+        for (int i = 0; i < NLB; ++i) *reinterpret_cast<uint4 *>(ldsB + lrow * PB + (lhalf * NLB + i) * 16) = rb[i];
         __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order: no s_barrier needed
+        if (p0 + PK < p_end) load_stage();  // next stage's global loads fly under this stage's MFMAs
         if constexpr (ES == 2) {
             // bf16: per K=16 step two transposed 4x16 reads per 32-channel fragment.
             // lane = 16g+4q+p: rows (pixels) kbase+8h+{q, 4+q}, columns 16(g&1)+4p..+3, h = g>>1.
@@ -451,6 +422,14 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgArgs a)
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
                                                                             acc[i][j], 0, 0, 0);
+                if (do_sum) {   // lane (channel r, half h) holds 8 of the 16 pixels of this step
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const unsigned w[4] = {fa[i].x, fa[i].y, fa[i].z, fa[i].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) fsum[i] += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xffff0000u);
+                    }
+                }
             }
         } else {
             // fp32: lane (i = lane&31, k = lane>>5) reads element [pixel 2*ks+k][channel i]
@@ -466,11 +445,23 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgArgs a)
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                if (do_sum) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fsum[i] += fa[i];
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
 
+    if (do_sum) {   // lanes r and r+32 hold the two pixel halves of channel r
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float tot = fsum[i] + __shfl_xor(fsum[i], 32, 64);
+            const int co = co0 + i * 32 + (lane & 31);
+            if (lane < 32 && co < a.Cout) a.gsum[(size_t)split * a.Cout + co] = tot;
+        }
+    }
     // slab store: acc lane l: column (ci) = l&31, rows (co) = (reg&3)+8(reg>>2)+4(l>>5)
     const int taps = a.kh * a.kw;
     float *slab = a.slabs + (size_t)split * a.Cout * taps * a.Cin;
@@ -513,7 +504,7 @@ extern "C" int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const flo
     DCF_REQUIRE((int64_t)B * H * W * Cin < (1ll << 31) * 1, "dcf_conv2d_fwd: tensor too large for 32-bit pixel index");
     ConvArgs a;
     a.x = (const char *)x; a.w = (const char *)w; a.shift = shift; a.res = (const char *)res; a.y = (char *)y;
-    a.mask = nullptr; a.gsum = nullptr;
+    a.mask = nullptr;
     a.B = B; a.Hi = H; a.Wi = W; a.Ck = Cin; a.Ho = Ho; a.Wo = Wo; a.Cn = Cout;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.relu = relu; a.M = B * Ho * Wo;
     a.pixbytes = Cin * (dtype == DCF_F32 ? 4 : 2);
@@ -524,7 +515,7 @@ extern "C" int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const flo
     return launch_igemm<bf16_t, false>(a, S(stream), "conv_fwd_bf16");
 }
 
-extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const void *res, const void *mask, float *gsum, void *gx,
+extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const void *res, const void *mask, void *gx,
                                 int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
                                 dcf_stream_t stream)
 {
@@ -534,7 +525,7 @@ extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const
     DCF_REQUIRE(gy && wt && gx, "dcf_conv2d_dgrad: null pointer");
     ConvArgs a;
     a.x = (const char *)gy; a.w = (const char *)wt; a.shift = nullptr; a.res = (const char *)res; a.y = (char *)gx;
-    a.mask = (const char *)mask; a.gsum = gsum;
+    a.mask = (const char *)mask;
     a.B = B; a.Hi = Ho; a.Wi = Wo; a.Ck = Cout; a.Ho = H; a.Wo = W; a.Cn = Cin;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.relu = 0; a.M = B * H * W;
     a.pixbytes = Cout * (dtype == DCF_F32 ? 4 : 2);
@@ -564,7 +555,7 @@ extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout,
     return (int)((want + 3) / 4 * 4);
 }
 
-extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float *slabs, int nsplit,
+extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float *slabs, float *gsum, int nsplit,
                                 int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
                                 dcf_stream_t stream)
 {
@@ -572,7 +563,7 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
     if (rc) return rc;
     DCF_REQUIRE(x && gy && slabs && nsplit > 0 && nsplit % 4 == 0, "dcf_conv2d_wgrad: bad arguments");
     WgArgs a;
-    a.x = (const char *)x; a.gy = (const char *)gy; a.slabs = slabs;
+    a.x = (const char *)x; a.gy = (const char *)gy; a.slabs = slabs; a.gsum = gsum;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
     a.M = B * Ho * Wo; a.nsplit = nsplit;
@@ -614,7 +605,7 @@ extern "C" int dcf_stem7x7_fwd(int dtype, const void *img4, const void *w, const
     DCF_REQUIRE(Ho == (H + 6 - 7) / 2 + 1 && Wo == (W + 6 - 7) / 2 + 1, "dcf_stem7x7_fwd: output size mismatch");
     ConvArgs a;
     a.x = (const char *)img4; a.w = (const char *)w; a.shift = shift; a.res = nullptr; a.y = (char *)y;
-    a.mask = nullptr; a.gsum = nullptr;
+    a.mask = nullptr;
     a.B = B; a.Hi = H + 6; a.Wi = W + 8; a.Ck = 32; a.Ho = Ho; a.Wo = Wo; a.Cn = Cout;
     a.kh = 7; a.kw = 1; a.stride = 2; a.pad = 0; a.relu = relu; a.M = B * Ho * Wo;
     a.pixbytes = 4 * (dtype == DCF_F32 ? 4 : 2);
@@ -624,12 +615,12 @@ extern "C" int dcf_stem7x7_fwd(int dtype, const void *img4, const void *w, const
     return launch_igemm<bf16_t, false>(a, S(stream), "stem_fwd_bf16");
 }
 
-extern "C" int dcf_stem7x7_wgrad(int dtype, const void *img4, const void *gy, float *slabs, int nsplit,
+extern "C" int dcf_stem7x7_wgrad(int dtype, const void *img4, const void *gy, float *slabs, float *gsum, int nsplit,
                                  int B, int H, int W, int Ho, int Wo, int Cout, dcf_stream_t stream)
 {
     DCF_REQUIRE(img4 && gy && slabs && nsplit > 0 && nsplit % 4 == 0 && Cout % 32 == 0, "dcf_stem7x7_wgrad: bad arguments");
     WgArgs a;
-    a.x = (const char *)img4; a.gy = (const char *)gy; a.slabs = slabs;
+    a.x = (const char *)img4; a.gy = (const char *)gy; a.slabs = slabs; a.gsum = gsum;
     a.B = B; a.H = H + 6; a.W = W + 8; a.Cin = 32; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
     a.kh = 7; a.kw = 1; a.stride = 2; a.pad = 0;
     a.M = B * Ho * Wo; a.nsplit = nsplit;

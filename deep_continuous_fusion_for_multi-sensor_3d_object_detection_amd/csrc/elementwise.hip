@@ -89,7 +89,8 @@ __global__ void __launch_bounds__(256) k_relu_bwd_chansum(T *gy, const T *y, flo
         atomicAdd(&sm[cg * 4 + 3], acc.w);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < cgroups * 4; i += blockDim.x) atomicAdd(&gsum[i], sm[i]);
+    if (gsum)
+        for (int i = threadIdx.x; i < cgroups * 4; i += blockDim.x) atomicAdd(&gsum[i], sm[i]);
 }
 
 // ------------------------------------------------------------------------------------
@@ -374,33 +375,55 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_weight_prep(const dcf_conv_param *table, const float *params, const float *buffers, char *warena,
                                                      float *ssarena, float eps)
 {
+    // 32(co) x 32(ci) tiles per tap: coalesced 128-B reads of the fp32 master weights, coalesced
+    // 64/128-B writes of both images (the dgrad image goes through an LDS transpose).
+    __shared__ float tile[32][33];
     const dcf_conv_param d = table[blockIdx.y];
     const int K = d.taps * d.cin;
-    const int64_t total = (int64_t)d.cout_pad * K;
+    const int cot = d.cout_pad / 32, cit = d.cin / 32;
+    const int ntiles = d.taps * cot * cit;
     T *wf = reinterpret_cast<T *>(warena + d.wfwd_off);
     T *wd = d.wdgrad_off >= 0 ? reinterpret_cast<T *>(warena + d.wdgrad_off) : nullptr;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int co = (int)(e / K);
-        const int k = (int)(e - (int64_t)co * K);
-        float v = 0.f;
-        if (co < d.cout) {
-            float scale = 1.f;
-            if (d.gamma_off >= 0) scale = params[d.gamma_off + co] * rsqrtf(buffers[d.var_off + co] + eps);
-            v = params[d.w_off + e] * scale;
-            if (k == 0) {
-                float shift = 0.f;
-                if (d.gamma_off >= 0) shift = params[d.beta_off + co] - buffers[d.mean_off + co] * scale;
-                ssarena[d.shift_off + co] = scale;
-                ssarena[d.shift_off + d.cout_pad + co] = shift;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tap = t % d.taps;
+        const int r = t / d.taps;
+        const int c0 = (r % cit) * 32, o0 = (r / cit) * 32;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int co = o0 + ty + 8 * k, ci = c0 + tx;
+            float v = 0.f;
+            if (co < d.cout) {
+                float scale = 1.f;
+                if (d.gamma_off >= 0) scale = params[d.gamma_off + co] * rsqrtf(buffers[d.var_off + co] + eps);
+                v = params[d.w_off + (int64_t)co * K + tap * d.cin + ci] * scale;
             }
-        } else if (k == 0) {
-            ssarena[d.shift_off + co] = 0.f;
-            ssarena[d.shift_off + d.cout_pad + co] = 0.f;
+            DT<T>::st(wf + (int64_t)co * K + tap * d.cin + ci, v);
+            tile[ty + 8 * k][tx] = v;
         }
-        DT<T>::st(wf + e, v);
+        __syncthreads();
         if (wd) {
-            const int tap = k / d.cin, ci = k - tap * d.cin;
-            DT<T>::st(wd + ((int64_t)ci * d.taps + tap) * d.cout_pad + co, v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ci = c0 + ty + 8 * k, co = o0 + tx;
+                DT<T>::st(wd + ((int64_t)ci * d.taps + tap) * d.cout_pad + co, tile[tx][ty + 8 * k]);
+            }
+        }
+        __syncthreads();
+    }
+    // scale | shift (one thread per output channel, first block of the conv)
+    if (blockIdx.x == 0) {
+        for (int co = threadIdx.x; co < d.cout_pad; co += blockDim.x) {
+            float scale = 0.f, shift = 0.f;
+            if (co < d.cout) {
+                scale = 1.f;
+                if (d.gamma_off >= 0) {
+                    scale = params[d.gamma_off + co] * rsqrtf(buffers[d.var_off + co] + eps);
+                    shift = params[d.beta_off + co] - buffers[d.mean_off + co] * scale;
+                }
+            }
+            ssarena[d.shift_off + co] = scale;
+            ssarena[d.shift_off + d.cout_pad + co] = shift;
         }
     }
 }
@@ -420,9 +443,16 @@ __global__ void __launch_bounds__(256) k_wgrad_finalize(const dcf_conv_param *ta
     float dot = 0.f;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         const int64_t e = (int64_t)co * K + k;
-        float G = 0.f;
+        // fixed-order reduction with 8 loads in flight (nsplit is a multiple of 4)
         const float *sp = slabs + d.slab_off + e;
-        for (int s = 0; s < d.nsplit; ++s) G += sp[(int64_t)s * slab_elems];
+        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int sidx = 0;
+        for (; sidx + 8 <= d.nsplit; sidx += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) part[u] += sp[(int64_t)(sidx + u) * slab_elems];
+        }
+        for (; sidx < d.nsplit; ++sidx) part[sidx & 7] += sp[(int64_t)sidx * slab_elems];
+        float G = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
         // stem weights are stored [Cout][7][8][4]: tap kw=7 and channel 3 are structural zeros
         if ((d.flags & 1) && ((((k & 31) >> 2) == 7) || ((k & 3) == 3))) G = 0.f;
         grads[d.w_off + e] = d.gamma_off >= 0 ? scale * G : G;
@@ -435,7 +465,8 @@ __global__ void __launch_bounds__(256) k_wgrad_finalize(const dcf_conv_param *ta
     __syncthreads();
     if (threadIdx.x == 0) {
         const float tot = red[0] + red[1] + red[2] + red[3];
-        const float dbeta = gsum[d.gsum_off + co];
+        float dbeta = 0.f;
+        for (int sp = 0; sp < d.nsplit; ++sp) dbeta += gsum[d.gsum_off + (int64_t)sp * d.cout_pad + co];
         const float invstd = rsqrtf(buffers[d.var_off + co] + eps);
         grads[d.beta_off + co] = dbeta;
         grads[d.gamma_off + co] = (tot - buffers[d.mean_off + co] * dbeta) * invstd;
@@ -553,7 +584,7 @@ static inline int64_t chan_stride(int64_t nvec, int cgroups, int &blocks)
 extern "C" int dcf_relu_bwd_chansum(int dtype, void *gy, const void *y, float *gsum, int64_t npix, int C, int relu,
                                     dcf_stream_t stream)
 {
-    DCF_REQUIRE(gy && gsum && C % 4 == 0 && (!relu || y), "dcf_relu_bwd_chansum: bad arguments");
+    DCF_REQUIRE(gy && C % 4 == 0 && (!relu || y), "dcf_relu_bwd_chansum: bad arguments");
     const int cg = C / 4;
     const int64_t nvec = npix * cg;
     if (nvec == 0) return DCF_OK;
@@ -642,7 +673,7 @@ extern "C" int dcf_weight_prep(int dtype, const dcf_conv_param *table, int nconv
 {
     DCF_REQUIRE(table && nconv > 0 && params && warena && ssarena, "dcf_weight_prep: bad arguments");
     hipStream_t s = S(stream);
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("weight_prep", s, hipLaunchKernelGGL(k_weight_prep<T>, dim3(64, nconv), dim3(256), 0, s, table, params, buffers, (char *)warena, ssarena, eps)); })
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("weight_prep", s, hipLaunchKernelGGL(k_weight_prep<T>, dim3(96, nconv), dim3(256), 0, s, table, params, buffers, (char *)warena, ssarena, eps)); })
     return DCF_OK;
 }
 

@@ -102,27 +102,26 @@ class Block(object):
 
     def backward(self, K, g, extra=None, need_gx=True, g_masked=False, prev=None):
         """g = dL/dy (consumed / overwritten).  extra = gradient reaching x from other consumers.
-        g_masked: the producer of g already applied this block's output ReLU mask and dbeta sums.
-        prev: the Block whose output is this block's input x -- its ReLU backward (mask by x, dbeta
-        sums) is then fused into the epilogue of the dgrad that produces gx."""
+        g_masked: the producer of g already applied this block's output ReLU mask.
+        prev: the Block whose output is this block's input x -- its ReLU backward (mask by x) is then
+        fused into the epilogue of the dgrad that produces gx."""
         x, y1, y = self.saved
         self.saved = None
-        g2 = g if g_masked else K.relu_mask_sum(self.sum_layers(), g, y, True)
-        K.conv_wgrad(self.conv2, y1, g2)
-        g1 = K.conv_dgrad(self.conv2, g2, tuple(y1.shape), None, y1, [self.conv1])   # fused mask(y1) + dbeta(bn1)
+        g2 = g if g_masked else K.relu_mask(g, y)
+        K.conv_wgrad(self.conv2, y1, g2)                                              # also dbeta(bn2) = sum g2
+        g1 = K.conv_dgrad(self.conv2, g2, tuple(y1.shape), None, y1)                  # fused ReLU mask of y1
         K.conv_wgrad(self.conv1, x, g1)
         pm = x if prev is not None else None
-        ps = prev.sum_layers() if prev is not None else None
         if self.down is not None:
             K.conv_wgrad(self.down, x, g2)
             if not need_gx:
                 return None
             gx = K.conv_dgrad(self.down, g2, tuple(x.shape), extra)
-            return K.conv_dgrad(self.conv1, g1, tuple(x.shape), gx, pm, ps)
+            return K.conv_dgrad(self.conv1, g1, tuple(x.shape), gx, pm)
         if not need_gx:
             return None
         assert extra is None, "an identity-shortcut block cannot take an extra gradient"
-        return K.conv_dgrad(self.conv1, g1, tuple(x.shape), g2, pm, ps)
+        return K.conv_dgrad(self.conv1, g1, tuple(x.shape), g2, pm)
 
 
 class Plan(object):
@@ -141,6 +140,8 @@ class Plan(object):
             raise ValueError("voxel_channel must equal out_feature1 (model.py:67)")
         if cfg["voxel_length"] % 16 or cfg["voxel_width"] % 16:
             raise ValueError("voxel_length and voxel_width must be multiples of 16 (FPN add, model.py:151)")
+        if any(w % 32 for w in self.widths) or cf % 32:
+            raise ValueError("channel counts must be multiples of 32 (MFMA 32x32 tiles; dcf_weight_prep works on 32x32 weight tiles)")
         if len(set(self.widths)) != 5:
             raise ValueError("stage widths must differ (a stage strides only when its width changes, model.py:43-45)")
         self._build_lidar()
@@ -371,7 +372,7 @@ class Plan(object):
                 masked = prev is not None
         # g = gradient at the max-pool output
         gc1 = K.maxpool_bwd(im["c1"], g)
-        gc1 = K.relu_mask_sum([self.stem], gc1, im["c1"], True)
+        gc1 = K.relu_mask(gc1, im["c1"])
         K.stem_wgrad(self.stem, im["img4"], gc1, im["hw"][0], im["hw"][1])
 
     # ------------------------------------------------------------------ fusion

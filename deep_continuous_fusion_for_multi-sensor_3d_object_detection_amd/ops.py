@@ -48,11 +48,11 @@ def conv2d_fwd(dtype, x, w, shift, res, kh, kw, stride, pad, relu, cout):
     return y
 
 
-def conv2d_dgrad(dtype, gy, wt, res, in_shape, kh, kw, stride, pad, mask=None, gsum=None):
+def conv2d_dgrad(dtype, gy, wt, res, in_shape, kh, kw, stride, pad, mask=None):
     B, Hh, W, Cin = in_shape
     _, Ho, Wo, Cout = gy.shape
     gx = torch.empty((B, Hh, W, Cin), dtype=gy.dtype, device=gy.device)
-    H.call("dcf_conv2d_dgrad", dtype, gy, wt, res, mask, gsum, gx, B, Hh, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, H.stream_ptr())
+    H.call("dcf_conv2d_dgrad", dtype, gy, wt, res, mask, gx, B, Hh, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, H.stream_ptr())
     return gx
 
 
@@ -60,10 +60,10 @@ def conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, kh, kw):
     return H.lib().dcf_conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, kh, kw)
 
 
-def conv2d_wgrad(dtype, x, gy, slabs, nsplit, kh, kw, stride, pad):
+def conv2d_wgrad(dtype, x, gy, slabs, nsplit, kh, kw, stride, pad, gsum=None):
     B, Hh, W, Cin = x.shape
     _, Ho, Wo, Cout = gy.shape
-    H.call("dcf_conv2d_wgrad", dtype, x, gy, slabs, nsplit, B, Hh, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, H.stream_ptr())
+    H.call("dcf_conv2d_wgrad", dtype, x, gy, slabs, gsum, nsplit, B, Hh, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, H.stream_ptr())
     return slabs
 
 
@@ -75,9 +75,9 @@ def stem7x7_fwd(dtype, img4, w, shift, relu, cout, Hh, W):
     return y
 
 
-def stem7x7_wgrad(dtype, img4, gy, slabs, nsplit, Hh, W):
+def stem7x7_wgrad(dtype, img4, gy, slabs, nsplit, Hh, W, gsum=None):
     B, Ho, Wo, Cout = gy.shape
-    H.call("dcf_stem7x7_wgrad", dtype, img4, gy, slabs, nsplit, B, Hh, W, Ho, Wo, Cout, H.stream_ptr())
+    H.call("dcf_stem7x7_wgrad", dtype, img4, gy, slabs, gsum, nsplit, B, Hh, W, Ho, Wo, Cout, H.stream_ptr())
     return slabs
 
 

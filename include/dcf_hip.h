@@ -97,27 +97,29 @@ int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const float *shift, 
 /* Input gradient: gx [B,H,W,Cin] = conv_transpose(gy [B,Ho,Wo,Cout], wt) (+ res).
  * wt [Cin][kh][kw][Cout] (dtype) as produced by dcf_weight_prep.
  * Optional fused ReLU backward of the layer that produced x: mask (dtype, like gx) zeroes gx where
- * mask <= 0, and gsum fp32 [Cin] += per-channel sums of the stored gx (that layer's dL/dbeta). */
-int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const void *res, const void *mask, float *gsum, void *gx,
+ * mask <= 0. */
+int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const void *res, const void *mask, void *gx,
                      int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
                      dcf_stream_t stream);
 /* Weight gradient, split over pixel ranges: slabs fp32 [nsplit][Cout][kh][kw][Cin] (plain stores,
  * reduced in fixed order by dcf_wgrad_finalize => bitwise reproducible).
+ * gsum (optional) fp32 [nsplit][Cout]: per-split sums over pixels of gy (dL/dbeta of a folded BN),
+ * accumulated by the same kernel from the gy fragments it already holds.
  * nsplit = dcf_conv2d_wgrad_splits(...). */
 int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw);
-int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float *slabs, int nsplit,
+int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float *slabs, float *gsum, int nsplit,
                      int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
                      dcf_stream_t stream);
 /* The 7x7/2 RGB stem of the image stream on the NHWC4+halo image. */
 int dcf_stem7x7_fwd(int dtype, const void *img4, const void *w, const float *shift, void *y,
                     int B, int H, int W, int Ho, int Wo, int Cout, int relu, dcf_stream_t stream);
-int dcf_stem7x7_wgrad(int dtype, const void *img4, const void *gy, float *slabs, int nsplit,
+int dcf_stem7x7_wgrad(int dtype, const void *img4, const void *gy, float *slabs, float *gsum, int nsplit,
                       int B, int H, int W, int Ho, int Wo, int Cout, dcf_stream_t stream);
 
 /* Per-step parameter preparation (table driven, one launch for the whole net):
  * for conv i: scale = gamma*rsqrt(var+eps) (or 1), shift = beta - mean*scale (or 0),
  * w_fwd = cast(scale[co]*W), w_dgrad = transpose of the same.  Descriptor table lives on
- * the device (struct dcf_conv_param, below). */
+ * the device (struct dcf_conv_param, below).  cin and cout_pad must be multiples of 32. */
 typedef struct dcf_conv_param {
     int64_t w_off;      /* element offset of W [Cout][taps][Cin] fp32 in the parameter arena */
     int64_t gamma_off;  /* BN gamma/beta offsets in the parameter arena, -1 = no BN            */
@@ -128,14 +130,14 @@ typedef struct dcf_conv_param {
     int64_t wdgrad_off; /* -1 = not needed                                                      */
     int64_t shift_off;  /* element offset into the fp32 scale/shift arena: [scale Cout][shift Cout] */
     int64_t slab_off;   /* element offset of this conv's wgrad slabs in the slab arena         */
-    int64_t gsum_off;   /* element offset of this conv's per-channel sum(g) in the gsum arena */
+    int64_t gsum_off;   /* element offset of this conv's [nsplit][cout_pad] sums of g in the gsum arena */
     int32_t cout, cin, taps, cout_pad;
     int32_t nsplit, flags, pad0, pad1;
 } dcf_conv_param;
 int dcf_weight_prep(int dtype, const dcf_conv_param *table, int nconv, const float *params, const float *buffers,
                     void *warena, float *ssarena, float eps, dcf_stream_t stream);
 /* Reduce wgrad slabs in split order and apply the folded-BN chain rule:
- * dW = scale*G, dgamma = (<W,G> - mean*dbeta)*invstd, dbeta = sum g (from gsum arena). */
+ * dW = scale*G, dgamma = (<W,G> - mean*dbeta)*invstd, dbeta = sum over splits of gsum[split][co]. */
 int dcf_wgrad_finalize(const dcf_conv_param *table, int nconv, const float *params, const float *buffers,
                        const float *ssarena, const float *slabs, const float *gsum, float *grads, float eps,
                        dcf_stream_t stream);
