@@ -28,7 +28,8 @@ SIGNATURES = {
     "dcf_version": (c_int, []),
     "dcf_prof_enable": (c_int, [c_int]),
     "dcf_prof_reset": (c_int, []),
-    "dcf_prof_read": (c_int, [P, P, P, c_int]),
+    "dcf_prof_calibrate": (c_int, [P, c_int]),
+    "dcf_prof_read": (c_int, [P, P, P, P, c_int]),
     "dcf_compact_workspace_bytes": (c_size_t, [c_int]),
     "dcf_range_filter": (c_int, [P, c_int, P, P, P, P, P, P]),
     "dcf_voxelize_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -147,9 +148,11 @@ def prof_read(cap=256):
     names = ctypes.create_string_buffer(cap * 64)
     tot = (ctypes.c_double * cap)()
     cnt = (ctypes.c_int64 * cap)()
-    k = lib().dcf_prof_read(ctypes.cast(names, c_void_p), ctypes.cast(tot, c_void_p), ctypes.cast(cnt, c_void_p), cap)
+    wk = (ctypes.c_double * cap)()
+    k = lib().dcf_prof_read(ctypes.cast(names, c_void_p), ctypes.cast(tot, c_void_p), ctypes.cast(cnt, c_void_p),
+                            ctypes.cast(wk, c_void_p), cap)
     out = {}
     for i in range(k):
         nm = names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode()
-        out[nm] = (tot[i], cnt[i])
+        out[nm] = (tot[i], cnt[i], wk[i])       # (total ms, launches, algorithmic flops)
     return out

@@ -247,8 +247,9 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
 }
 
 template <typename T, bool TR>
-int launch_igemm(const ConvArgs &a, hipStream_t s, const char *name)
+int launch_igemm(const ConvArgs &a, hipStream_t s, const char *base, double flops)
 {
+    char name[64];
     constexpr int ES = DT<T>::size;
     const int rowbytes = a.Ck * ES;
     const bool kb128 = (rowbytes % 128) == 0;
@@ -256,7 +257,8 @@ int launch_igemm(const ConvArgs &a, hipStream_t s, const char *name)
     do {                                                                                                            \
         constexpr int BN_ = WN_ * TN_ * 32, BM_ = WM_ * TM_ * 32;                                                   \
         dim3 grid(cdiv(a.M, BM_), a.Cn / BN_);                                                                      \
-        DCF_LAUNCH(name, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR>), grid, dim3(256), 0, s, a)); \
+        snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d>", base, KB_, TN_, TM_, WN_, WM_);                           \
+        DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR>), grid, dim3(256), 0, s, a)); \
         return DCF_OK;                                                                                              \
     } while (0)
     // tile choice: the biggest tile that still gives the chip >= ~2 workgroups per CU
@@ -511,8 +513,9 @@ extern "C" int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const flo
     DCF_REQUIRE((int64_t)B * H * W * a.pixbytes < 0xFFFFFF00ll, "dcf_conv2d_fwd: tensor exceeds the 4 GiB buffer-descriptor range");
     a.xbytes = (unsigned)((int64_t)B * H * W * a.pixbytes);
     a.wbytes = (unsigned)((int64_t)Cout * kh * kw * a.pixbytes);
-    if (dtype == DCF_F32) return launch_igemm<float, false>(a, S(stream), "conv_fwd_f32");
-    return launch_igemm<bf16_t, false>(a, S(stream), "conv_fwd_bf16");
+    const double flops = 2.0 * a.M * Cout * (double)Cin * kh * kw;
+    if (dtype == DCF_F32) return launch_igemm<float, false>(a, S(stream), "conv_fwd_f32", flops);
+    return launch_igemm<bf16_t, false>(a, S(stream), "conv_fwd_bf16", flops);
 }
 
 extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const void *res, const void *mask, void *gx,
@@ -532,8 +535,9 @@ extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const
     DCF_REQUIRE((int64_t)B * Ho * Wo * a.pixbytes < 0xFFFFFF00ll, "dcf_conv2d_dgrad: tensor exceeds the 4 GiB buffer-descriptor range");
     a.xbytes = (unsigned)((int64_t)B * Ho * Wo * a.pixbytes);
     a.wbytes = (unsigned)((int64_t)Cin * kh * kw * a.pixbytes);
-    if (dtype == DCF_F32) return launch_igemm<float, true>(a, S(stream), "conv_dgrad_f32");
-    return launch_igemm<bf16_t, true>(a, S(stream), "conv_dgrad_bf16");
+    const double flops = 2.0 * B * Ho * Wo * Cout * (double)Cin * kh * kw;   // algorithmic (= the forward conv's)
+    if (dtype == DCF_F32) return launch_igemm<float, true>(a, S(stream), "conv_dgrad_f32", flops);
+    return launch_igemm<bf16_t, true>(a, S(stream), "conv_dgrad_bf16", flops);
 }
 
 static void wgrad_tiles(int Cin, int Cout, int &TM, int &TN) { TM = Cout >= 64 ? 2 : 1; TN = Cin >= 64 ? 2 : 1; }
@@ -578,12 +582,13 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
     a.ci_tiles = cdiv(Cin, TN * 32);
     dim3 grid(a.co_tiles * a.ci_tiles * kh * kw, nsplit / 4);
     hipStream_t s = S(stream);
-#define DCF_WG(T_, NAME_)                                                                                                      \
-    do {                                                                                                                       \
-        if (TM == 2 && TN == 2) DCF_LAUNCH(NAME_, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 2, 2>), grid, dim3(256), 0, s, a));   \
-        else if (TM == 2) DCF_LAUNCH(NAME_, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 2, 1>), grid, dim3(256), 0, s, a));         \
-        else if (TN == 2) DCF_LAUNCH(NAME_, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 1, 2>), grid, dim3(256), 0, s, a));         \
-        else DCF_LAUNCH(NAME_, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 1, 1>), grid, dim3(256), 0, s, a));                      \
+    const double flops = 2.0 * a.M * Cout * (double)Cin * kh * kw;
+#define DCF_WG(T_, NAME_)                                                                                                                       \
+    do {                                                                                                                                        \
+        if (TM == 2 && TN == 2) DCF_LAUNCH_W(NAME_ "<2,2>", flops, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 2, 2>), grid, dim3(256), 0, s, a));   \
+        else if (TM == 2) DCF_LAUNCH_W(NAME_ "<2,1>", flops, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 2, 1>), grid, dim3(256), 0, s, a));         \
+        else if (TN == 2) DCF_LAUNCH_W(NAME_ "<1,2>", flops, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 1, 2>), grid, dim3(256), 0, s, a));         \
+        else DCF_LAUNCH_W(NAME_ "<1,1>", flops, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 1, 1>), grid, dim3(256), 0, s, a));                      \
     } while (0)
     if (dtype == DCF_F32) DCF_WG(float, "conv_wgrad_f32"); else DCF_WG(bf16_t, "conv_wgrad_bf16");
 #undef DCF_WG
@@ -611,8 +616,9 @@ extern "C" int dcf_stem7x7_fwd(int dtype, const void *img4, const void *w, const
     a.pixbytes = 4 * (dtype == DCF_F32 ? 4 : 2);
     a.xbytes = (unsigned)((int64_t)B * (H + 6) * (W + 8) * a.pixbytes);
     a.wbytes = (unsigned)((int64_t)Cout * 7 * 32 * (dtype == DCF_F32 ? 4 : 2));
-    if (dtype == DCF_F32) return launch_igemm<float, false>(a, S(stream), "stem_fwd_f32");
-    return launch_igemm<bf16_t, false>(a, S(stream), "stem_fwd_bf16");
+    const double flops = 2.0 * a.M * Cout * 147.0;   // 7x7x3 taps (the padded K of 224 is not algorithmic work)
+    if (dtype == DCF_F32) return launch_igemm<float, false>(a, S(stream), "stem_fwd_f32", flops);
+    return launch_igemm<bf16_t, false>(a, S(stream), "stem_fwd_bf16", flops);
 }
 
 extern "C" int dcf_stem7x7_wgrad(int dtype, const void *img4, const void *gy, float *slabs, float *gsum, int nsplit,
@@ -633,12 +639,13 @@ extern "C" int dcf_stem7x7_wgrad(int dtype, const void *img4, const void *gy, fl
     a.ci_tiles = 1;
     dim3 grid(a.co_tiles * 7, nsplit / 4);
     hipStream_t s = S(stream);
+    const double sflops = 2.0 * a.M * Cout * 147.0;
     if (dtype == DCF_F32) {
-        if (TM == 2) DCF_LAUNCH("stem_wgrad_f32", s, hipLaunchKernelGGL((k_conv_wgrad<float, 2, 1>), grid, dim3(256), 0, s, a));
-        else DCF_LAUNCH("stem_wgrad_f32", s, hipLaunchKernelGGL((k_conv_wgrad<float, 1, 1>), grid, dim3(256), 0, s, a));
+        if (TM == 2) DCF_LAUNCH_W("stem_wgrad_f32", sflops, s, hipLaunchKernelGGL((k_conv_wgrad<float, 2, 1>), grid, dim3(256), 0, s, a));
+        else DCF_LAUNCH_W("stem_wgrad_f32", sflops, s, hipLaunchKernelGGL((k_conv_wgrad<float, 1, 1>), grid, dim3(256), 0, s, a));
     } else {
-        if (TM == 2) DCF_LAUNCH("stem_wgrad_bf16", s, hipLaunchKernelGGL((k_conv_wgrad<bf16_t, 2, 1>), grid, dim3(256), 0, s, a));
-        else DCF_LAUNCH("stem_wgrad_bf16", s, hipLaunchKernelGGL((k_conv_wgrad<bf16_t, 1, 1>), grid, dim3(256), 0, s, a));
+        if (TM == 2) DCF_LAUNCH_W("stem_wgrad_bf16", sflops, s, hipLaunchKernelGGL((k_conv_wgrad<bf16_t, 2, 1>), grid, dim3(256), 0, s, a));
+        else DCF_LAUNCH_W("stem_wgrad_bf16", sflops, s, hipLaunchKernelGGL((k_conv_wgrad<bf16_t, 1, 1>), grid, dim3(256), 0, s, a));
     }
     return DCF_OK;
 }

@@ -30,13 +30,16 @@ void dcf_set_error(const char *fmt, ...);
 // ---------------------------------------------------------------- launch + profiling
 // Every kernel launch goes through DCF_LAUNCH so that the optional event timing
 // (dcf_prof_enable) brackets it on the stream it is launched on.
-void dcf_prof_begin(const char *name, hipStream_t s);
+void dcf_prof_begin(const char *name, hipStream_t s, double work = 0.0);
 void dcf_prof_end(hipStream_t s);
 extern int g_dcf_prof_on;
 
-#define DCF_LAUNCH(name, stream, ...)                                               \
+#define DCF_LAUNCH(name, stream, ...) DCF_LAUNCH_W(name, 0.0, stream, __VA_ARGS__)
+
+// same, with the launch's ALGORITHMIC work (flops or bytes) recorded next to its time
+#define DCF_LAUNCH_W(name, work, stream, ...)                                       \
     do {                                                                            \
-        if (g_dcf_prof_on) dcf_prof_begin(name, stream);                            \
+        if (g_dcf_prof_on) dcf_prof_begin(name, stream, work);                      \
         __VA_ARGS__;                                                                \
         if (g_dcf_prof_on) dcf_prof_end(stream);                                    \
         hipError_t e__ = hipGetLastError();                                         \

@@ -40,8 +40,12 @@ int dcf_version(void);
 /* Optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg). */
 int dcf_prof_enable(int on);
 int dcf_prof_reset(void);
-/* Fills up to `cap` records; returns the number of kernel classes seen. HOST pointers. */
-int dcf_prof_read(char *names /*[cap][64]*/, double *total_ms, int64_t *calls, int cap);
+/* Records n empty brackets named "__empty_bracket__": the per-launch cost of the event pair itself. */
+int dcf_prof_calibrate(dcf_stream_t stream, int n);
+/* Fills up to `cap` records (one per kernel name = template instantiation); `work` receives the summed
+ * ALGORITHMIC flops the launches declared (0 for kernels priced in bytes). Returns the number of
+ * records. HOST pointers. */
+int dcf_prof_read(char *names /*[cap][64]*/, double *total_ms, int64_t *calls, double *work, int cap);
 
 /* ------------------------------------------------------------------ geometry
  * Replaces CarlaDataset.Voxelization_Projection / Projection
