@@ -90,8 +90,8 @@ class HipBackend(object):
                 L.nsplit = ops.conv2d_wgrad_splits(B, Ho, Wo, L.cin, L.cout_pad, L.kh, L.kw)
                 L.slab_off = off
                 off += L.nsplit * L.cout_pad * L.taps * L.cin
-                L.gsum_off = goff                       # [nsplit][cout_pad] per-split sums of g (dbeta)
-                goff += L.nsplit * L.cout_pad
+                L.gsum_off = goff                       # [4*nsplit][cout_pad] per-wave sums of g (dbeta)
+                goff += 4 * L.nsplit * L.cout_pad
             self.slabs = torch.empty(max(off, 4), dtype=torch.float32, device=self.dev)
             self.gsum = torch.zeros(max(goff, 4), dtype=torch.float32, device=self.dev)
             self._upload_table(layers)

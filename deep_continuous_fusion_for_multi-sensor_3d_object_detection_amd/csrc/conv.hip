@@ -464,9 +464,51 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgArgs a)
             if (lane < 32 && co < a.Cout) a.gsum[(size_t)split * a.Cout + co] = tot;
         }
     }
+    // Block-level reduction of the 4 waves' partial tiles through LDS in a fixed order
+    // ((w0 + w2) + (w1 + w3)): one slab per BLOCK, so 4x more waves hide latency per slab byte.
+    {
+        float *red = reinterpret_cast<float *>(lds_all);
+        constexpr int TILE = TM * TN * 16 * 64;   // floats of one wave's accumulator tile
+        static_assert(2 * TILE * 4 <= 4 * WAVE_LDS, "two accumulator tiles must fit the block's LDS");
+        __syncthreads();                          // every wave is done with its staging region
+        if (wid >= 2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) red[(wid - 2) * TILE + ((i * TN + j) * 16 + q) * 64 + lane] = acc[i][j][q];
+        }
+        __syncthreads();
+        if (wid < 2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[i][j][q] += red[wid * TILE + ((i * TN + j) * 16 + q) * 64 + lane];
+        }
+        __syncthreads();
+        if (wid == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) red[((i * TN + j) * 16 + q) * 64 + lane] = acc[i][j][q];
+        }
+        __syncthreads();
+        if (wid != 0) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][j][q] += red[((i * TN + j) * 16 + q) * 64 + lane];
+    }
     // slab store: acc lane l: column (ci) = l&31, rows (co) = (reg&3)+8(reg>>2)+4(l>>5)
     const int taps = a.kh * a.kw;
-    float *slab = a.slabs + (size_t)split * a.Cout * taps * a.Cin;
+    float *slab = a.slabs + (size_t)blockIdx.y * a.Cout * taps * a.Cin;
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -548,15 +590,16 @@ extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout,
     wgrad_tiles(Cin, Cout, TM, TN);
     const int tiles = cdiv(Cout, TM * 32) * cdiv(Cin, TN * 32) * kh * kw;
     const int64_t M = (int64_t)B * Ho * Wo;
-    int64_t want = cdiv(2048, tiles);                 // ~8 waves per CU in total
-    int64_t maxs = (M + 255) / 256;                   // at least 8 stages of 32 pixels per split
+    // nsplit = number of SLABS = workgroups along the pixel axis; each has 4 waves (own pixel ranges)
+    int64_t want = cdiv(1024, tiles);                 // ~16 waves per CU in total
+    int64_t maxs = (M + 511) / 512;                   // at least 4 stages of 32 pixels per wave
     if (want > maxs) want = maxs;
     // keep each layer's slab arena small: it is written once and re-read by dcf_wgrad_finalize
     const int64_t slab_bytes = (int64_t)cdiv(Cout, 32) * 32 * kh * kw * Cin * 4;
     const int64_t cap = (16ll << 20) / slab_bytes;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
-    return (int)((want + 3) / 4 * 4);
+    return (int)want;
 }
 
 extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float *slabs, float *gsum, int nsplit,
@@ -565,7 +608,7 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
 {
     int rc = check_conv("dcf_conv2d_wgrad", dtype, Cin, Cout, kh, kw, stride);
     if (rc) return rc;
-    DCF_REQUIRE(x && gy && slabs && nsplit > 0 && nsplit % 4 == 0, "dcf_conv2d_wgrad: bad arguments");
+    DCF_REQUIRE(x && gy && slabs && nsplit > 0, "dcf_conv2d_wgrad: bad arguments");
     WgArgs a;
     a.x = (const char *)x; a.gy = (const char *)gy; a.slabs = slabs; a.gsum = gsum;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
@@ -575,12 +618,12 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
     DCF_REQUIRE((int64_t)B * H * W * a.pixbytes < 0xFFFFFF00ll && (int64_t)a.M * Cout * 4 < 0xFFFFFF00ll, "dcf_conv2d_wgrad: tensor exceeds the 4 GiB buffer-descriptor range");
     a.xbytes = (unsigned)((int64_t)B * H * W * a.pixbytes);
     a.gbytes = (unsigned)((int64_t)a.M * Cout * (dtype == DCF_F32 ? 4 : 2));
-    a.per_split = cdiv(cdiv(a.M, nsplit), 32) * 32;
+    a.per_split = cdiv(cdiv(a.M, 4 * nsplit), 32) * 32;   // pixels per WAVE (4 waves reduce into one slab)
     int TM, TN;
     wgrad_tiles(Cin, Cout, TM, TN);
     a.co_tiles = cdiv(Cout, TM * 32);
     a.ci_tiles = cdiv(Cin, TN * 32);
-    dim3 grid(a.co_tiles * a.ci_tiles * kh * kw, nsplit / 4);
+    dim3 grid(a.co_tiles * a.ci_tiles * kh * kw, nsplit);
     hipStream_t s = S(stream);
     const double flops = 2.0 * a.M * Cout * (double)Cin * kh * kw;
 #define DCF_WG(T_, NAME_)                                                                                                                       \
@@ -624,7 +667,7 @@ extern "C" int dcf_stem7x7_fwd(int dtype, const void *img4, const void *w, const
 extern "C" int dcf_stem7x7_wgrad(int dtype, const void *img4, const void *gy, float *slabs, float *gsum, int nsplit,
                                  int B, int H, int W, int Ho, int Wo, int Cout, dcf_stream_t stream)
 {
-    DCF_REQUIRE(img4 && gy && slabs && nsplit > 0 && nsplit % 4 == 0 && Cout % 32 == 0, "dcf_stem7x7_wgrad: bad arguments");
+    DCF_REQUIRE(img4 && gy && slabs && nsplit > 0 && Cout % 32 == 0, "dcf_stem7x7_wgrad: bad arguments");
     WgArgs a;
     a.x = (const char *)img4; a.gy = (const char *)gy; a.slabs = slabs; a.gsum = gsum;
     a.B = B; a.H = H + 6; a.W = W + 8; a.Cin = 32; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
@@ -633,11 +676,11 @@ extern "C" int dcf_stem7x7_wgrad(int dtype, const void *img4, const void *gy, fl
     a.pixbytes = 4 * (dtype == DCF_F32 ? 4 : 2);
     a.xbytes = (unsigned)((int64_t)B * (H + 6) * (W + 8) * a.pixbytes);
     a.gbytes = (unsigned)((int64_t)a.M * Cout * (dtype == DCF_F32 ? 4 : 2));
-    a.per_split = cdiv(cdiv(a.M, nsplit), 32) * 32;
+    a.per_split = cdiv(cdiv(a.M, 4 * nsplit), 32) * 32;   // pixels per WAVE (4 waves reduce into one slab)
     const int TM = Cout >= 64 ? 2 : 1;
     a.co_tiles = cdiv(Cout, TM * 32);
     a.ci_tiles = 1;
-    dim3 grid(a.co_tiles * 7, nsplit / 4);
+    dim3 grid(a.co_tiles * 7, nsplit);
     hipStream_t s = S(stream);
     const double sflops = 2.0 * a.M * Cout * 147.0;
     if (dtype == DCF_F32) {

@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(256) k_wgrad_finalize(const dcf_conv_param *ta
     float dot = 0.f;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         const int64_t e = (int64_t)co * K + k;
-        // fixed-order reduction with 8 loads in flight (nsplit is a multiple of 4)
+        // fixed-order reduction with 8 loads in flight
         const float *sp = slabs + d.slab_off + e;
         float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int sidx = 0;
@@ -459,14 +459,17 @@ __global__ void __launch_bounds__(256) k_wgrad_finalize(const dcf_conv_param *ta
         dot += params[d.w_off + e] * G;
     }
     if (d.gamma_off < 0) return;
-    __shared__ float red[4];
+    // dbeta: per-wave partial sums written by the wgrad kernel, reduced with a fixed thread mapping
+    float db = 0.f;
+    for (int sp = threadIdx.x; sp < 4 * d.nsplit; sp += blockDim.x) db += gsum[d.gsum_off + (int64_t)sp * d.cout_pad + co];
+    __shared__ float red[8];
     dot = wave_sum(dot);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    db = wave_sum(db);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = dot; red[4 + (threadIdx.x >> 6)] = db; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float tot = red[0] + red[1] + red[2] + red[3];
-        float dbeta = 0.f;
-        for (int sp = 0; sp < d.nsplit; ++sp) dbeta += gsum[d.gsum_off + (int64_t)sp * d.cout_pad + co];
+        const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+        const float dbeta = (red[4] + red[5]) + (red[6] + red[7]);
         const float invstd = rsqrtf(buffers[d.var_off + co] + eps);
         grads[d.beta_off + co] = dbeta;
         grads[d.gamma_off + co] = (tot - buffers[d.mean_off + co] * dbeta) * invstd;

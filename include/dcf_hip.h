@@ -107,7 +107,7 @@ int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const void *res,
                      dcf_stream_t stream);
 /* Weight gradient, split over pixel ranges: slabs fp32 [nsplit][Cout][kh][kw][Cin] (plain stores,
  * reduced in fixed order by dcf_wgrad_finalize => bitwise reproducible).
- * gsum (optional) fp32 [nsplit][Cout]: per-split sums over pixels of gy (dL/dbeta of a folded BN),
+ * gsum (optional) fp32 [4*nsplit][Cout]: per-wave sums over pixels of gy (dL/dbeta of a folded BN),
  * accumulated by the same kernel from the gy fragments it already holds.
  * nsplit = dcf_conv2d_wgrad_splits(...). */
 int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw);
@@ -134,14 +134,14 @@ typedef struct dcf_conv_param {
     int64_t wdgrad_off; /* -1 = not needed                                                      */
     int64_t shift_off;  /* element offset into the fp32 scale/shift arena: [scale Cout][shift Cout] */
     int64_t slab_off;   /* element offset of this conv's wgrad slabs in the slab arena         */
-    int64_t gsum_off;   /* element offset of this conv's [nsplit][cout_pad] sums of g in the gsum arena */
+    int64_t gsum_off;   /* element offset of this conv's [4*nsplit][cout_pad] sums of g in the gsum arena */
     int32_t cout, cin, taps, cout_pad;
     int32_t nsplit, flags, pad0, pad1;
 } dcf_conv_param;
 int dcf_weight_prep(int dtype, const dcf_conv_param *table, int nconv, const float *params, const float *buffers,
                     void *warena, float *ssarena, float eps, dcf_stream_t stream);
 /* Reduce wgrad slabs in split order and apply the folded-BN chain rule:
- * dW = scale*G, dgamma = (<W,G> - mean*dbeta)*invstd, dbeta = sum over splits of gsum[split][co]. */
+ * dW = scale*G, dgamma = (<W,G> - mean*dbeta)*invstd, dbeta = sum over the 4*nsplit rows of gsum[.][co]. */
 int dcf_wgrad_finalize(const dcf_conv_param *table, int nconv, const float *params, const float *buffers,
                        const float *ssarena, const float *slabs, const float *gsum, float *grads, float eps,
                        dcf_stream_t stream);

@@ -97,7 +97,7 @@ def test_conv_wgrad(shape, dtype):
     y.backward(gy)
     Ho, Wo = y.shape[-2:]
     ns = ops.conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, k, k)
-    assert ns >= 4 and ns % 4 == 0
+    assert ns >= 1
     slabs = torch.full((ns, Cout, k, k, Cin), float("nan"), device="cuda")
     ops.conv2d_wgrad(dtype, to_dev(x, dtype), to_dev(gy, dtype), slabs, ns, k, k, s, pad)
     G = slabs.sum(0).cpu().permute(0, 3, 1, 2)                  # -> [Cout,Cin,kh,kw]
@@ -106,10 +106,10 @@ def test_conv_wgrad(shape, dtype):
     assert e < (2e-4 if dtype == 0 else 2e-3), "wgrad rel err %g" % e
     # fixed-order slabs: bitwise reproducible
     slabs2 = torch.zeros_like(slabs)
-    gsum = torch.full((ns, Cout), float("nan"), device="cuda")
+    gsum = torch.full((4 * ns, Cout), float("nan"), device="cuda")
     ops.conv2d_wgrad(dtype, to_dev(x, dtype), to_dev(gy, dtype), slabs2, ns, k, k, s, pad, gsum)
     assert torch.equal(slabs, slabs2)
-    # per-split column sums of gy (dbeta of a folded BN) from the all-ones MFMA operand
+    # per-split column sums of gy (dbeta of a folded BN) per wave
     want = gy.sum((0, 2, 3))
     got = gsum.sum(0).cpu()
     assert torch.isfinite(got).all()

@@ -142,7 +142,7 @@ def test_weight_prep_and_finalize(dtype):
     slab1, slab2 = 0, ns1 * cp * Cin
     tab = (H.ConvParam * 2)()
     tab[0] = H.ConvParam(o_w1, -1, -1, -1, -1, wf1, wd1, 0, slab1, 0, Cout, Cin, 1, cp, ns1, 0, 0, 0)
-    tab[1] = H.ConvParam(o_w2, o_g, o_b, 0, C2o, wf2, wd2, 2 * cp, slab2, ns1 * cp, C2o, C2i, 9, C2o, ns2, 0, 0, 0)
+    tab[1] = H.ConvParam(o_w2, o_g, o_b, 0, C2o, wf2, wd2, 2 * cp, slab2, 4 * ns1 * cp, C2o, C2i, 9, C2o, ns2, 0, 0, 0)
     tdev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).cuda()
     warena = torch.zeros(wbytes, dtype=torch.uint8, device="cuda")
     ss = torch.zeros(2 * cp + 2 * C2o, device="cuda")
@@ -162,7 +162,7 @@ def test_weight_prep_and_finalize(dtype):
     assert torch.equal(ssc[:Cout], torch.ones(Cout)) and float(ssc[Cout:2 * cp].abs().max()) == 0.0
     # finalize: random slabs + gsum -> dW, dgamma, dbeta vs the analytic chain rule
     slabs = torch.cat((rnd((ns1, cp, Cin), 22).reshape(-1), rnd((ns2, C2o, 9 * C2i), 23).reshape(-1))).cuda()
-    gsum = rnd((ns1 * cp + ns2 * C2o,), 24).cuda()       # [nsplit][cout_pad] per layer
+    gsum = rnd((4 * ns1 * cp + 4 * ns2 * C2o,), 24).cuda()       # [4*nsplit][cout_pad] per layer
     grads = torch.zeros_like(params)
     H.call("dcf_wgrad_finalize", tdev, 2, params, buffers, ss, slabs, gsum, grads, 1e-5, H.stream_ptr())
     gr = grads.cpu()
@@ -170,7 +170,7 @@ def test_weight_prep_and_finalize(dtype):
     G2 = slabs.cpu()[ns1 * cp * Cin:].view(ns2, C2o, 9 * C2i).sum(0)
     assert torch.allclose(gr[o_w1:o_w1 + w1.numel()].view(Cout, Cin), G1, rtol=1e-5, atol=1e-6)
     assert torch.allclose(gr[o_w2:o_g].view(C2o, -1), G2 * scale.view(-1, 1), rtol=1e-5, atol=1e-6)
-    dbeta = gsum.cpu()[ns1 * cp:].view(ns2, C2o).sum(0)
+    dbeta = gsum.cpu()[4 * ns1 * cp:].view(4 * ns2, C2o).sum(0)
     dgamma = ((w2.reshape(C2o, -1) * G2).sum(1) - mean * dbeta) / torch.sqrt(var + 1e-5)
     assert torch.allclose(gr[o_b:o_b + C2o], dbeta, rtol=1e-5, atol=1e-6)
     assert torch.allclose(gr[o_g:o_g + C2o], dgamma, rtol=1e-4, atol=1e-4)
