@@ -207,9 +207,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def log(msg):
+        if os.environ.get("DCF_BENCH_DEBUG"):
+            print("[rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
+
+    log("model + frame pool ready")
     for s in range(args.warmup):
         train_step(trainer, pool, pool.batch(s, args.batch))
     barrier()
+    log("warm-up done")
     t0 = time.perf_counter()
     for s in range(args.steps):
         train_step(trainer, pool, pool.batch(args.warmup + s, args.batch))
@@ -220,9 +226,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(trainer.loss_value.item())
+    log("timed region done: %.3f s" % dt)
 
     roof, breakdown, cpu = None, None, None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
+        # every rank runs the instrumented steps (they contain the gradient all-reduce); rank 0 reports its own
         roof, breakdown = roofline_leg(trainer, pool, args.batch, 2)
     if ws > 1:
         dist.barrier()

@@ -87,10 +87,15 @@ def init_distributed():
     """env:// rendezvous, one rank per GPU (RANK/LOCAL_RANK/WORLD_SIZE from torchrun)."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     if ws > 1 and not dist.is_initialized():
-        local = int(os.environ.get("LOCAL_RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        # "nccl" is RCCL on ROCm (xGMI). DCF_DIST_BACKEND=gloo lets two ranks share one GPU for functional tests.
+        backend = os.environ.get("DCF_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
     return ws
 
 
