@@ -72,17 +72,13 @@ class FramePool(object):
 
 
 def train_step(trainer, pool, ids):
-    """Whole hot path for one batch; everything is enqueued on torch's current stream."""
-    vox, pcs, uvs, cnts = [], [], [], []
-    for i in ids:
-        v, pc, uv, cnt, _ = pool.geometry(pool.pts[i])
-        vox.append(v); pcs.append(pc); uvs.append(uv); cnts.append(cnt)
-    x_lidar = torch.stack(vox, 0)
+    """Whole hot path for one batch.  Geometry + KNN run on the trainer's side stream (overlapping the camera
+    stream on the compute stream); everything else is enqueued on torch's current stream."""
+    x_lidar, geom = trainer.geometry_async(pool.geometry, [pool.pts[i] for i in ids])
     x_image = torch.stack([pool.img[i] for i in ids], 0)
-    points, uv, n_valid = torch.stack(pcs, 0), torch.stack(uvs, 0), torch.cat(cnts, 0)
     boxes = torch.stack([pool.boxes[i] for i in ids], 0)          # CPU, as a DataLoader would hand them over
     nb = torch.tensor([pool.nb[i] for i in ids])
-    trainer.one_step(x_lidar, x_image, boxes, nb, points=points, uv=uv, n_valid=n_valid)
+    trainer.one_step(x_lidar, x_image, boxes, nb, geom=geom)
 
 
 def roofline_leg(trainer, pool, B, steps):

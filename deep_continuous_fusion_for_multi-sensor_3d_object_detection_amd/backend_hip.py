@@ -133,6 +133,10 @@ class HipBackend(object):
         ops.relu_bwd_chansum(self.dtype, g, y, None, True)
         return g
 
+    def wait_event(self, ev):
+        """Make the compute stream wait for work recorded on another stream (side-stream geometry)."""
+        torch.cuda.current_stream().wait_event(ev)
+
     # ------------------------------------------------------------------ elementwise
     def to_device(self, t):
         return t.to(self.dev)

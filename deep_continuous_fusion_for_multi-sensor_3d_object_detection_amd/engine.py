@@ -245,6 +245,8 @@ class Plan(object):
         fmap = None
         if self.with_image and geom is not None:
             fmap = self._image_forward(K, x_image, save)
+        if geom is not None and geom.get("voxel_event") is not None:
+            K.wait_event(geom["voxel_event"])          # voxel grid produced on the geometry side stream
         x = K.nchw_to_nhwc(x_lidar)
         outs = []
         for si, blocks in enumerate(self.stages):
@@ -379,6 +381,9 @@ class Plan(object):
     def _fusion_forward(self, K, f, x, fmap, geom, site, save):
         B, h, w, cb = x.shape
         n_max = geom["xyz"].shape[1]
+        if geom.get("event") is not None and not geom.get("_waited"):
+            K.wait_event(geom["event"])                # KNN indices produced on the geometry side stream
+            geom["_waited"] = True
         fp = K.point_sample_fwd(fmap, geom["uv"], geom["cnt"], n_max)            # [B,n_max,Cf]
         P = K.conv_fwd(f["fc1_feat"], fp.view(B, n_max, 1, fp.shape[-1]), None, False).view(B, n_max, cb)
         hsum, cnt = K.fusion_gather_fwd(P, geom["xyz"], geom["idx"][site], f["stride"], geom["aff"], f["w1d_off"], f["b1_off"])

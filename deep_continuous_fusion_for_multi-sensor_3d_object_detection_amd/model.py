@@ -220,10 +220,15 @@ class ObjectDetection_DCF(nn.Module):
                                                 self.r_max) for b in range(B)], 0))
         return dict(xyz=points.contiguous(), uv=uv.contiguous(), cnt=cnt, idx=idx, aff=self._grid.aff)
 
-    def forward(self, x_lidar, x_image, points=None, uv=None, n_valid=None):
+    def forward(self, x_lidar, x_image, points=None, uv=None, n_valid=None, geom=None):
+        """geom: optional result of fusion_geometry() computed ahead of time (e.g. on a side stream, see
+        train.Train.geometry_async); otherwise it is derived here from points / uv / n_valid."""
         K = self._ensure_backend(x_lidar.device)
-        geom = None
-        if self.fusion_enabled and points is not None:
+        if not self.fusion_enabled:
+            if geom is not None and geom.get("voxel_event") is not None:
+                torch.cuda.current_stream().wait_event(geom["voxel_event"])
+            geom = None
+        elif geom is None and points is not None:
             geom = self.fusion_geometry(points, uv, n_valid)
         K.prepare()
         need = torch.is_grad_enabled() and self._param_list[0].requires_grad

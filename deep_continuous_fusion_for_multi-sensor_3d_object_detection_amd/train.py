@@ -63,6 +63,38 @@ class Train(nn.Module):
         if world() > 1:  # identical replicas: rank 0's parameters and buffers win
             dist.broadcast(self.model.flat_params, 0)
             dist.broadcast(self.model._bufflat, 0)
+        self._side = None
+
+    def geometry_async(self, frame_geometry, points_list):
+        """Per-frame geometry (voxelise, project, KNN of the fusion sites) on a side HIP stream, so that these
+        small latency-bound kernels overlap the camera stream's convolutions on the compute stream.
+        Returns (x_lidar [B,Cz,L,W], geom) where geom carries the events the engine waits on."""
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        with torch.cuda.stream(self._side):
+            vox, pcs, uvs, cnts = [], [], [], []
+            for pts in points_list:
+                v, pc, uv, cnt, _ = frame_geometry(pts)
+                vox.append(v); pcs.append(pc); uvs.append(uv); cnts.append(cnt)
+            x_lidar = torch.stack(vox, 0)
+            ev_vox = torch.cuda.Event()
+            ev_vox.record()
+            geom = None
+            if self.model.fusion_enabled:
+                geom = self.model.fusion_geometry(torch.stack(pcs, 0), torch.stack(uvs, 0), torch.cat(cnts, 0))
+                ev = torch.cuda.Event()
+                ev.record()
+                geom["event"] = ev
+            else:
+                geom = {}
+            geom["voxel_event"] = ev_vox
+        # tensors born on the side stream are consumed on the compute stream
+        x_lidar.record_stream(main)
+        for t in [geom.get("xyz"), geom.get("uv"), geom.get("cnt")] + list(geom.get("idx") or []):
+            if t is not None:
+                t.record_stream(main)
+        return x_lidar, geom
 
     def _predict(self, lidar_voxel, camera_image, extra):
         pred = self.model(lidar_voxel, camera_image, **extra)

@@ -63,9 +63,9 @@ def test_image_stream_feature_map():
     assert err < 1e-3, err
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 6e-2)])
-def test_fused_forward(dtype, tol):
-    cfg, pts, img, crt = setup(dtype)
+@pytest.mark.parametrize("dtype,tol,K", [("f32", 1e-3, 3), ("bf16", 6e-2, 3), ("f32", 1e-3, 5), ("f32", 1e-3, 1)])
+def test_fused_forward(dtype, tol, K):
+    cfg, pts, img, crt = setup(dtype, K=K)
     net = pkg("model").ObjectDetection_DCF(cfg)
     pkg("detfill").fill_state_dict(net)
     net = net.cuda().eval()
