@@ -310,13 +310,21 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgArgs a)
     char *ldsA = lds_all + wid * WAVE_LDS;
     char *ldsB = ldsA + PK * PA;
 
-    int t = blockIdx.x;
+    // XCD-aware work mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so all
+    // (tile, tap) workgroups of one pixel range get the same (linear id % 8): they re-read the same gy / x
+    // pixels 9*tiles times, and now do it out of ONE XCD's L2 instead of the fabric.
+    // (Used when the number of pixel ranges is a multiple of 8; otherwise plain tile-major order.)
+    const int ninner = a.co_tiles * a.ci_tiles * a.kh * a.kw;
+    const int L = blockIdx.x;
+    const bool xcd = ((a.nsplit & 7) == 0) && (a.nsplit >= 48);   // measured: a loss for the few-range (small-M) layers
+    const int slab_id = xcd ? (L / (8 * ninner)) * 8 + (L & 7) : L / ninner;
+    int t = xcd ? (L >> 3) % ninner : L % ninner;
     const int tap = t % (a.kh * a.kw); t /= (a.kh * a.kw);
     const int cit = t % a.ci_tiles;
     const int cot = t / a.ci_tiles;
     const int co0 = cot * TM * 32, ci0 = cit * TN * 32;
     const int ki = tap / a.kw, kj = tap - ki * a.kw;
-    const int split = blockIdx.y * 4 + wid;
+    const int split = slab_id * 4 + wid;
     const int p_begin = split * a.per_split;
     const int p_end = min(p_begin + a.per_split, a.M);
 
@@ -508,7 +516,7 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgArgs a)
     }
     // slab store: acc lane l: column (ci) = l&31, rows (co) = (reg&3)+8(reg>>2)+4(l>>5)
     const int taps = a.kh * a.kw;
-    float *slab = a.slabs + (size_t)blockIdx.y * a.Cout * taps * a.Cin;
+    float *slab = a.slabs + (size_t)slab_id * a.Cout * taps * a.Cin;
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -591,7 +599,7 @@ extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout,
     const int tiles = cdiv(Cout, TM * 32) * cdiv(Cin, TN * 32) * kh * kw;
     const int64_t M = (int64_t)B * Ho * Wo;
     // nsplit = number of SLABS = workgroups along the pixel axis; each has 4 waves (own pixel ranges)
-    int64_t want = cdiv(1024, tiles);                 // ~16 waves per CU in total
+    int64_t want = cdiv(1024, tiles);                 // ~16 waves per CU in total (more splits measured slower)
     int64_t maxs = (M + 511) / 512;                   // at least 4 stages of 32 pixels per wave
     if (want > maxs) want = maxs;
     // keep each layer's slab arena small: it is written once and re-read by dcf_wgrad_finalize
@@ -599,6 +607,7 @@ extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout,
     const int64_t cap = (16ll << 20) / slab_bytes;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
+    if (want >= 44) want = (want + 4) / 8 * 8;        // multiples of 8 (>= 48) enable the XCD-aware work mapping
     return (int)want;
 }
 
@@ -623,7 +632,7 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
     wgrad_tiles(Cin, Cout, TM, TN);
     a.co_tiles = cdiv(Cout, TM * 32);
     a.ci_tiles = cdiv(Cin, TN * 32);
-    dim3 grid(a.co_tiles * a.ci_tiles * kh * kw, nsplit);
+    dim3 grid(a.co_tiles * a.ci_tiles * kh * kw * nsplit);
     hipStream_t s = S(stream);
     const double flops = 2.0 * a.M * Cout * (double)Cin * kh * kw;
 #define DCF_WG(T_, NAME_)                                                                                                                       \
@@ -680,7 +689,7 @@ extern "C" int dcf_stem7x7_wgrad(int dtype, const void *img4, const void *gy, fl
     const int TM = Cout >= 64 ? 2 : 1;
     a.co_tiles = cdiv(Cout, TM * 32);
     a.ci_tiles = 1;
-    dim3 grid(a.co_tiles * 7, nsplit);
+    dim3 grid(a.co_tiles * 7 * nsplit);
     hipStream_t s = S(stream);
     const double sflops = 2.0 * a.M * Cout * 147.0;
     if (dtype == DCF_F32) {

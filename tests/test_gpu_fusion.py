@@ -147,3 +147,24 @@ def test_fused_backward_all_parameters():
         if err > 5e-3 and float((got - ref).abs().max()) > 1e-5:
             bad.append((k, err, scale))
     assert not bad, "%d parameters off, worst %s" % (len(bad), sorted(bad, key=lambda t: -t[1])[:5])
+
+
+def test_side_stream_geometry_matches_inline():
+    """train.Train.geometry_async (voxelise / project / KNN on a side stream with events) gives the same
+    prediction as the inline path."""
+    cfg, pts, img, crt = setup("f32")
+    T = pkg("train")
+    trainer = T.Train(cfg)
+    pkg("detfill").fill_state_dict(trainer.model)
+    geo = pkg("data_import_carla").FrameGeometry(cfg, crt)
+    dev_pts = [torch.from_numpy(p).cuda() for p in pts]
+    with torch.no_grad():
+        x_lidar, geom = trainer.geometry_async(geo, dev_pts)
+        a = trainer.model(x_lidar, img.cuda(), geom=geom)
+        vox, pcs, uvs, cnts = [], [], [], []
+        for p in dev_pts:
+            v, pc, uv, cnt, _ = geo(p)
+            vox.append(v); pcs.append(pc); uvs.append(uv); cnts.append(cnt)
+        b = trainer.model(torch.stack(vox), img.cuda(), points=torch.stack(pcs), uv=torch.stack(uvs), n_valid=torch.cat(cnts))
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
