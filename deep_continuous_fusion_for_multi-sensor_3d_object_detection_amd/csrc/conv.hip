@@ -45,6 +45,8 @@ struct ConvArgs {
     const char *mask;         // [M][Cn] or null: output *= (mask > 0)
 };
 
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
     // one 16-byte fragment pair = one K=16 MFMA
@@ -85,8 +87,17 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wn = wid / WM, wm = wid % WM;
     const int r = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.y * BN;
-    const int m0 = blockIdx.x * BM;
+    // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, so XCD x takes
+    // the x-th contiguous chunk of the (pixel-tile, channel-tile) list, channel tiles fastest: vertically
+    // adjacent pixel tiles (shared halo rows) and the channel tiles of one pixel tile (same input rows)
+    // hit the same L2 instead of each pulling their own copy over the fabric.
+    const int nt = a.Cn / BN;
+    const int nblk = cdiv_dev(a.M, BM) * nt;
+    const int chunk = (nblk + 7) >> 3;
+    const int gidx = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (gidx >= nblk) return;
+    const int n0 = (gidx % nt) * BN;
+    const int m0 = (gidx / nt) * BM;
     const int taps = a.kh * a.kw;
     const int rowbytes = a.Ck * ES;              // bytes of one pixel's channel vector
     const int cchunks = rowbytes / KB;
@@ -256,7 +267,7 @@ int launch_igemm(const ConvArgs &a, hipStream_t s, const char *base, double flop
 #define DCF_IGEMM(KB_, TN_, TM_, WN_, WM_)                                                                          \
     do {                                                                                                            \
         constexpr int BN_ = WN_ * TN_ * 32, BM_ = WM_ * TM_ * 32;                                                   \
-        dim3 grid(cdiv(a.M, BM_), a.Cn / BN_);                                                                      \
+        dim3 grid(((cdiv(a.M, BM_) * (a.Cn / BN_) + 7) / 8) * 8);                                                   \
         snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d>", base, KB_, TN_, TM_, WN_, WM_);                           \
         DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR>), grid, dim3(256), 0, s, a)); \
         return DCF_OK;                                                                                              \
