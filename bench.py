@@ -112,9 +112,36 @@ def roofline_leg(trainer, pool, B, steps):
     roof.update({"avg_launch_us": round(ms * 1e3 / max(calls, 1), 2), "launches_per_step": calls / steps,
                  "share_of_gpu_time": round(ms / total_ms, 3) if total_ms else None, "flops_per_step": work / steps,
                  "gpu_ms_per_step_all_kernels": round(total_ms / steps, 3), "event_bracket_us_subtracted": round(bracket_ms * 1e3, 2)})
+    roof["traffic"], roof["traffic_source"] = pmc_traffic(name)
     breakdown = [{"kernel": n, "ms_per_step": round(m / steps, 4), "calls_per_step": c / steps,
                   "tflops": round(w / (m * 1e-3) / 1e12, 1) if w > 0 and m > 0 else None} for n, m, c, w in table[:16]]
     return roof, breakdown
+
+
+def pmc_traffic(name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/*_pmc_traffic.csv; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).
+    A bench run cannot collect PMC counters itself; returns (None, None) when no matching row exists."""
+    import csv, glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.csv")))
+    if not files:
+        return None, None
+    kind, _, tmpl = name.partition("<")                       # e.g. conv_wgrad_bf16 <2,2>
+    want = "k_conv_wgrad" if "wgrad" in kind else "k_conv_igemm"
+    tr = ("true" if "dgrad" in kind else "false")
+    for row in csv.DictReader(open(files[-1])):
+        k = row["kernel"]
+        if want not in k:
+            continue
+        args = k[k.index("<") + 1:k.index(">")].replace(" ", "").split(",")[1:]   # drop the dtype
+        if want == "k_conv_igemm":
+            if args[-1] != tr or ",".join(args[:-1]) != tmpl.rstrip(">"):
+                continue
+        elif ",".join(args) != tmpl.rstrip(">"):
+            continue
+        b = (2.0 * float(row["FETCH_SIZE_KB_per_launch_raw"]) + float(row["WRITE_SIZE_KB_per_launch"])) * 1024.0
+        return round(b), os.path.basename(files[-1])
+    return None, None
 
 
 def cpu_baseline(cfg, pool_seed):
