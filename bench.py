@@ -208,6 +208,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2, help="frames per GPU (cfg2: 2)")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--points", type=int, default=100000)
+    ap.add_argument("--bn-mode", default="eval", help="eval = what the reference's train.py really does (F4); train = batch statistics")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -218,6 +219,7 @@ def main():
     if ws <= 1:
         torch.cuda.set_device(0)
     cfg = kitti_config(args.batch, args.dtype, args.points)
+    cfg["bn_mode"] = args.bn_mode
     torch.manual_seed(0)
     np.random.seed(1234 + rank)
     trainer = train.Train(cfg)
@@ -265,7 +267,7 @@ def main():
                "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "cfg2: grid 32x704x800, %d pts/frame, 1242x375 RGB, ResNet-18 image stream, K=3 fusion x4 sites, "
-                                      "eval-mode BN (reference F4), batch %d/GPU" % (args.points, args.batch),
+                                      "%s-mode BN%s, batch %d/GPU" % (args.points, args.bn_mode, " (reference F4)" if args.bn_mode == "eval" else "", args.batch),
                           "global_batch": args.batch * ws, "parallelism": "dp%d" % ws, "final_loss": round(loss, 4)},
                "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown}
         print(json.dumps(out))

@@ -29,6 +29,8 @@ class HipBackend(object):
         self.tdtype = H.torch_dtype(self.dtype)
         self.es = 4 if self.dtype == H.F32 else 2
         self.dev = params.device
+        self.bn_train = False          # batch statistics instead of running statistics (train-mode BatchNorm)
+        self._bn_ws = {}
         self._layout(plan.layers)
         self._sig = None
         self.slabs = None
@@ -57,7 +59,10 @@ class HipBackend(object):
     def _upload_table(self, layers):
         tab = (H.ConvParam * len(layers))()
         for i, L in enumerate(layers):
-            tab[i] = H.ConvParam(L.w_off, L.gamma_off, L.beta_off, L.mean_off, L.var_off, L.wfwd_off, L.wdgrad_off,
+            bn = (L.gamma_off, L.beta_off, L.mean_off, L.var_off)
+            if self.bn_train:           # nothing is folded: plain weights, BN runs as its own kernels
+                bn = (-1, -1, -1, -1)
+            tab[i] = H.ConvParam(L.w_off, bn[0], bn[1], bn[2], bn[3], L.wfwd_off, L.wdgrad_off,
                                  L.shift_off, L.slab_off, L.gsum_off, L.cout, L.cin, L.taps, L.cout_pad, L.nsplit,
                                  1 if L.kind == "stem" else 0, 0, 0)
         self.table = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.dev)
@@ -67,8 +72,15 @@ class HipBackend(object):
         off = L.wdgrad_off if dgrad else L.wfwd_off
         return self.warena[off:]
 
+    def set_bn_mode(self, train):
+        train = bool(train)
+        if train != self.bn_train:
+            self.bn_train = train
+            self._upload_table(self.plan.layers)
+            self._sig = None
+
     def _shift(self, L):
-        if L.bn is None:
+        if L.bn is None or self.bn_train:
             return None
         return self.ssarena[L.shift_off + L.cout_pad:]
 
@@ -104,9 +116,36 @@ class HipBackend(object):
 
     # ------------------------------------------------------------------ convolutions
     def conv_fwd(self, L, x, res, relu):
+        if self.bn_train and L.bn is not None:
+            raw = ops.conv2d_fwd(self.dtype, x, self._w(L), None, None, L.kh, L.kw, L.stride, L.pad, False, L.cout_pad)
+            L.out_shape = (raw.shape[0], raw.shape[1], raw.shape[2])
+            return self._bn_fwd(L, raw, res, relu)
         y = ops.conv2d_fwd(self.dtype, x, self._w(L), self._shift(L), res, L.kh, L.kw, L.stride, L.pad, relu, L.cout_pad)
         L.out_shape = (y.shape[0], y.shape[1], y.shape[2])
         return y
+
+    # train-mode BatchNorm as separate kernels (batch statistics; running stats updated in place)
+    def _ws(self, C):
+        if C not in self._bn_ws:
+            self._bn_ws[C] = ops.bn_workspace(C, self.dev)
+        return self._bn_ws[C]
+
+    def _bn_fwd(self, L, raw, res, relu):
+        C = L.cout_pad
+        y, mean, invstd = ops.bn_train_fwd(self.dtype, raw, self.params[L.gamma_off:], self.params[L.beta_off:], res,
+                                           self.buffers[L.mean_off:], self.buffers[L.var_off:], relu, self._ws(C), BN_EPS, 0.1)
+        L.bn_saved = (raw, mean, invstd)
+        return y
+
+    def bn_bwd(self, L, g):
+        """Gradient through the layer's BatchNorm: identity in eval mode (BN is folded into the conv and its
+        chain rule lives in dcf_wgrad_finalize); the batch-statistics backward in train mode."""
+        if not (self.bn_train and L.bn is not None):
+            return g
+        raw, mean, invstd = L.bn_saved
+        L.bn_saved = None
+        return ops.bn_train_bwd(self.dtype, g, raw, mean, invstd, self.params[L.gamma_off:], self.grads[L.gamma_off:],
+                                self.grads[L.beta_off:], self._ws(L.cout_pad))
 
     def conv_dgrad(self, L, gy, in_shape, res, mask=None):
         """mask: fused ReLU backward of the layer that produced the tensor gx belongs to."""
@@ -115,12 +154,16 @@ class HipBackend(object):
         return ops.conv2d_dgrad(self.dtype, gy, self._w(L, True), res, in_shape, L.kh, L.kw, L.stride, L.pad, mask)
 
     def _gs(self, L):
-        return self.gsum[L.gsum_off:] if L.bn is not None else None
+        return self.gsum[L.gsum_off:] if (L.bn is not None and not self.bn_train) else None
 
     def conv_wgrad(self, L, x, gy):
         ops.conv2d_wgrad(self.dtype, x, gy, self.slabs[L.slab_off:], L.nsplit, L.kh, L.kw, L.stride, L.pad, self._gs(L))
 
     def stem_fwd(self, L, img4, Hh, W):
+        if self.bn_train:
+            raw = ops.stem7x7_fwd(self.dtype, img4, self._w(L), None, False, L.cout_pad, Hh, W)
+            L.out_shape = (raw.shape[0], raw.shape[1], raw.shape[2])
+            return self._bn_fwd(L, raw, None, True)
         y = ops.stem7x7_fwd(self.dtype, img4, self._w(L), self._shift(L), True, L.cout_pad, Hh, W)
         L.out_shape = (y.shape[0], y.shape[1], y.shape[2])
         return y

@@ -551,6 +551,120 @@ __global__ void __launch_bounds__(256) k_rowscale_bias_bwd(const T *gy, const fl
     for (int i = threadIdx.x; i < cgroups * 4; i += blockDim.x) atomicAdd(&gb2[i], sm[i]);
 }
 
+// ------------------------------------------------------------------------------------
+// Train-mode BatchNorm2d (model.py:20,24,29 when the module is in .train(): batch statistics).
+//   stats : per-channel sum / sum-of-squares partials per workgroup, finalised in double
+//           (mean, biased var -> invstd; running stats updated with momentum, unbiased var)
+//   apply : y = act(gamma*(x-mean)*invstd + beta + res)
+//   bwd   : dbeta = sum g, dgamma = sum g*xhat, dx = gamma*invstd*(g - dbeta/M - xhat*dgamma/M)
+// ------------------------------------------------------------------------------------
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(256) k_bn_partial(const T *x, const T *g, const float *mean, const float *invstd, float *partial,
+                                                    int64_t nvec, int cgroups, int64_t stride)
+{
+    extern __shared__ float sm[];  // [2][C]
+    const int C = cgroups * 4;
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sm[i] = 0.f;
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < stride) {
+        const int cg = (int)(t % cgroups);
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+        float mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {1.f, 1.f, 1.f, 1.f};
+        if (BWD) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { mu[k] = mean[cg * 4 + k]; is[k] = invstd[cg * 4 + k]; }
+        }
+        for (int64_t e = t; e < nvec; e += stride) {
+            const float4 xv = ld4(x + e * 4);
+            const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+            if (BWD) {
+                const float4 gv = ld4(g + e * 4);
+                const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { a[k] += gg[k]; b[k] += gg[k] * ((xx[k] - mu[k]) * is[k]); }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { a[k] += xx[k]; b[k] += xx[k] * xx[k]; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { atomicAdd(&sm[cg * 4 + k], a[k]); atomicAdd(&sm[C + cg * 4 + k], b[k]); }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) partial[(int64_t)blockIdx.x * 2 * C + i] = sm[i];
+}
+
+__global__ void __launch_bounds__(256) k_bn_stats_final(const float *partial, int nblk, int C, double count, float eps, float momentum,
+                                                        float *mean, float *invstd, float *running_mean, float *running_var)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += partial[(int64_t)b * 2 * C + c]; q += partial[(int64_t)b * 2 * C + C + c]; }
+    const double m = s / count;
+    double var = q / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bn_bwd_final(const float *partial, int nblk, int C, float *dgamma, float *dbeta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += partial[(int64_t)b * 2 * C + c]; q += partial[(int64_t)b * 2 * C + C + c]; }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_bn_apply_fwd(const T *x, const float *mean, const float *invstd, const float *gamma, const float *beta,
+                                                      const T *res, T *y, int64_t nvec, int cgroups, int relu)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nvec) return;
+    const int c = (int)(e % cgroups) * 4;
+    const float4 xv = ld4(x + e * 4);
+    const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (xx[k] - mean[c + k]) * invstd[c + k] * gamma[c + k] + beta[c + k];
+    if (res) {
+        const float4 r = ld4(res + e * 4);
+        o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+    }
+    if (relu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = fmaxf(o[k], 0.f);
+    }
+    st4(y + e * 4, make_float4(o[0], o[1], o[2], o[3]));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_bn_apply_bwd(const T *g, const T *x, const float *mean, const float *invstd, const float *gamma,
+                                                      const float *dgamma, const float *dbeta, T *dx, int64_t nvec, int cgroups, float inv_count)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nvec) return;
+    const int c = (int)(e % cgroups) * 4;
+    const float4 xv = ld4(x + e * 4), gv = ld4(g + e * 4);
+    const float xx[4] = {xv.x, xv.y, xv.z, xv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float xh = (xx[k] - mean[c + k]) * invstd[c + k];
+        o[k] = gamma[c + k] * invstd[c + k] * (gg[k] - dbeta[c + k] * inv_count - xh * dgamma[c + k] * inv_count);
+    }
+    st4(dx + e * 4, make_float4(o[0], o[1], o[2], o[3]));
+}
+
 }  // namespace
 
 // ================================================================== C ABI
@@ -737,5 +851,58 @@ extern "C" int dcf_rowscale_bias_bwd(int dtype, const void *gy, const float *cnt
     const int64_t stride = chan_stride(nvec, cg, blocks);
     hipStream_t s = S(stream);
     DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("rowscale_bias_bwd", s, hipLaunchKernelGGL(k_rowscale_bias_bwd<T>, dim3(blocks), dim3(256), sizeof(float) * C, s, (const T *)gy, cnt, gb2, nvec, cg, stride)); })
+    return DCF_OK;
+}
+
+// ------------------------------------------------------------------ train-mode BatchNorm C ABI
+static inline int bn_blocks(int64_t nvec, int cg, int64_t *stride)
+{
+    int64_t want = nvec < 128 * 1024 ? nvec : 128 * 1024;   // <= 512 workgroups of partials
+    if (want < cg) want = cg;
+    *stride = want / cg * cg;
+    return cdiv(*stride, 256);
+}
+
+extern "C" size_t dcf_bn_workspace_bytes(int C) { return sizeof(float) * 2 * (size_t)C * 512; }
+
+extern "C" int dcf_bn_train_fwd(int dtype, const void *x, const float *gamma, const float *beta, const void *res, void *y,
+                                float *mean, float *invstd, float *running_mean, float *running_var, int64_t npix, int C,
+                                float eps, float momentum, int relu, void *ws, dcf_stream_t stream)
+{
+    DCF_REQUIRE(x && gamma && beta && y && mean && invstd && ws && C % 4 == 0 && npix > 0, "dcf_bn_train_fwd: bad arguments");
+    const int cg = C / 4;
+    const int64_t nvec = npix * cg;
+    int64_t stride;
+    const int nblk = bn_blocks(nvec, cg, &stride);
+    hipStream_t s = S(stream);
+    float *partial = (float *)ws;
+    DCF_DISPATCH_DTYPE(dtype, {
+        DCF_LAUNCH("bn_stats_partial", s, hipLaunchKernelGGL((k_bn_partial<T, false>), dim3(nblk), dim3(256), sizeof(float) * 2 * C, s, (const T *)x,
+                                                              (const T *)nullptr, (const float *)nullptr, (const float *)nullptr, partial, nvec, cg, stride));
+        DCF_LAUNCH("bn_stats_final", s, hipLaunchKernelGGL(k_bn_stats_final, dim3(cdiv(C, 256)), dim3(256), 0, s, partial, nblk, C, (double)npix, eps,
+                                                            momentum, mean, invstd, running_mean, running_var));
+        DCF_LAUNCH("bn_apply_fwd", s, hipLaunchKernelGGL(k_bn_apply_fwd<T>, dim3(cdiv(nvec, 256)), dim3(256), 0, s, (const T *)x, mean, invstd, gamma, beta,
+                                                          (const T *)res, (T *)y, nvec, cg, relu));
+    })
+    return DCF_OK;
+}
+
+extern "C" int dcf_bn_train_bwd(int dtype, const void *g, const void *x, const float *mean, const float *invstd, const float *gamma,
+                                float *dgamma, float *dbeta, void *dx, int64_t npix, int C, void *ws, dcf_stream_t stream)
+{
+    DCF_REQUIRE(g && x && mean && invstd && gamma && dgamma && dbeta && dx && ws && C % 4 == 0 && npix > 0, "dcf_bn_train_bwd: bad arguments");
+    const int cg = C / 4;
+    const int64_t nvec = npix * cg;
+    int64_t stride;
+    const int nblk = bn_blocks(nvec, cg, &stride);
+    hipStream_t s = S(stream);
+    float *partial = (float *)ws;
+    DCF_DISPATCH_DTYPE(dtype, {
+        DCF_LAUNCH("bn_bwd_partial", s, hipLaunchKernelGGL((k_bn_partial<T, true>), dim3(nblk), dim3(256), sizeof(float) * 2 * C, s, (const T *)x, (const T *)g,
+                                                            mean, invstd, partial, nvec, cg, stride));
+        DCF_LAUNCH("bn_bwd_final", s, hipLaunchKernelGGL(k_bn_bwd_final, dim3(cdiv(C, 256)), dim3(256), 0, s, partial, nblk, C, dgamma, dbeta));
+        DCF_LAUNCH("bn_apply_bwd", s, hipLaunchKernelGGL(k_bn_apply_bwd<T>, dim3(cdiv(nvec, 256)), dim3(256), 0, s, (const T *)g, (const T *)x, mean, invstd, gamma,
+                                                          dgamma, dbeta, (T *)dx, nvec, cg, 1.0f / (float)npix));
+    })
     return DCF_OK;
 }

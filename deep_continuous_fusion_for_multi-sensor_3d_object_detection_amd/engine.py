@@ -108,15 +108,17 @@ class Block(object):
         x, y1, y = self.saved
         self.saved = None
         g2 = g if g_masked else K.relu_mask(g, y)
-        K.conv_wgrad(self.conv2, y1, g2)                                              # also dbeta(bn2) = sum g2
-        g1 = K.conv_dgrad(self.conv2, g2, tuple(y1.shape), None, y1)                  # fused ReLU mask of y1
+        d2 = K.bn_bwd(self.conv2, g2)                                                 # identity with folded (eval) BN
+        K.conv_wgrad(self.conv2, y1, d2)                                              # also dbeta(bn2) = sum g2
+        g1 = K.bn_bwd(self.conv1, K.conv_dgrad(self.conv2, d2, tuple(y1.shape), None, y1))   # fused ReLU mask of y1
         K.conv_wgrad(self.conv1, x, g1)
         pm = x if prev is not None else None
         if self.down is not None:
-            K.conv_wgrad(self.down, x, g2)
+            dd = K.bn_bwd(self.down, g2)
+            K.conv_wgrad(self.down, x, dd)
             if not need_gx:
                 return None
-            gx = K.conv_dgrad(self.down, g2, tuple(x.shape), extra)
+            gx = K.conv_dgrad(self.down, dd, tuple(x.shape), extra)
             return K.conv_dgrad(self.conv1, g1, tuple(x.shape), gx, pm)
         if not need_gx:
             return None
@@ -374,7 +376,7 @@ class Plan(object):
                 masked = prev is not None
         # g = gradient at the max-pool output
         gc1 = K.maxpool_bwd(im["c1"], g)
-        gc1 = K.relu_mask(gc1, im["c1"])
+        gc1 = K.bn_bwd(self.stem, K.relu_mask(gc1, im["c1"]))
         K.stem_wgrad(self.stem, im["img4"], gc1, im["hw"][0], im["hw"][1])
 
     # ------------------------------------------------------------------ fusion

@@ -81,10 +81,12 @@ class ObjectDetection_DCF(nn.Module):
         self.r_max = fu.get("r_max", None)
         self.cf = int(fu.get("image_channels", 64))
         self.dtype = H.dtype_code(config.get("dtype", "f32"))
-        bn_mode = config.get("bn_mode", "eval")
-        if bn_mode != "eval":
-            raise NotImplementedError("bn_mode=%r: only the reference's effective mode (eval-mode BatchNorm, test.py:37) "
-                                      "is implemented on the HIP path" % (bn_mode,))
+        # "eval": running statistics always -- what train.py effectively does (test.py:37 puts the trained module in
+        # eval mode before the first step); "train": batch statistics always; "module": follow
+        # nn.Module.training exactly like nn.BatchNorm2d would.
+        self.bn_mode = config.get("bn_mode", "eval")
+        if self.bn_mode not in ("eval", "train", "module"):
+            raise ValueError("bn_mode must be eval, train or module (got %r)" % (self.bn_mode,))
         stream = fu.get("image_stream", "resnet18")
         if self.fusion_enabled and stream != "resnet18":
             raise NotImplementedError("image_stream=%r (resnet18 only in this round)" % (stream,))
@@ -108,9 +110,11 @@ class ObjectDetection_DCF(nn.Module):
             self._param_list.append(p)
             self._param_meta.append((shape, off, n, layout))
         self._buf_meta = []
+        self._nbt_keys = []
         for key, shape, off, n in t.buffers:
             if key.endswith("num_batches_tracked"):
                 self._register(key, torch.zeros((), dtype=torch.long, device=device), True)
+                self._nbt_keys.append(key)
             else:
                 self._register(key, self._bufflat[off:off + n].view(shape), True)
                 self._buf_meta.append((key, shape, off, n))
@@ -177,6 +181,14 @@ class ObjectDetection_DCF(nn.Module):
         self._plan._anc_key = None
         return self
 
+    @property
+    def _nbt(self):
+        out = []
+        for key in self._nbt_keys:
+            node, leaf = self._resolve(key)
+            out.append(node._buffers[leaf])
+        return out
+
     def _bind_grads(self):
         for p, (shape, off, n, layout) in zip(self._param_list, self._param_meta):
             p.grad = ParamTable.view(self._gradflat, shape, off, n, layout)
@@ -230,6 +242,11 @@ class ObjectDetection_DCF(nn.Module):
             geom = None
         elif geom is None and points is not None:
             geom = self.fusion_geometry(points, uv, n_valid)
+        bn_train = self.bn_mode == "train" or (self.bn_mode == "module" and self.training)
+        K.set_bn_mode(bn_train)
+        if bn_train:
+            for b in self._nbt:
+                b += 1
         K.prepare()
         need = torch.is_grad_enabled() and self._param_list[0].requires_grad
         return _RunPlan.apply(self._param_list[0], self, x_lidar, x_image, geom, need)

@@ -89,6 +89,29 @@ def relu_bwd_chansum(dtype, gy, y, gsum, relu=True):
     return gy
 
 
+def bn_workspace(C, device):
+    return torch.empty((H.lib().dcf_bn_workspace_bytes(C),), dtype=torch.uint8, device=device)
+
+
+def bn_train_fwd(dtype, x, gamma, beta, res, running_mean, running_var, relu, ws, eps=1e-5, momentum=0.1):
+    """Returns (y, mean, invstd); running stats are updated in place when given."""
+    C = x.shape[-1]
+    npix = x.numel() // C
+    y = torch.empty_like(x)
+    mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+    invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+    H.call("dcf_bn_train_fwd", dtype, x, gamma, beta, res, y, mean, invstd, running_mean, running_var, npix, C, eps, momentum,
+           int(relu), ws, H.stream_ptr())
+    return y, mean, invstd
+
+
+def bn_train_bwd(dtype, g, x, mean, invstd, gamma, dgamma, dbeta, ws):
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    H.call("dcf_bn_train_bwd", dtype, g, x, mean, invstd, gamma, dgamma, dbeta, dx, x.numel() // C, C, ws, H.stream_ptr())
+    return dx
+
+
 def resize_bilinear_fwd(dtype, x, out_hw, align_corners, add=None):
     B, Hi, Wi, C = x.shape
     Ho, Wo = out_hw

@@ -172,6 +172,18 @@ int dcf_head_fwd(int dtype, const void *head, int Cp, const float *anchors, floa
 int dcf_head_bwd(int dtype, const void *head, int Cp, const float *anchors, const float *pred, const float *gpred,
                  void *ghead, int B, int h, int w, dcf_stream_t stream);
 
+/* Train-mode BatchNorm2d (model.py:20,24,29 with the module in .train(): batch statistics, momentum 0.1,
+ * eps 1e-5).  fwd: batch mean / invstd (fp32 [C], kept for backward), running stats updated in place
+ * (unbiased variance) when non-NULL, y = act(gamma*(x-mean)*invstd + beta + res).
+ * bwd: dgamma/dbeta written (not accumulated), dx = gamma*invstd*(g - dbeta/M - xhat*dgamma/M).
+ * ws: dcf_bn_workspace_bytes(C). */
+size_t dcf_bn_workspace_bytes(int C);
+int dcf_bn_train_fwd(int dtype, const void *x, const float *gamma, const float *beta, const void *res, void *y,
+                     float *mean, float *invstd, float *running_mean, float *running_var, int64_t npix, int C,
+                     float eps, float momentum, int relu, void *ws, dcf_stream_t stream);
+int dcf_bn_train_bwd(int dtype, const void *g, const void *x, const float *mean, const float *invstd, const float *gamma,
+                     float *dgamma, float *dbeta, void *dx, int64_t npix, int C, void *ws, dcf_stream_t stream);
+
 /* ------------------------------------------------------------------ fusion
  * SURVEY.md App. D (reference: model.py:199-203 TODO).  Per sample.
  * (1) per-point camera feature: fp [n][Cf] = bilinear(F [Hf][Wf][Cf], u/4-0.5, v/4-0.5), border clamp */

@@ -174,3 +174,29 @@ def test_weight_prep_and_finalize(dtype):
     dgamma = ((w2.reshape(C2o, -1) * G2).sum(1) - mean * dbeta) / torch.sqrt(var + 1e-5)
     assert torch.allclose(gr[o_b:o_b + C2o], dbeta, rtol=1e-5, atol=1e-6)
     assert torch.allclose(gr[o_g:o_g + C2o], dgamma, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_bn_train_kernels(dtype):
+    """Train-mode BatchNorm2d forward (+ running-stat update, residual, ReLU) and backward against F.batch_norm."""
+    ops = pkg("ops")
+    C, B, Hh, W = 96, 2, 9, 7
+    x = q(rnd((B, C, Hh, W), 51, -2.0, 2.0) + 0.3, dtype).requires_grad_(True)
+    res = q(rnd((B, C, Hh, W), 52), dtype)
+    gamma, beta = rnd((C,), 53, 0.5, 1.5).requires_grad_(True), rnd((C,), 54, -0.2, 0.2).requires_grad_(True)
+    rm, rv = rnd((C,), 55, -0.1, 0.1), rnd((C,), 56, 0.8, 1.2)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = torch.relu(F.batch_norm(x, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5) + res)
+    ws = ops.bn_workspace(C, "cuda")
+    rmd, rvd = rm.cuda(), rv.cuda()
+    y, mean, invstd = ops.bn_train_fwd(dtype, to_dev(x.detach(), dtype), gamma.detach().cuda(), beta.detach().cuda(), to_dev(res, dtype),
+                                       rmd, rvd, True, ws)
+    assert rel_err(from_dev(y), ref.detach()) < (1e-5 if dtype == 0 else 1e-2)
+    assert torch.allclose(rmd.cpu(), rm_ref, rtol=1e-5, atol=1e-6) and torch.allclose(rvd.cpu(), rv_ref, rtol=1e-4, atol=1e-6)
+    g = q(rnd((B, C, Hh, W), 57), dtype) * (ref.detach() > 0)
+    ref.backward(g)
+    dgam, dbet = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx = ops.bn_train_bwd(dtype, to_dev(g, dtype), to_dev(x.detach(), dtype), mean, invstd, gamma.detach().cuda(), dgam, dbet, ws)
+    tol = 1e-4 if dtype == 0 else 2e-2
+    assert rel_err(from_dev(dx), x.grad) < tol
+    assert rel_err(dgam.cpu(), gamma.grad) < tol and rel_err(dbet.cpu(), beta.grad) < tol

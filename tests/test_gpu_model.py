@@ -131,3 +131,51 @@ def test_cpu_tensors_fail_loudly():
     with pytest.raises(Exception) as e:
         net(tiny_input(), torch.zeros(2, 3, 8, 8, dtype=torch.uint8))
     assert "no CPU fallback" in str(e.value) or "HIP" in str(e.value)
+
+
+def test_train_mode_batchnorm_forward_backward():
+    """bn_mode=train (batch statistics, what a literal .train() reference module does): forward (B=2) and
+    backward (B=1) against the train-mode golden vectors of the imported reference, fp32 path."""
+    z = load_golden("model_tiny.npz")
+    net, cfg = build(golden_cfg(z), "f32", bn_mode="train")
+    img = torch.zeros(2, 3, 8, 8, dtype=torch.uint8, device="cuda")
+    with torch.no_grad():
+        pred = net(tiny_input().cuda(), img).cpu().numpy()
+    ref = z["pred_train"]
+    for name, sl in (("cls", slice(0, 4)), ("reg", slice(4, 18)), ("bbox", slice(18, 32))):
+        err = np.abs(pred[:, sl] - ref[:, sl]).max() / np.abs(ref[:, sl]).max()
+        assert err < 1e-3, "train-BN %s: rel err %g" % (name, err)
+    # running statistics moved (momentum 0.1) and the batch counter advanced
+    sd = net.state_dict()
+    k = "lidar_backbone.backbone.layer1.sequential.resblock_0.bn1."
+    assert int(sd[k + "num_batches_tracked"]) == 1
+    fresh, _ = build(golden_cfg(z), "f32", bn_mode="train")
+    assert not torch.equal(sd[k + "running_mean"], fresh.state_dict()[k + "running_mean"])
+    # backward, B=1
+    net, cfg = build(golden_cfg(z), "f32", bn_mode="train")
+    R = torch.from_numpy(pkg("detfill").uniform((1, 32, 16, 8), 777, -1.0, 1.0)).cuda()
+    out = net(tiny_input()[:1].cuda(), img[:1])
+    (out * R).sum().backward()
+    named = dict(net.named_parameters())
+    for k in [str(s) for s in z["grad_keys"]]:
+        ref = z["g_train_" + k]
+        got = named[k].grad.detach().cpu().numpy()
+        err = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err < 5e-3, "train-BN grad of %s: rel err %g" % (k, err)
+    gabs = np.array([named[k].grad.abs().sum().item() for k in named])
+    rel = np.abs(gabs - z["gabs_train"]) / (z["gabs_train"] + 1e-6)
+    assert rel.max() < 1e-2, "checksum rel err %g at %d" % (rel.max(), int(rel.argmax()))
+
+
+def test_module_mode_follows_training_flag():
+    z = load_golden("model_tiny.npz")
+    net, cfg = build(golden_cfg(z), "f32", bn_mode="module")
+    img = torch.zeros(2, 3, 8, 8, dtype=torch.uint8, device="cuda")
+    x = tiny_input().cuda()
+    with torch.no_grad():
+        net.eval()
+        a = net(x, img).cpu().numpy()
+        net.train()
+        b = net(x, img).cpu().numpy()
+    assert np.abs(a - z["pred_eval"]).max() / np.abs(z["pred_eval"]).max() < 1e-3
+    assert np.abs(b - z["pred_train"]).max() / np.abs(z["pred_train"]).max() < 1e-3

@@ -63,8 +63,8 @@ def test_plan_rejects_bad_configs():
     bad = copy.deepcopy(cfg); bad["voxel_channel"] = 16
     with pytest.raises(ValueError):
         M.ObjectDetection_DCF(bad)
-    bad = copy.deepcopy(cfg); bad["bn_mode"] = "train"
-    with pytest.raises(NotImplementedError):
+    bad = copy.deepcopy(cfg); bad["bn_mode"] = "sync"
+    with pytest.raises(ValueError):
         M.ObjectDetection_DCF(bad)
 
 
