@@ -595,13 +595,23 @@ __global__ void __launch_bounds__(256) k_bn_partial(const T *x, const T *g, cons
     for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) partial[(int64_t)blockIdx.x * 2 * C + i] = sm[i];
 }
 
-__global__ void __launch_bounds__(256) k_bn_stats_final(const float *partial, int nblk, int C, double count, float eps, float momentum,
-                                                        float *mean, float *invstd, float *running_mean, float *running_var)
+__device__ __forceinline__ double wave_sum_d(double v)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// one wave per channel: lanes stride over the workgroup partials (fixed mapping => reproducible), double sums
+__global__ void __launch_bounds__(64) k_bn_stats_final(const float *partial, int nblk, int C, double count, float eps, float momentum,
+                                                       float *mean, float *invstd, float *running_mean, float *running_var)
+{
+    const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += partial[(int64_t)b * 2 * C + c]; q += partial[(int64_t)b * 2 * C + C + c]; }
+    for (int b = threadIdx.x; b < nblk; b += 64) { s += partial[(int64_t)b * 2 * C + c]; q += partial[(int64_t)b * 2 * C + C + c]; }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if (threadIdx.x != 0) return;
     const double m = s / count;
     double var = q / count - m * m;
     if (var < 0.0) var = 0.0;
@@ -614,14 +624,14 @@ __global__ void __launch_bounds__(256) k_bn_stats_final(const float *partial, in
     }
 }
 
-__global__ void __launch_bounds__(256) k_bn_bwd_final(const float *partial, int nblk, int C, float *dgamma, float *dbeta)
+__global__ void __launch_bounds__(64) k_bn_bwd_final(const float *partial, int nblk, int C, float *dgamma, float *dbeta)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += partial[(int64_t)b * 2 * C + c]; q += partial[(int64_t)b * 2 * C + C + c]; }
-    dbeta[c] = (float)s;
-    dgamma[c] = (float)q;
+    for (int b = threadIdx.x; b < nblk; b += 64) { s += partial[(int64_t)b * 2 * C + c]; q += partial[(int64_t)b * 2 * C + C + c]; }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if (threadIdx.x == 0) { dbeta[c] = (float)s; dgamma[c] = (float)q; }
 }
 
 template <typename T>
@@ -879,7 +889,7 @@ extern "C" int dcf_bn_train_fwd(int dtype, const void *x, const float *gamma, co
     DCF_DISPATCH_DTYPE(dtype, {
         DCF_LAUNCH("bn_stats_partial", s, hipLaunchKernelGGL((k_bn_partial<T, false>), dim3(nblk), dim3(256), sizeof(float) * 2 * C, s, (const T *)x,
                                                               (const T *)nullptr, (const float *)nullptr, (const float *)nullptr, partial, nvec, cg, stride));
-        DCF_LAUNCH("bn_stats_final", s, hipLaunchKernelGGL(k_bn_stats_final, dim3(cdiv(C, 256)), dim3(256), 0, s, partial, nblk, C, (double)npix, eps,
+        DCF_LAUNCH("bn_stats_final", s, hipLaunchKernelGGL(k_bn_stats_final, dim3(C), dim3(64), 0, s, partial, nblk, C, (double)npix, eps,
                                                             momentum, mean, invstd, running_mean, running_var));
         DCF_LAUNCH("bn_apply_fwd", s, hipLaunchKernelGGL(k_bn_apply_fwd<T>, dim3(cdiv(nvec, 256)), dim3(256), 0, s, (const T *)x, mean, invstd, gamma, beta,
                                                           (const T *)res, (T *)y, nvec, cg, relu));
@@ -900,7 +910,7 @@ extern "C" int dcf_bn_train_bwd(int dtype, const void *g, const void *x, const f
     DCF_DISPATCH_DTYPE(dtype, {
         DCF_LAUNCH("bn_bwd_partial", s, hipLaunchKernelGGL((k_bn_partial<T, true>), dim3(nblk), dim3(256), sizeof(float) * 2 * C, s, (const T *)x, (const T *)g,
                                                             mean, invstd, partial, nvec, cg, stride));
-        DCF_LAUNCH("bn_bwd_final", s, hipLaunchKernelGGL(k_bn_bwd_final, dim3(cdiv(C, 256)), dim3(256), 0, s, partial, nblk, C, dgamma, dbeta));
+        DCF_LAUNCH("bn_bwd_final", s, hipLaunchKernelGGL(k_bn_bwd_final, dim3(C), dim3(64), 0, s, partial, nblk, C, dgamma, dbeta));
         DCF_LAUNCH("bn_apply_bwd", s, hipLaunchKernelGGL(k_bn_apply_bwd<T>, dim3(cdiv(nvec, 256)), dim3(256), 0, s, (const T *)g, (const T *)x, mean, invstd, gamma,
                                                           dgamma, dbeta, (T *)dx, nvec, cg, 1.0f / (float)npix));
     })
