@@ -87,6 +87,7 @@ def roofline_leg(trainer, pool, B, steps):
     priced at the forward conv's flops).  Kernel names are template instantiations, so the average
     durations line up with `rocprofv3 --kernel-trace --stats` rows (profiles/)."""
     Hm = pkg("_hip")
+    trainer.model.graphs_off = True                    # per-launch event brackets need eager launches
     Hm.call("dcf_prof_reset")
     Hm.call("dcf_prof_enable", 1)
     for s in range(steps):
@@ -94,6 +95,7 @@ def roofline_leg(trainer, pool, B, steps):
     Hm.call("dcf_prof_calibrate", Hm.stream_ptr(), 200)
     torch.cuda.synchronize()
     Hm.call("dcf_prof_enable", 0)
+    trainer.model.graphs_off = False
     prof = Hm.prof_read()
     Hm.call("dcf_prof_reset")
     empty = prof.pop("__empty_bracket__", (0.0, 1, 0.0))
@@ -209,6 +211,8 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--points", type=int, default=100000)
     ap.add_argument("--bn-mode", default="eval", help="eval = what the reference's train.py really does (F4); train = batch statistics")
+    ap.add_argument("--graphs", action="store_true", help="replay captured forward/backward HIP graphs instead of eager launches "
+                    "(measured equal on this workload: the step is kernel-bound, not launch-bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -220,6 +224,7 @@ def main():
         torch.cuda.set_device(0)
     cfg = kitti_config(args.batch, args.dtype, args.points)
     cfg["bn_mode"] = args.bn_mode
+    cfg["hip_graphs"] = bool(args.graphs)
     torch.manual_seed(0)
     np.random.seed(1234 + rank)
     trainer = train.Train(cfg)

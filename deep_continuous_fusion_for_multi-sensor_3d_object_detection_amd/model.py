@@ -71,6 +71,84 @@ class _RunPlan(torch.autograd.Function):
         return None, None, None, None, None, None
 
 
+class _RunGraphs(torch.autograd.Function):
+    """Same bridge as _RunPlan, but the ~120 forward and ~250 backward launches are two captured HIP graphs
+    replayed with one call each (config['hip_graphs']): launch-bound gaps between the many small kernels and
+    the per-launch host work disappear.  Inputs are copied into the graphs' static buffers first."""
+
+    @staticmethod
+    def forward(ctx, token, model, x_lidar, x_image, geom):
+        ctx.model = model
+        return model._graphs.run_forward(x_lidar, x_image, geom)
+
+    @staticmethod
+    def backward(ctx, gpred):
+        model = ctx.model
+        model._graphs.run_backward(gpred)
+        model._bind_grads()
+        return None, None, None, None, None
+
+
+class _StepGraphs(object):
+    """Captured forward / backward HIP graphs of one model for one input signature."""
+
+    def __init__(self, model):
+        self.model = model
+        self.sig = None
+
+    @staticmethod
+    def _signature(x_lidar, x_image, geom):
+        g = None if geom is None else (tuple(geom["xyz"].shape), tuple(geom["idx"][0].shape))
+        return (tuple(x_lidar.shape), None if x_image is None else tuple(x_image.shape), g)
+
+    def _capture(self, x_lidar, x_image, geom):
+        m = self.model
+        K = m._backend
+        self.sx = x_lidar.clone()
+        self.simg = None if x_image is None else x_image.clone()
+        self.sgeom = None
+        if geom is not None:
+            self.sgeom = dict(xyz=geom["xyz"].clone(), uv=geom["uv"].clone(), cnt=geom["cnt"].clone(),
+                              idx=[t.clone() for t in geom["idx"]], aff=geom["aff"])
+        # eager warm-up step on the static buffers: lazy allocations (slabs, anchors, workspaces) happen here
+        K.prepare()
+        pred = m._plan.forward(K, self.sx, self.simg, self.sgeom, save=True)
+        m._plan.backward(K, torch.zeros_like(pred))
+        torch.cuda.synchronize()
+        self.g_fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fwd):
+            K.prepare()
+            self.spred = m._plan.forward(K, self.sx, self.simg, self.sgeom, save=True)
+        self.sgpred = torch.zeros_like(self.spred)
+        self.g_bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()):
+            m._plan.backward(K, self.sgpred)
+
+    def run_forward(self, x_lidar, x_image, geom):
+        cur = torch.cuda.current_stream()
+        if geom is not None:
+            for k in ("voxel_event", "event"):
+                if geom.get(k) is not None:
+                    cur.wait_event(geom[k])
+        sig = self._signature(x_lidar, x_image, geom)
+        if sig != self.sig:
+            self._capture(x_lidar, x_image, geom)
+            self.sig = sig
+        self.sx.copy_(x_lidar)
+        if self.simg is not None:
+            self.simg.copy_(x_image)
+        if self.sgeom is not None:
+            self.sgeom["xyz"].copy_(geom["xyz"]); self.sgeom["uv"].copy_(geom["uv"]); self.sgeom["cnt"].copy_(geom["cnt"])
+            for d, s_ in zip(self.sgeom["idx"], geom["idx"]):
+                d.copy_(s_)
+        self.g_fwd.replay()
+        return self.spred
+
+    def run_backward(self, gpred):
+        self.sgpred.copy_(gpred)
+        self.g_bwd.replay()
+
+
 class ObjectDetection_DCF(nn.Module):
     def __init__(self, config):
         super(ObjectDetection_DCF, self).__init__()
@@ -90,6 +168,8 @@ class ObjectDetection_DCF(nn.Module):
         stream = fu.get("image_stream", "resnet18")
         if self.fusion_enabled and stream != "resnet18":
             raise NotImplementedError("image_stream=%r (resnet18 only in this round)" % (stream,))
+        self.use_graphs = bool(config.get("hip_graphs", False))
+        self._graphs = None
         self._plan = Plan(config, with_image=self.fusion_enabled, cf=self.cf)
         self._backend = None
         self._build_parameters()
@@ -178,6 +258,7 @@ class ObjectDetection_DCF(nn.Module):
                 node, leaf = self._resolve(key)
                 node._buffers[leaf] = fn(node._buffers[leaf])
         self._backend = None
+        self._graphs = None
         self._plan._anc_key = None
         return self
 
@@ -247,9 +328,18 @@ class ObjectDetection_DCF(nn.Module):
         if bn_train:
             for b in self._nbt:
                 b += 1
-        K.prepare()
         need = torch.is_grad_enabled() and self._param_list[0].requires_grad
+        if self.use_graphs and need and not bn_train and not self._profiling():
+            if self._graphs is None:
+                self._graphs = _StepGraphs(self)
+            return _RunGraphs.apply(self._param_list[0], self, x_lidar, x_image, geom)
+        K.prepare()
         return _RunPlan.apply(self._param_list[0], self, x_lidar, x_image, geom, need)
+
+    graphs_off = False     # set True to force the eager path (per-kernel event timing cannot see inside a graph)
+
+    def _profiling(self):
+        return self.graphs_off
 
 
 class OffsettoBbox(nn.Module):

@@ -179,3 +179,20 @@ def test_module_mode_follows_training_flag():
         b = net(x, img).cpu().numpy()
     assert np.abs(a - z["pred_eval"]).max() / np.abs(z["pred_eval"]).max() < 1e-3
     assert np.abs(b - z["pred_train"]).max() / np.abs(z["pred_train"]).max() < 1e-3
+
+
+def test_hip_graph_replay_matches_eager():
+    """config hip_graphs: forward/backward captured once and replayed -- same prediction and gradients as eager."""
+    z = load_golden("model_tiny.npz")
+    x = tiny_input()[:1].cuda()
+    img = torch.zeros(1, 3, 8, 8, dtype=torch.uint8, device="cuda")
+    R = torch.from_numpy(pkg("detfill").uniform((1, 32, 16, 8), 777, -1.0, 1.0)).cuda()
+    outs = []
+    for graphs in (False, True):
+        net, cfg = build(golden_cfg(z), "f32", hip_graphs=graphs)
+        for rep in range(3):                       # replays after the capture step
+            pred = net(x * (1.0 + 0.1 * rep), img)
+            (pred * R).sum().backward()
+        outs.append((pred.detach().clone(), net.flat_grads.clone()))
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-6)
