@@ -22,6 +22,8 @@
 //
 // dtype: bf16 -> v_mfma_f32_32x32x16_bf16;  fp32 -> v_mfma_f32_32x32x2_f32 (exact fp32,
 // used by the parity tests against the reference's fp32 CPU path).  fp32 accumulate.
+#include <stdlib.h>
+
 #include "dcf_common.h"
 
 namespace {
@@ -72,7 +74,7 @@ template <> struct Mma<float> {
 // channels x TM*32 pixels.  K is walked tap by tap in chunks of KB bytes of channels.
 // LDS rows are padded by 16 B: the ds_read_b128 fragment reads are then conflict free.
 // ------------------------------------------------------------------------------------
-template <typename T, int KB, int TN, int TM, int WN, int WM, bool TRANSPOSED>
+template <typename T, int KB, int TN, int TM, int WN, int WM, bool TRANSPOSED, bool DB>
 __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
 {
     constexpr int ES = DT<T>::size;
@@ -81,8 +83,10 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
     constexpr int CPR = KB / 16;                 // 16-byte chunks per row
     constexpr int NCW = BN * CPR, NCX = BM * CPR;
     constexpr int NLW = (NCW + 255) / 256, NLX = (NCX + 255) / 256;
-    __shared__ __attribute__((aligned(16))) char lds[(BN + BM) * PITCH];
-    char *ldsW = lds, *ldsX = lds + BN * PITCH;
+    constexpr int STAGE = (BN + BM) * PITCH;      // one K-chunk of both operands
+    // DB: two LDS buffers, one barrier per K-chunk (wins when few workgroups share a CU: small-M layers);
+    // !DB: one buffer, two barriers, half the LDS => more resident workgroups (wins on the large layers).
+    __shared__ __attribute__((aligned(16))) char lds[(DB ? 2 : 1) * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wn = wid / WM, wm = wid % WM;
@@ -170,7 +174,8 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
         for (int i = 0; i < NLX; ++i)
             rx[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srcX, pix[i] == OOB ? OOB : pix[i] + ccoff, 0, 0));
     };
-    auto store_lds = [&]() {
+    auto store_lds = [&](int buf) {
+        char *ldsW = lds + buf * STAGE, *ldsX = ldsW + BN * PITCH;
 #pragma unroll
         for (int i = 0; i < NLW; ++i) {
             const int c = tid + i * 256;
@@ -185,20 +190,15 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
 
     const int nit = taps * cchunks;
     int ki = 0, kj = 0, cc = 0;
-    set_tap(0, 0);
-    load_global(0, 0);
-    store_lds();
-    __syncthreads();
-    for (int it = 0; it < nit; ++it) {
-        const bool more = (it + 1 < nit);
-        if (more) {                                   // next chunk's loads fly under the MFMAs below
-            if (++cc == cchunks) {
-                cc = 0;
-                if (++kj == a.kw) { kj = 0; ++ki; }
-                set_tap(ki, kj);
-            }
-            load_global((unsigned)(it + 1) * KB, (unsigned)cc * KB);
+    auto advance = [&]() {
+        if (++cc == cchunks) {
+            cc = 0;
+            if (++kj == a.kw) { kj = 0; ++ki; }
+            set_tap(ki, kj);
         }
+    };
+    auto compute = [&](int buf) {
+        const char *ldsW = lds + buf * STAGE, *ldsX = ldsW + BN * PITCH;
 #pragma unroll
         for (int ks = 0; ks < KB / 32; ++ks) {
             uint4 fa[TN], fb[TM];
@@ -213,10 +213,34 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
 #pragma unroll
                 for (int j = 0; j < TM; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
         }
+    };
+    set_tap(0, 0);
+    load_global(0, 0);
+    store_lds(0);
+    if constexpr (DB) {
+        // while the MFMAs of chunk `it` run out of buffer it&1, chunk it+1 (already in registers) is written to
+        // the other buffer and chunk it+2 is requested from L2
+        if (nit > 1) { advance(); load_global((unsigned)KB, (unsigned)cc * KB); }
         __syncthreads();
-        if (more) {
-            store_lds();
+        for (int it = 0; it < nit; ++it) {
+            compute(it & 1);
+            if (it + 1 < nit) {
+                store_lds((it + 1) & 1);              // buffer (it+1)&1 was last read in iteration it-1
+                if (it + 2 < nit) { advance(); load_global((unsigned)(it + 2) * KB, (unsigned)cc * KB); }
+            }
             __syncthreads();
+        }
+    } else {
+        __syncthreads();
+        for (int it = 0; it < nit; ++it) {
+            const bool more = (it + 1 < nit);
+            if (more) { advance(); load_global((unsigned)(it + 1) * KB, (unsigned)cc * KB); }   // flies under the MFMAs
+            compute(0);
+            __syncthreads();
+            if (more) {
+                store_lds(0);
+                __syncthreads();
+            }
         }
     }
 
@@ -268,11 +292,20 @@ int launch_igemm(const ConvArgs &a, hipStream_t s, const char *base, double flop
     do {                                                                                                            \
         constexpr int BN_ = WN_ * TN_ * 32, BM_ = WM_ * TM_ * 32;                                                   \
         dim3 grid(((cdiv(a.M, BM_) * (a.Cn / BN_) + 7) / 8) * 8);                                                   \
-        snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d>", base, KB_, TN_, TM_, WN_, WM_);                           \
-        DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR>), grid, dim3(256), 0, s, a)); \
+        const bool db = (int64_t)cdiv(a.M, BM_) * (a.Cn / BN_) <= 512;   /* <= 2 workgroups per CU: 1-barrier pipeline */ \
+        snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d%s>", base, KB_, TN_, TM_, WN_, WM_, db ? ",db" : "");        \
+        if (db) DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR, true>), grid, dim3(256), 0, s, a)); \
+        else DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR, false>), grid, dim3(256), 0, s, a)); \
         return DCF_OK;                                                                                              \
     } while (0)
-    // tile choice: the biggest tile that still gives the chip >= ~2 workgroups per CU
+    // tile choice: the biggest tile that still gives the chip >= ~1 workgroup per CU
+    // (DCF_TILE=0..3 forces a tile for experiments: 128x128, 64x128, 64x64, 32x128 channels x pixels)
+    static const char *force_env = getenv("DCF_TILE");
+    const int force = force_env ? atoi(force_env) : -1;
+    if (force == 0 && a.Cn % 128 == 0) { if (kb128) DCF_IGEMM(128, 2, 2, 2, 2); else DCF_IGEMM(64, 2, 2, 2, 2); }
+    if (force == 1 && a.Cn % 64 == 0) { if (kb128) DCF_IGEMM(128, 2, 1, 1, 4); else DCF_IGEMM(64, 2, 1, 1, 4); }
+    if (force == 2 && a.Cn % 64 == 0) { if (kb128) DCF_IGEMM(128, 1, 1, 2, 2); else DCF_IGEMM(64, 1, 1, 2, 2); }
+    if (force == 3) { if (kb128) DCF_IGEMM(128, 1, 1, 1, 4); else DCF_IGEMM(64, 1, 1, 1, 4); }
     const int64_t want_blocks = 256;
     auto blocks = [&](int bn, int bm) { return (int64_t)cdiv(a.M, bm) * (a.Cn / bn); };
     if (a.Cn % 128 == 0 && blocks(128, 128) >= want_blocks) {
