@@ -97,9 +97,6 @@ class Block(object):
         self.saved = (x, y1, y) if save else None
         return y
 
-    def sum_layers(self):
-        return [self.conv2] + ([self.down] if self.down is not None else [])
-
     def backward(self, K, g, extra=None, need_gx=True, g_masked=False, prev=None):
         """g = dL/dy (consumed / overwritten).  extra = gradient reaching x from other consumers.
         g_masked: the producer of g already applied this block's output ReLU mask.
@@ -346,11 +343,7 @@ class Plan(object):
                 p2 = p
         fmap = K.conv_fwd(self.img_smooth, p2, None, False)
         if save:
-            self.ctx["img"] = dict(img4=img4, hw=(Hh, W), c1=c1, pool=None, feats=feats, p2=p2, fmap_shape=tuple(fmap.shape))
-            self.ctx["img"]["pool_out"] = None
-            self.ctx["img"]["pool_in"] = c1
-            self.ctx["img"]["pool_y"] = feats and None
-        self._pool_y = None
+            self.ctx["img"] = dict(img4=img4, hw=(Hh, W), c1=c1, feats=feats, p2=p2)
         return fmap
 
     def _image_backward(self, K, gF):
