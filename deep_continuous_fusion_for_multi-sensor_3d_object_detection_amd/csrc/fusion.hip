@@ -10,6 +10,8 @@
 // per (pixel, neighbour), and fc2 is linear so it commutes with the K-sum.  Steps (1),(3)
 // are gathers of whole contiguous channel rows (coalesced 8-16 B per lane); their backward
 // passes are scatter-adds with fp32 atomics.
+#include <stdlib.h>
+
 #include "dcf_common.h"
 
 namespace {
@@ -241,8 +243,10 @@ extern "C" int dcf_fusion_gather_bwd(int dtype, const void *P, const float *xyz,
     hipStream_t s = S(stream);
     DCF_REQUIRE(K <= 8, "dcf_fusion_gather_bwd: K must be <= 8");
     const int64_t hw = (int64_t)h * w;
-    int chunk = (int)(hw * Cb / (256 * 1024));            // ~1024 workgroups
-    if (chunk < 16) chunk = 16;
+    // pixels per thread run: swept on cfg2 (div 32..512): ~256k threads is the sweet spot between
+    // latency hiding (more, shorter runs) and atomic aggregation (fewer, longer runs)
+    int chunk = (int)(hw * Cb / (256 * 1024));
+    if (chunk < 8) chunk = 8;
     const int64_t groups = (hw + chunk - 1) / chunk;
     DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("fusion_gather_bwd", s, hipLaunchKernelGGL(k_fusion_gather_bwd<T>, dim3(cdiv(groups * Cb, 256)), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, idx, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, chunk)); })
     return DCF_OK;

@@ -36,14 +36,15 @@ class FrameGeometry(object):
             return c["image_height"], c["image_width"]
         return c["image_width"], c["image_height"]
 
-    def __call__(self, lidar_points, want_ids=False):
+    def __call__(self, lidar_points, want_ids=False, voxel_out=None):
         """lidar_points [N,3] f32 (any device) -> (voxel [Cz,L,W], pointcloud_raw [max_num_pc,3],
-        uv [max_num_pc,2], n_valid int32[1] on device, ids or None)."""
+        uv [max_num_pc,2], n_valid int32[1] on device, ids or None).  voxel_out: optional [Cz,L,W] slice of a
+        batch tensor to write the grid into (saves the stack copy)."""
         pts = lidar_points.to(device="cuda", dtype=torch.float32).contiguous()
         g = self.grid
         if self.voxel_mode == H.VOXEL_COMPAT and (self._owner is None or self._owner.device != pts.device):
             self._owner = torch.zeros((2, g.dims[0] * g.dims[1] * g.dims[2]), dtype=torch.int32, device=pts.device)
-        voxel = ops.voxelize(pts, g.lim, g.aff, g.dims, self.voxel_mode, self._owner)
+        voxel = ops.voxelize(pts, g.lim, g.aff, g.dims, self.voxel_mode, self._owner, voxel_out)
         ulim, vlim = self.limits()
         n_out = max(int(self.config["max_num_pc"]), pts.shape[0])
         uv, xyz, cnt, _ = ops.project_filter(pts, g.lim, self.crt, ulim, vlim, self.proj_mode, n_out=n_out)

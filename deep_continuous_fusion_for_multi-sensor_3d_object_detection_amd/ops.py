@@ -201,10 +201,10 @@ def range_filter(pts, lim):
     return out, src, cnt
 
 
-def voxelize(pts, lim, aff, dims, mode=H.VOXEL_COMPAT, owner_ws=None):
+def voxelize(pts, lim, aff, dims, mode=H.VOXEL_COMPAT, owner_ws=None, out=None):
     Cz, L, W = dims
     dev = pts.device
-    grid = torch.empty((Cz, L, W), dtype=torch.float32, device=dev)
+    grid = torch.empty((Cz, L, W), dtype=torch.float32, device=dev) if out is None else _chk(out, "out")
     if mode == H.VOXEL_COMPAT and owner_ws is None:
         owner_ws = torch.zeros((2, Cz * L * W), dtype=torch.int32, device=dev)
     H.call("dcf_voxelize", _chk(pts, "pts"), pts.shape[0], H.host_f32(lim), H.host_f32(aff), Cz, L, W, mode, grid, owner_ws,

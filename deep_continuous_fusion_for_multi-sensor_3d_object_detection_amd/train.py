@@ -73,11 +73,12 @@ class Train(nn.Module):
         if self._side is None:
             self._side = torch.cuda.Stream()
         with torch.cuda.stream(self._side):
-            vox, pcs, uvs, cnts = [], [], [], []
-            for pts in points_list:
-                v, pc, uv, cnt, _ = frame_geometry(pts)
-                vox.append(v); pcs.append(pc); uvs.append(uv); cnts.append(cnt)
-            x_lidar = torch.stack(vox, 0)
+            pcs, uvs, cnts = [], [], []
+            Cz, L, W = frame_geometry.grid.dims
+            x_lidar = torch.empty((len(points_list), Cz, L, W), dtype=torch.float32, device="cuda")
+            for b, pts in enumerate(points_list):
+                _, pc, uv, cnt, _ = frame_geometry(pts, voxel_out=x_lidar[b])     # grid written in place
+                pcs.append(pc); uvs.append(uv); cnts.append(cnt)
             ev_vox = torch.cuda.Event()
             ev_vox.record()
             geom = None
