@@ -45,6 +45,12 @@ struct ConvArgs {
     int pixbytes;        // byte pitch between adjacent input pixels (= Ck*esize except for the stem)
     unsigned xbytes, wbytes;  // sizes of the gathered tensor and of the weight image (buffer descriptors)
     const char *mask;         // [M][Cn] or null: output *= (mask > 0)
+    // stride-2 dgrad only: output pixels are enumerated parity class by parity class ((oh+pad)&1, (ow+pad)&1),
+    // each class padded to whole pixel tiles, so a tile only walks the taps that can hit a real gy pixel
+    int parity;               // 1 = class-major enumeration in use
+    int cls_tile[5];          // first pixel-tile of each class (prefix sums), in tiles of the launch's BM
+    int cls_h[2], cls_w[2];   // rows / columns per parity
+    int cls_h0[2], cls_w0[2]; // first row / column of each parity
 };
 
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
@@ -96,12 +102,32 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
     // adjacent pixel tiles (shared halo rows) and the channel tiles of one pixel tile (same input rows)
     // hit the same L2 instead of each pulling their own copy over the fabric.
     const int nt = a.Cn / BN;
-    const int nblk = cdiv_dev(a.M, BM) * nt;
+    const bool PAR = TRANSPOSED && a.parity;
+    const int mtiles = PAR ? a.cls_tile[4] : cdiv_dev(a.M, BM);
+    const int nblk = mtiles * nt;
     const int chunk = (nblk + 7) >> 3;
     const int gidx = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     if (gidx >= nblk) return;
     const int n0 = (gidx % nt) * BN;
-    const int m0 = (gidx / nt) * BM;
+    const int mt = gidx / nt;
+    int m0 = mt * BM;                              // first (class-local when PAR) pixel of this tile
+    int ph = 0, pw = 0, clsM = a.M;               // parity class of the tile, pixels in the class
+    if (PAR) {
+        const int cls = (mt >= a.cls_tile[1]) + (mt >= a.cls_tile[2]) + (mt >= a.cls_tile[3]);
+        ph = cls >> 1; pw = cls & 1;
+        m0 = (mt - a.cls_tile[cls]) * BM;
+        clsM = a.B * a.cls_h[ph] * a.cls_w[pw];
+    }
+    // class-local pixel index -> linear output pixel (identity without parity classes), -1 past the end
+    auto out_pixel = [&](int m) -> int {
+        if (m >= clsM) return -1;
+        if (!PAR) return m;
+        const int hwc = a.cls_h[ph] * a.cls_w[pw];
+        const int b = m / hwc;
+        const int rem = m - b * hwc;
+        const int i = rem / a.cls_w[pw], j = rem - i * a.cls_w[pw];
+        return (b * a.Ho + a.cls_h0[ph] + 2 * i) * a.Wo + a.cls_w0[pw] + 2 * j;
+    };
     const int taps = a.kh * a.kw;
     const int rowbytes = a.Ck * ES;              // bytes of one pixel's channel vector
     const int cchunks = rowbytes / KB;
@@ -119,9 +145,9 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
     for (int i = 0; i < NLX; ++i) {
         const int c = tid + i * 256;
         const int row = c / CPR;
-        const int m = m0 + row;
+        const int m = (c < NCX) ? out_pixel(m0 + row) : -1;
         xoff[i] = (c % CPR) * 16;
-        if (c < NCX && m < a.M) {
+        if (m >= 0) {
             const int b = m / (a.Ho * a.Wo);
             const int rem = m - b * (a.Ho * a.Wo);
             const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
@@ -188,15 +214,20 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
         }
     };
 
-    const int nit = taps * cchunks;
-    int ki = 0, kj = 0, cc = 0;
+    // taps walked by this tile: all of them, or (stride-2 dgrad) only those of the tile's parity class
+    const int tstep = PAR ? 2 : 1;
+    const int nki = PAR ? (a.kh - ph + 1) / 2 : a.kh, nkj = PAR ? (a.kw - pw + 1) / 2 : a.kw;
+    const int nit = nki * nkj * cchunks;
+    int ki = ph, kj = pw, cc = 0;
     auto advance = [&]() {
         if (++cc == cchunks) {
             cc = 0;
-            if (++kj == a.kw) { kj = 0; ++ki; }
+            kj += tstep;
+            if (kj >= a.kw) { kj = pw; ki += tstep; }
             set_tap(ki, kj);
         }
     };
+    auto koff = [&]() { return (unsigned)((ki * a.kw + kj) * cchunks + cc) * KB; };   // K offset of (tap, chunk) in a weight row
     auto compute = [&](int buf) {
         const char *ldsW = lds + buf * STAGE, *ldsX = ldsW + BN * PITCH;
 #pragma unroll
@@ -214,19 +245,21 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
                 for (int j = 0; j < TM; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
         }
     };
-    set_tap(0, 0);
-    load_global(0, 0);
-    store_lds(0);
+    if (nit > 0) {
+        set_tap(ki, kj);
+        load_global(koff(), 0);
+        store_lds(0);
+    }
     if constexpr (DB) {
         // while the MFMAs of chunk `it` run out of buffer it&1, chunk it+1 (already in registers) is written to
         // the other buffer and chunk it+2 is requested from L2
-        if (nit > 1) { advance(); load_global((unsigned)KB, (unsigned)cc * KB); }
+        if (nit > 1) { advance(); load_global(koff(), (unsigned)cc * KB); }
         __syncthreads();
         for (int it = 0; it < nit; ++it) {
             compute(it & 1);
             if (it + 1 < nit) {
                 store_lds((it + 1) & 1);              // buffer (it+1)&1 was last read in iteration it-1
-                if (it + 2 < nit) { advance(); load_global((unsigned)(it + 2) * KB, (unsigned)cc * KB); }
+                if (it + 2 < nit) { advance(); load_global(koff(), (unsigned)cc * KB); }
             }
             __syncthreads();
         }
@@ -234,7 +267,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
         __syncthreads();
         for (int it = 0; it < nit; ++it) {
             const bool more = (it + 1 < nit);
-            if (more) { advance(); load_global((unsigned)(it + 1) * KB, (unsigned)cc * KB); }   // flies under the MFMAs
+            if (more) { advance(); load_global(koff(), (unsigned)cc * KB); }   // flies under the MFMAs
             compute(0);
             __syncthreads();
             if (more) {
@@ -252,8 +285,8 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
     const T *mask = reinterpret_cast<const T *>(a.mask);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        const int m = m0 + (wm * TM + j) * 32 + r;
-        if (m >= a.M) continue;
+        const int m = out_pixel(m0 + (wm * TM + j) * 32 + r);
+        if (m < 0) continue;
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
 #pragma unroll
@@ -282,17 +315,25 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
 }
 
 template <typename T, bool TR>
-int launch_igemm(const ConvArgs &a, hipStream_t s, const char *base, double flops)
+int launch_igemm(const ConvArgs &a_in, hipStream_t s, const char *base, double flops)
 {
     char name[64];
+    const ConvArgs &a = a_in;
     constexpr int ES = DT<T>::size;
     const int rowbytes = a.Ck * ES;
     const bool kb128 = (rowbytes % 128) == 0;
 #define DCF_IGEMM(KB_, TN_, TM_, WN_, WM_)                                                                          \
     do {                                                                                                            \
         constexpr int BN_ = WN_ * TN_ * 32, BM_ = WM_ * TM_ * 32;                                                   \
-        dim3 grid(((cdiv(a.M, BM_) * (a.Cn / BN_) + 7) / 8) * 8);                                                   \
-        const bool db = (int64_t)cdiv(a.M, BM_) * (a.Cn / BN_) <= 512;   /* <= 2 workgroups per CU: 1-barrier pipeline */ \
+        ConvArgs a = a_in;                                                                                          \
+        int mtiles = cdiv(a.M, BM_);                                                                                \
+        if (a.parity) {                                                                                             \
+            a.cls_tile[0] = 0;                                                                                      \
+            for (int c = 0; c < 4; ++c) a.cls_tile[c + 1] = a.cls_tile[c] + cdiv((int64_t)a.B * a.cls_h[c >> 1] * a.cls_w[c & 1], BM_); \
+            mtiles = a.cls_tile[4];                                                                                 \
+        }                                                                                                           \
+        dim3 grid((((int64_t)mtiles * (a.Cn / BN_) + 7) / 8) * 8);                                                  \
+        const bool db = (int64_t)mtiles * (a.Cn / BN_) <= 512;   /* <= 2 workgroups per CU: 1-barrier pipeline */   \
         snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d%s>", base, KB_, TN_, TM_, WN_, WM_, db ? ",db" : "");        \
         if (db) DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR, true>), grid, dim3(256), 0, s, a)); \
         else DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR, false>), grid, dim3(256), 0, s, a)); \
@@ -600,7 +641,7 @@ extern "C" int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const flo
     DCF_REQUIRE((int64_t)B * H * W * Cin < (1ll << 31) * 1, "dcf_conv2d_fwd: tensor too large for 32-bit pixel index");
     ConvArgs a;
     a.x = (const char *)x; a.w = (const char *)w; a.shift = shift; a.res = (const char *)res; a.y = (char *)y;
-    a.mask = nullptr;
+    a.mask = nullptr; a.parity = 0;
     a.B = B; a.Hi = H; a.Wi = W; a.Ck = Cin; a.Ho = Ho; a.Wo = Wo; a.Cn = Cout;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.relu = relu; a.M = B * Ho * Wo;
     a.pixbytes = Cin * (dtype == DCF_F32 ? 4 : 2);
@@ -623,6 +664,12 @@ extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const
     ConvArgs a;
     a.x = (const char *)gy; a.w = (const char *)wt; a.shift = nullptr; a.res = (const char *)res; a.y = (char *)gx;
     a.mask = (const char *)mask;
+    // class-major order writes every other pixel of a row: only worth it when one pixel is a whole 128-B line
+    a.parity = (stride == 2 && Cin * (dtype == DCF_F32 ? 4 : 2) >= 128) ? 1 : 0;
+    for (int p = 0; p < 2; ++p) {       // rows / columns of dX whose (index + pad) has parity p
+        a.cls_h0[p] = (p + pad) & 1; a.cls_w0[p] = (p + pad) & 1;
+        a.cls_h[p] = (H - a.cls_h0[p] + 1) / 2; a.cls_w[p] = (W - a.cls_w0[p] + 1) / 2;
+    }
     a.B = B; a.Hi = Ho; a.Wi = Wo; a.Ck = Cout; a.Ho = H; a.Wo = W; a.Cn = Cin;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.relu = 0; a.M = B * H * W;
     a.pixbytes = Cout * (dtype == DCF_F32 ? 4 : 2);
@@ -706,7 +753,7 @@ extern "C" int dcf_stem7x7_fwd(int dtype, const void *img4, const void *w, const
     DCF_REQUIRE(Ho == (H + 6 - 7) / 2 + 1 && Wo == (W + 6 - 7) / 2 + 1, "dcf_stem7x7_fwd: output size mismatch");
     ConvArgs a;
     a.x = (const char *)img4; a.w = (const char *)w; a.shift = shift; a.res = nullptr; a.y = (char *)y;
-    a.mask = nullptr;
+    a.mask = nullptr; a.parity = 0;
     a.B = B; a.Hi = H + 6; a.Wi = W + 8; a.Ck = 32; a.Ho = Ho; a.Wo = Wo; a.Cn = Cout;
     a.kh = 7; a.kw = 1; a.stride = 2; a.pad = 0; a.relu = relu; a.M = B * Ho * Wo;
     a.pixbytes = 4 * (dtype == DCF_F32 ? 4 : 2);
