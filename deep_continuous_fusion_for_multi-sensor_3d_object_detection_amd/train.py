@@ -109,6 +109,24 @@ class Train(nn.Module):
         n = allreduce_grads(self.model.flat_grads)
         self.optimizer.step(1.0 / n)
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def save_checkpoint(self, path, epoch=0):
+        """Model state_dict (the reference's key names, train.py:79) plus what the reference never saved:
+        optimiser moments / step count and the epoch, so that training can really resume."""
+        sd = {k: v.detach().clone().contiguous().cpu() for k, v in self.model.state_dict().items()}
+        opt = {"step": self.optimizer.step_count, "m": self.optimizer.m.cpu(), "v": self.optimizer.v.cpu()}
+        torch.save({"model": sd, "optimizer": opt, "epoch": int(epoch)}, path)
+
+    def load_checkpoint(self, path):
+        ck = torch.load(path, map_location="cpu")
+        if "model" not in ck:                      # a bare state_dict written by the reference's train.py
+            self.model.load_state_dict(ck)
+            return 0
+        self.model.load_state_dict(ck["model"])
+        self.optimizer.load_state_dict({k: (v.to(self.model.flat_params.device) if torch.is_tensor(v) else v)
+                                        for k, v in ck["optimizer"].items()})
+        return int(ck.get("epoch", 0))
+
     def get_loss_value(self, lidar_voxel, camera_image, object_data, num_ref_box, **extra):
         with torch.no_grad():
             pred_cls, pred_reg, _ = self._predict(lidar_voxel, camera_image, extra)

@@ -141,3 +141,43 @@ def test_knn_edge_cases():
     cnt = torch.tensor([8], dtype=torch.int32, device="cuda")
     got = ops.knn_bev(torch.from_numpy(far).cuda(), cnt, 3, h, w, s, g.aff).cpu().numpy()
     assert np.array_equal(got, geometry_ref.knn_bev(far, 3, h, w, s, g.aff))
+
+
+@pytest.mark.parametrize("npts,hw,K", [(120000, (375, 1242), 5), (300000, (1080, 1920), 3)])
+def test_cfg4_cfg5_geometry_scale(npts, hw, K):
+    """BASELINE configs[3]/[4] input sizes (120k pts + 1242x375, K=5; 300k pts + 1920x1080): voxel grid, projection
+    and compaction bit-exact against the C oracle; KNN bit-exact on a BEV window (brute force kept to seconds)."""
+    ops, H, det, calib = pkg("ops"), pkg("_hip"), pkg("detfill"), pkg("calib")
+    cfg = golden_cfg(load_golden("geometry_carla.npz"))
+    cfg.update(dict(voxel_length=704, voxel_width=800, lidar_x_max=70.4, lidar_y_min=-40.0, lidar_y_max=40.0,
+                    image_height=hw[0], image_width=hw[1], max_num_pc=npts))
+    g = _spec(cfg)
+    crt = calib.kitti_like_crt() if hw[0] == 375 else calib.hd_crt()
+    pts = det.synthetic_points(npts, (0.0, 70.4, -40.0, 40.0, -2.4, 0.8), seed=11)
+    ref_grid, ref_pc, ref_uv, ref_n, _ = geometry_ref.voxelization_projection(pts, cfg, crt, proj_mode="correct")
+    d = torch.from_numpy(pts).cuda()
+    grid = ops.voxelize(d, g.lim, g.aff, g.dims, H.VOXEL_COMPAT)
+    assert np.array_equal(grid.cpu().numpy().view(np.uint32), ref_grid.view(np.uint32))
+    uv, xyz, cnt, _ = ops.project_filter(d, g.lim, crt, hw[1], hw[0], H.PROJ_CORRECT)
+    n = int(cnt.item())
+    assert n == ref_n and n > 10000
+    assert np.array_equal(uv.cpu().numpy()[:n].view(np.uint32), ref_uv[:n].view(np.uint32))
+    assert np.array_equal(xyz.cpu().numpy()[:n].view(np.uint32), ref_pc[:n].view(np.uint32))
+    # KNN: full site on the GPU, a 24x200-pixel strip checked against the brute-force oracle
+    s = 4
+    h, w = 704 // s, 800 // s
+    got = ops.knn_bev(xyz, cnt, K, h, w, s, g.aff).cpu().numpy()
+    ref = geometry_ref.knn_bev(ref_pc[:n], K, 24, w, s, g.aff)       # first 24 BEV rows
+    assert np.array_equal(got[:, :24, :], ref)
+    # size-independent property on the whole site: every index valid, neighbours sorted by (d2, index)
+    assert got.min() >= 0 and got.max() < n
+    p = ref_pc[:n]
+    X = ((np.arange(h, dtype=np.float32) + np.float32(0.5)) * np.float32(s) - g.aff[1]) / g.aff[0]
+    Y = ((np.arange(w, dtype=np.float32) + np.float32(0.5)) * np.float32(s) - g.aff[3]) / g.aff[2]
+    d2 = []
+    for k in range(K):
+        dx = p[got[k], 0] - X[:, None]
+        dy = p[got[k], 1] - Y[None, :]
+        d2.append((dx * dx).astype(np.float32) + (dy * dy).astype(np.float32))
+    for k in range(K - 1):
+        assert ((d2[k] < d2[k + 1]) | ((d2[k] == d2[k + 1]) & (got[k] < got[k + 1]))).all()

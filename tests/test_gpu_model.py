@@ -196,3 +196,31 @@ def test_hip_graph_replay_matches_eager():
         outs.append((pred.detach().clone(), net.flat_grads.clone()))
     assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-6)
     assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-6)
+
+
+def test_checkpoint_resume_is_exact(tmp_path):
+    """save after 2 steps, resume in a fresh Train, take step 3: identical parameters to an uninterrupted run."""
+    z = load_golden("model_tiny.npz")
+    lz = load_golden("loss.npz")
+    cfg = golden_cfg(z)
+    cfg["dtype"] = "f32"
+    T = pkg("train")
+    x = tiny_input()[:1].cuda()
+    img = torch.zeros(1, 3, 8, 8, dtype=torch.uint8, device="cuda")
+    boxes, nb = torch.from_numpy(lz["bboxes"])[:1], torch.from_numpy(lz["nbox"])[:1]
+
+    def run(trainer, steps, first):
+        for s in range(first, first + steps):
+            np.random.seed(100 + s)
+            trainer.one_step(x, img, boxes, nb)
+
+    a = T.Train(cfg)
+    pkg("detfill").fill_state_dict(a.model)
+    run(a, 2, 0)
+    a.save_checkpoint(str(tmp_path / "ck.pt"), epoch=7)
+    run(a, 1, 2)
+    b = T.Train(cfg)
+    assert b.load_checkpoint(str(tmp_path / "ck.pt")) == 7
+    run(b, 1, 2)
+    assert torch.equal(a.model.flat_params, b.model.flat_params)
+    assert b.optimizer.step_count == 3
