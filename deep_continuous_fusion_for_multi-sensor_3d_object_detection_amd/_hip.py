@@ -41,7 +41,7 @@ SIGNATURES = {
     "dcf_image_to_nhwc4": (c_int, [c_int, P, P, c_int, c_int, c_int, P]),
     "dcf_conv2d_fwd": (c_int, [c_int, P, P, P, P, P] + [c_int] * 12 + [P]),
     "dcf_conv2d_dgrad": (c_int, [c_int, P, P, P, P, P] + [c_int] * 11 + [P]),
-    "dcf_conv2d_wgrad_splits": (c_int, [c_int] * 7),
+    "dcf_conv2d_wgrad_splits": (c_int, [c_int] * 8),
     "dcf_conv2d_wgrad": (c_int, [c_int, P, P, P, P, c_int] + [c_int] * 11 + [P]),
     "dcf_stem7x7_fwd": (c_int, [c_int, P, P, P, P] + [c_int] * 7 + [P]),
     "dcf_stem7x7_wgrad": (c_int, [c_int, P, P, P, P, c_int] + [c_int] * 6 + [P]),

@@ -99,7 +99,7 @@ class HipBackend(object):
                     L.nsplit, L.slab_off, L.gsum_off = 0, 0, 0
                     continue
                 B, Ho, Wo = L.out_shape
-                L.nsplit = ops.conv2d_wgrad_splits(B, Ho, Wo, L.cin, L.cout_pad, L.kh, L.kw)
+                L.nsplit = ops.conv2d_wgrad_splits(B, Ho, Wo, L.cin, L.cout_pad, L.kh, L.kw, L.stride)
                 L.slab_off = off
                 off += L.nsplit * L.cout_pad * L.taps * L.cin
                 L.gsum_off = goff                       # [4*nsplit][cout_pad] per-wave sums of g (dbeta)

@@ -377,6 +377,7 @@ struct WgArgs {
     int co_tiles, ci_tiles;
     int pixbytes;              // byte pitch between adjacent x pixels (= Cin*esize except for the stem)
     unsigned xbytes, gbytes;   // tensor sizes for the buffer descriptors
+    int dbg;                   // experiments only (DCF_WGRAD3_DBG): 1 = every DMA reads the zero page
 };
 
 template <typename T, int TM, int TN>
@@ -616,6 +617,574 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgArgs a)
         }
 }
 
+// ------------------------------------------------------------------------------------
+// wgrad kernel for 3x3 / stride 1 / pad 1 layers (all but a handful of the network's convs).
+// The generic kernel above stages gy and x once PER TAP (9x each) and moves two LDS fragments per
+// MFMA; here one wave owns the three horizontal taps of KR kernel rows and walks the PADDED image
+// (rows of Wo + 2 positions; positions 0 and Wo+1 carry gy = 0 and x = 0): in that flattened space
+// the x fragment of tap kj is the same staged tile read kj rows further down, with no wrap between
+// image rows, so a stage of 32 positions costs one gy tile + one (32+2)-row x tile per kernel row
+// for 3*KR taps: a third of the L1 traffic and half the LDS traffic per MFMA.
+// grid.x = co_tiles*ci_tiles*(3/KR)*nsplit; 4 waves = 4 position ranges, reduced in fixed order.
+// ------------------------------------------------------------------------------------
+template <typename T, int TM, int TN, int KR>
+__global__ void __launch_bounds__(256, 2) k_conv_wgrad3(WgArgs a)
+{
+    constexpr int ES = DT<T>::size;
+    constexpr int PK = 32, XR = PK + 2;
+    constexpr int RA = TM * 32 * ES, RB = TN * 32 * ES;
+    constexpr int PA = (ES == 2) ? (RA == 64 ? 64 : 192) : RA + 16;
+    constexpr int PB = (ES == 2) ? (RB == 64 ? 64 : 192) : RB + 16;
+    constexpr int WAVE_LDS = PK * PA + KR * XR * PB;
+    constexpr int TILE = TM * TN * 16 * 64;       // floats of one tap's accumulator tile
+    constexpr int LDS_BYTES = 4 * WAVE_LDS > 2 * TILE * 4 ? 4 * WAVE_LDS : 2 * TILE * 4;
+    __shared__ __attribute__((aligned(16))) char lds_all[LDS_BYTES];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    char *ldsA = lds_all + wid * WAVE_LDS;
+    char *ldsB = ldsA + PK * PA;                  // KR buffers of XR rows
+
+    constexpr int NKG = 3 / KR;
+    const int ninner = a.co_tiles * a.ci_tiles * NKG;
+    const int L = blockIdx.x;
+    const bool xcd = ((a.nsplit & 7) == 0) && (a.nsplit >= 48);
+    const int slab_id = xcd ? (L / (8 * ninner)) * 8 + (L & 7) : L / ninner;
+    int t = xcd ? (L >> 3) % ninner : L % ninner;
+    const int kg = t % NKG; t /= NKG;
+    const int cit = t % a.ci_tiles;
+    const int cot = t / a.ci_tiles;
+    const int co0 = cot * TM * 32, ci0 = cit * TN * 32, ki0 = kg * KR;
+    const int Wp = a.Wo + 2;
+    const int split = slab_id * 4 + wid;
+    const int q_begin = split * a.per_split;
+    const int q_end = min(q_begin + a.per_split, a.M);     // a.M = B*Ho*(Wo+2) padded positions
+
+    f32x16 acc[KR][3][TM][TN];
+#pragma unroll
+    for (int r = 0; r < KR; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[r][k][i][j][q] = 0.f;
+
+    const bool do_sum = (a.gsum != nullptr) && (kg == 0) && (cit == 0);
+    float fsum[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fsum[i] = 0.f;
+
+    constexpr int CA = RA / 16, CB = RB / 16;
+    constexpr int NLA = PK * CA / 64, NLB = PK * CB / 64;
+    static_assert(NLA * 2 == CA && NLB * 2 == CB, "half a row per lane");
+    const int rowA = a.Cout * ES;
+    const int coutA = min(TM * 32, a.Cout - co0) * ES;
+    const int cinB = min(TN * 32, a.Cin - ci0) * ES;
+    const __amdgpu_buffer_rsrc_t srcG = __builtin_amdgcn_make_buffer_rsrc((void *)a.gy, 0, a.gbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srcX = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFF00u;
+    const int lrow = lane >> 1, lhalf = lane & 1;
+    const unsigned colA = (unsigned)(co0 * ES + lhalf * NLA * 16);
+    const unsigned colB = (unsigned)(ci0 * ES + lhalf * NLB * 16);
+
+    // lane state: gy position q_begin + lrow -> (image row Rg over the whole batch, padded column cg);
+    // x position one further (slots 2..33 of the x tile are positions q0+1 .. q0+32)
+    int qg = q_begin + lrow;
+    int Rg = qg / Wp, cg = qg - Rg * Wp;
+    int Rx = (qg + 1) / Wp, cx = (qg + 1) - Rx * Wp;
+    int ohx = Rx % a.Ho;
+
+    auto x_load = [&](int R, int c, int oh, int kr, unsigned col, int nchunk, int chunk0, uint4 *dst) {
+        const int ih = oh + ki0 + kr - 1;
+        const bool ok = (c >= 1) && (c <= a.Wo) && (ih >= 0) && (ih < a.H);
+        const unsigned vo = (unsigned)((R + ki0 + kr - 1) * a.W + c - 1) * (unsigned)a.pixbytes + col;
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) {
+            const bool okc = ok && (i < nchunk) && ((chunk0 + i) * 16 < cinB);
+            dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srcX, okc ? vo + i * 16 : OOB, 0, 0));
+        }
+    };
+
+    // prologue: x slots 0 and 1 (positions q_begin-1, q_begin) -- later stages inherit them from the previous stage
+    if (q_begin < q_end) {
+        const int slot = lane >> 1;
+        if (slot < 2) {
+            const int qq = q_begin - 1 + slot;
+            const int R = qq >= 0 ? qq / Wp : 0, c = qq >= 0 ? qq - R * Wp : 0;   // c = 0 reads as zero
+            const int oh = R % a.Ho;
+#pragma unroll
+            for (int kr = 0; kr < KR; ++kr) {
+                uint4 v[NLB];
+                x_load(R, c, oh, kr, colB, NLB, lhalf * NLB, v);
+#pragma unroll
+                for (int i = 0; i < NLB; ++i) *reinterpret_cast<uint4 *>(ldsB + (kr * XR + slot) * PB + (lhalf * NLB + i) * 16) = v[i];
+            }
+        }
+    }
+
+    uint4 ra[NLA], rb[KR][NLB];
+    auto load_stage = [&]() {
+        const bool live = (qg < q_end) && (cg >= 1) && (cg <= a.Wo);
+        const unsigned voA = (unsigned)(Rg * a.Wo + cg - 1) * (unsigned)rowA + colA;
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            const bool ok = live && ((lhalf * NLA + i) * 16 < coutA);
+            ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srcG, ok ? voA + i * 16 : OOB, 0, 0));
+        }
+#pragma unroll
+        for (int kr = 0; kr < KR; ++kr) x_load(Rx, cx, ohx, kr, colB, NLB, lhalf * NLB, rb[kr]);
+        qg += PK;
+        cg += PK;
+        while (cg >= Wp) { cg -= Wp; ++Rg; }
+        cx += PK;
+        while (cx >= Wp) { cx -= Wp; ++Rx; ++ohx; if (ohx == a.Ho) ohx = 0; }
+    };
+    if (q_begin < q_end) load_stage();
+    for (int q0 = q_begin; q0 < q_end; q0 += PK) {
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) *reinterpret_cast<uint4 *>(ldsA + lrow * PA + (lhalf * NLA + i) * 16) = ra[i];
+#pragma unroll
+        for (int kr = 0; kr < KR; ++kr)
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) *reinterpret_cast<uint4 *>(ldsB + (kr * XR + 2 + lrow) * PB + (lhalf * NLB + i) * 16) = rb[kr][i];
+        __builtin_amdgcn_wave_barrier();
+        if (q0 + PK < q_end) load_stage();
+        if constexpr (ES == 2) {
+            const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, hh = g >> 1;
+#pragma unroll
+            for (int ks = 0; ks < PK / 16; ++ks) {
+                uint4 fa[TM];
+                const int row0 = ks * 16 + 8 * hh + q;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const char *base = ldsA + row0 * PA + (i * 32 + 16 * (g & 1) + 4 * pp) * 2;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base + 4 * PA));
+                    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                    fa[i] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                }
+#pragma unroll
+                for (int kr = 0; kr < KR; ++kr)
+#pragma unroll
+                    for (int kj = 0; kj < 3; ++kj) {
+                        uint4 fb[TN];
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const char *base = ldsB + (kr * XR + row0 + kj) * PB + (j * 32 + 16 * (g & 1) + 4 * pp) * 2;
+                            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base));
+                            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base + 4 * PB));
+                            uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                            fb[j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                        }
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[kr][kj][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
+                                                                                            acc[kr][kj][i][j], 0, 0, 0);
+                    }
+                if (do_sum) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const unsigned w[4] = {fa[i].x, fa[i].y, fa[i].z, fa[i].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) fsum[i] += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xffff0000u);
+                    }
+                }
+            }
+        } else {
+            const int r = lane & 31, kk = lane >> 5;
+#pragma unroll 4
+            for (int ks = 0; ks < PK / 2; ++ks) {
+                float fa[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float *>(ldsA + (2 * ks + kk) * PA + (i * 32 + r) * 4);
+#pragma unroll
+                for (int kr = 0; kr < KR; ++kr)
+#pragma unroll
+                    for (int kj = 0; kj < 3; ++kj) {
+                        float fb[TN];
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float *>(ldsB + (kr * XR + 2 * ks + kk + kj) * PB + (j * 32 + r) * 4);
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) acc[kr][kj][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[kr][kj][i][j], 0, 0, 0);
+                    }
+                if (do_sum) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fsum[i] += fa[i];
+                }
+            }
+        }
+        // the last two x rows of this stage are the first two of the next (same wave, LDS ops in order)
+        if (lane < 2 * CB) {
+            const int row = lane / CB, ch = lane - row * CB;
+#pragma unroll
+            for (int kr = 0; kr < KR; ++kr) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(ldsB + (kr * XR + PK + row) * PB + ch * 16);
+                *reinterpret_cast<uint4 *>(ldsB + (kr * XR + row) * PB + ch * 16) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (do_sum) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float tot = fsum[i] + __shfl_xor(fsum[i], 32, 64);
+            const int co = co0 + i * 32 + (lane & 31);
+            if (lane < 32 && co < a.Cout) a.gsum[(size_t)split * a.Cout + co] = tot;
+        }
+    }
+    // fixed-order reduction of the 4 waves' tiles, one tap at a time: ((w0 + w2) + (w1 + w3))
+    float *red = reinterpret_cast<float *>(lds_all);
+    float *slab = a.slabs + (size_t)slab_id * a.Cout * 9 * a.Cin;
+    const int r = lane & 31, h = lane >> 5;
+    __syncthreads();
+#pragma unroll
+    for (int kr = 0; kr < KR; ++kr)
+#pragma unroll
+        for (int kj = 0; kj < 3; ++kj) {
+            if (wid >= 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) red[(wid - 2) * TILE + ((i * TN + j) * 16 + q) * 64 + lane] = acc[kr][kj][i][j][q];
+            }
+            __syncthreads();
+            if (wid < 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) acc[kr][kj][i][j][q] += red[wid * TILE + ((i * TN + j) * 16 + q) * 64 + lane];
+            }
+            __syncthreads();
+            if (wid == 1) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) red[((i * TN + j) * 16 + q) * 64 + lane] = acc[kr][kj][i][j][q];
+            }
+            __syncthreads();
+            if (wid == 0) {
+                const int tap = (ki0 + kr) * 3 + kj;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int ci = ci0 + j * 32 + r;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const int co = co0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                            const float v = acc[kr][kj][i][j][q] + red[((i * TN + j) * 16 + q) * 64 + lane];
+                            if (co < a.Cout && ci < a.Cin) slab[((size_t)co * 9 + tap) * a.Cin + ci] = v;
+                        }
+                    }
+            }
+            __syncthreads();
+        }
+}
+
+// ------------------------------------------------------------------------------------
+// k_conv_wgrad3g: the 3x3 / stride-1 row-sharing wgrad (see k_conv_wgrad3) with LDS-DMA staging.
+// The register-staged kernels above keep ONE stage of loads in flight per wave and pay ~2 us of
+// memory latency per 32-pixel stage; here a wave owns an NS-deep ring of LDS slots that
+// `global_load_lds_dwordx4` fills directly (no staging VGPRs, no ds_write), NS-1 stages ahead,
+// retired by a counted `s_waitcnt vmcnt` (the issuing wave's own wait orders its ds_reads; the
+// rings are wave-private, so the main loop has no barrier).  One workgroup per CU (LDS-bound),
+// one wave per SIMD, the whole register file for the 12 accumulator tiles.
+//   * DMA image is lane-linear (1 KiB = 8 rows x 128 B per instruction), so rows have no pad;
+//     128-B rows are XOR-swizzled (64-B half ^= row bit 1) on the SOURCE address and on the
+//     transposed reads, which keeps the 4 rows of a ds_read_b64_tr_b16 group on distinct banks.
+//   * padding, junk rows and masked channels read a 16-byte zero page instead of being skipped.
+// bf16 only; Wo + 2 >= the rows one stage loads (40 or 48).
+// ------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) unsigned g_dcf_zero16[4];
+__device__ long long g_dcf_dbg_t[8];     // DCF_WGRAD3_DBG & 2: phase timestamps (s_memtime) of workgroup 0, wave 0
+#define DCF_STAMP(i) do { if ((a.dbg & 2) && blockIdx.x == 0 && threadIdx.x == 0) g_dcf_dbg_t[i] = clock64(); } while (0)
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// One LDS-DMA instruction: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_dst, lds_dst + 1024).
+// Inline asm on purpose: hipcc counts a *builtin* LDS-DMA as a pending LDS write and drains it with vmcnt(0)
+// before the next ds_read, which would serialise the ring; an asm one is ours to count (wait_vmcnt above).
+// M0 (the DMA destination base) is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void glds16(const char *src, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+}
+
+template <typename V> __device__ __forceinline__ V opaque(V v) { asm volatile("" : "+v"(v)); return v; }   // stop re-derivation of lane constants
+
+template <int TM, int TN, int NS, int NW>
+__global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g(WgArgs a)
+{
+    constexpr int PK = 32, XROWS = PK + 2;
+    constexpr int RA = TM * 64, RB = TN * 64;        // row bytes = LDS pitch
+    constexpr int LPA = RA / 16, LPB = RB / 16;      // lanes (16-B chunks) per row
+    constexpr int RPA = 64 / LPA, RPB = 64 / LPB;    // rows per DMA instruction
+    constexpr int NA = PK / RPA;
+    constexpr int NB = (XROWS + RPB - 1) / RPB;
+    constexpr int GI = NA + NB;                      // DMA instructions per stage
+    constexpr int SA = PK * RA, SB = NB * 1024;      // slot bytes
+    constexpr int WAVE_LDS = NS * (SA + SB);
+    constexpr int TILE = TM * TN * 16 * 64;
+    constexpr int RED_BYTES = NW * TILE * 4;         // one tap's tile of every wave
+    constexpr int LDS_BYTES = NW * WAVE_LDS > RED_BYTES ? NW * WAVE_LDS : RED_BYTES;
+    static_assert((NS - 1) * GI < 64, "vmcnt range");
+    static_assert(NS >= 2 && NS <= 4 && (NW == 4 || NW == 8), "ring depth / waves");
+    __shared__ __attribute__((aligned(1024))) char lds_all[LDS_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: everything derived from it stays scalar
+    DCF_STAMP(0);
+    char *ldsA = lds_all + wid * WAVE_LDS;
+    char *ldsB = ldsA + NS * SA;
+    const unsigned ldsA0 = lds_addr(ldsA), ldsB0 = lds_addr(ldsB);
+
+    const int ninner = a.co_tiles * a.ci_tiles * 3;
+    const int L = blockIdx.x;
+    const bool xcd = ((a.nsplit & 7) == 0) && (a.nsplit >= 48);
+    const int slab_id = xcd ? (L / (8 * ninner)) * 8 + (L & 7) : L / ninner;
+    int t = xcd ? (L >> 3) % ninner : L % ninner;
+    const int ki = t % 3; t /= 3;
+    const int cit = t % a.ci_tiles;
+    const int cot = t / a.ci_tiles;
+    const int co0 = cot * TM * 32, ci0 = cit * TN * 32;
+    const int Wp = a.Wo + 2, BH = a.B * a.Ho;
+    const int split = slab_id * NW + wid;
+    const int q_begin = split * a.per_split;
+    const int q_end = min(q_begin + a.per_split, a.M);
+    const int nst = q_begin < q_end ? (q_end - q_begin + PK - 1) / PK : 0;
+
+    f32x16 acc[3][TM][TN];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[k][i][j][q] = 0.f;
+    const bool do_sum = (a.gsum != nullptr) && (ki == 0) && (cit == 0);
+    float fsum[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fsum[i] = 0.f;
+
+    // ---- DMA side.  Lane = (row lr, 16-B chunk ch) of every instruction; the XOR swizzle goes on the source chunk.
+    // The stage's first position is wave-uniform, so its (image row, padded column) live in SGPRs; a lane adds its
+    // row and handles the single possible wrap into the next image row (Wo + 2 >= rows staged).
+    const int rowA = a.Cout * 2;
+    const int coutA = min(TM * 32, a.Cout - co0) * 2, cinB = min(TN * 32, a.Cin - ci0) * 2;
+    const int lrA = lane / LPA, lrB = lane / LPB;
+    const int chA = (RA == 128) ? ((lane % LPA) ^ (((lrA >> 1) & 1) << 2)) : (lane % LPA);
+    const int chB = (RB == 128) ? ((lane % LPB) ^ (((lrB >> 1) & 1) << 2)) : (lane % LPB);
+    const bool chokA = (chA * 16 < coutA) & !(a.dbg & 1), chokB = (chB * 16 < cinB) & !(a.dbg & 1);
+    const char *gyb = opaque(a.gy + co0 * 2 + chA * 16 + (size_t)lrA * rowA);
+    const char *xb = opaque(a.x + ci0 * 2 + chB * 16 + (size_t)lrB * a.pixbytes);
+    const char *zero = reinterpret_cast<const char *>(g_dcf_zero16);
+    const int lrAo = opaque(lrA), lrBo = opaque(lrB);
+    const int wrapA = opaque(2 * rowA), wrapB = opaque(2 * a.pixbytes);
+    int sq = q_begin;                                    // scalar state: gy rows start at position sq, x rows at sq - 1
+    int sR = q_begin / Wp, sC = q_begin - sR * Wp;
+    int xR, xC, xOh;
+    if (q_begin == 0) { xR = -1; xC = Wp - 1; xOh = a.Ho - 1; }
+    else { xR = (q_begin - 1) / Wp; xC = (q_begin - 1) - xR * Wp; xOh = xR % a.Ho; }
+    auto issue = [&](int slot) {
+        const unsigned sa = __builtin_amdgcn_readfirstlane(ldsA0 + slot * SA), sb = __builtin_amdgcn_readfirstlane(ldsB0 + slot * SB);
+        {
+            const int rem = q_end - sq;
+            const int base = __builtin_amdgcn_readfirstlane((sR * a.Wo + sC - 1) * rowA);   // may be < 0 (lane rows make it valid); tensors < 2 GiB
+            const int cl = sC + lrAo;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int c = cl + j * RPA;
+                const bool w = c >= Wp;
+                const int cc = w ? c - Wp : c;
+                const bool ok = chokA & (lrAo < rem - j * RPA) & ((unsigned)(cc - 1) < (unsigned)a.Wo);
+                const int off = (base + j * RPA * rowA) - (w ? wrapA : 0);
+                glds16(ok ? gyb + (ptrdiff_t)off : zero, sa + j * 1024);
+            }
+        }
+        {
+            const int ih0 = xOh + ki - 1;
+            const int oh1 = xOh + 1 == a.Ho ? 0 : xOh + 1;
+            const int ih1 = oh1 + ki - 1;
+            const bool ok0 = (xR >= 0) & (xR < BH) & (ih0 >= 0) & (ih0 < a.H);
+            const bool ok1 = (xR + 1 < BH) & (ih1 >= 0) & (ih1 < a.H);
+            const int base = __builtin_amdgcn_readfirstlane(((xR + ki - 1) * a.W + xC - 1) * a.pixbytes);
+            const int cl = xC + lrBo;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int c = cl + j * RPB;
+                const bool w = c >= Wp;
+                const int cc = w ? c - Wp : c;
+                const bool ok = chokB & (lrBo < XROWS - j * RPB) & ((unsigned)(cc - 1) < (unsigned)a.Wo) & (w ? ok1 : ok0);
+                const int off = (base + j * RPB * a.pixbytes) - (w ? wrapB : 0);
+                glds16(ok ? xb + (ptrdiff_t)off : zero, sb + j * 1024);
+            }
+        }
+        sq += PK;
+        sC += PK;
+        if (sC >= Wp) { sC -= Wp; ++sR; }
+        xC += PK;
+        if (xC >= Wp) { xC -= Wp; ++xR; xOh = xOh + 1 == a.Ho ? 0 : xOh + 1; }
+    };
+
+    // ---- read side: lane-constant byte offsets of the transposed reads (swizzle folded in)
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, hh = g >> 1;
+    const int colw = (16 * (g & 1) + 4 * pp) * 2;
+    int offA[TM], offB[3][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) offA[i] = opaque((8 * hh + q) * RA + ((i * 64 + colw) ^ ((RA == 128) ? (((q >> 1) & 1) << 6) : 0)));
+#pragma unroll
+    for (int kj = 0; kj < 3; ++kj)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            offB[kj][j] = opaque((8 * hh + q + kj) * RB + ((j * 64 + colw) ^ ((RB == 128) ? ((((q + kj) >> 1) & 1) << 6) : 0)));
+
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+        if (s0 < nst) issue(s0);
+    int slot = 0, islot = NS - 1;
+    DCF_STAMP(1);
+    for (int n = 0; n < nst; ++n) {
+        if (n + NS - 1 < nst) issue(islot);
+        const int ahead = min(NS - 1, nst - 1 - n);          // stages issued after stage n
+        if (ahead >= NS - 1) wait_vmcnt<(NS - 1) * GI>();
+        else if (NS > 3 && ahead == 2) wait_vmcnt<2 * GI>();
+        else if (NS > 2 && ahead == 1) wait_vmcnt<1 * GI>();
+        else wait_vmcnt<0>();
+        const char *pa = ldsA + slot * SA, *pb = ldsB + slot * SB;
+#pragma unroll
+        for (int ks = 0; ks < PK / 16; ++ks) {
+            uint4 fa[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const char *base = pa + offA[i] + ks * 16 * RA;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base + 4 * RA));
+                uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                fa[i] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+            }
+#pragma unroll
+            for (int kj = 0; kj < 3; ++kj) {
+                uint4 fb[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const char *base = pb + offB[kj][j] + ks * 16 * RB;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base + 4 * RB));
+                    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                    fb[j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[kj][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
+                                                                                acc[kj][i][j], 0, 0, 0);
+            }
+            if (do_sum) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const unsigned w[4] = {fa[i].x, fa[i].y, fa[i].z, fa[i].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fsum[i] += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xffff0000u);
+                }
+            }
+        }
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        islot = islot + 1 == NS ? 0 : islot + 1;
+    }
+
+    float *red = reinterpret_cast<float *>(lds_all);
+    DCF_STAMP(2);
+    __syncthreads();                                   // every wave is done with its ring
+    DCF_STAMP(3);
+    if (a.gsum != nullptr && ki == 0 && cit == 0) {    // block-uniform.  gsum rows: 4 per slab (NW = 8: waves w and w + 4 pair up)
+        float tot[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) tot[i] = fsum[i] + __shfl_xor(fsum[i], 32, 64);
+        if (NW == 8) {
+            if (wid >= 4 && lane < 32)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) red[((wid - 4) * TM + i) * 32 + lane] = tot[i];
+            __syncthreads();
+            if (wid < 4 && lane < 32)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) tot[i] += red[(wid * TM + i) * 32 + lane];
+            __syncthreads();
+        }
+        if (wid < 4 && lane < 32)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int co = co0 + i * 32 + lane;
+                if (co < a.Cout) a.gsum[(size_t)(slab_id * 4 + wid) * a.Cout + co] = tot[i];
+            }
+    }
+    // Cross-wave reduction, one tap at a time: every wave parks its tile in LDS (b128, lane-linear), then wave w sums
+    // slice w of the NW copies in the fixed order w0 + w1 + ... and stores it -- all waves store in parallel, and the
+    // barriers are raw (LDS-only wait): a __syncthreads() here would also drain the previous tap's global stores.
+    float *slab = a.slabs + (size_t)slab_id * a.Cout * 9 * a.Cin;
+    const int r = lane & 31, h = lane >> 5;
+    constexpr int NG = TM * TN * 4;                   // float4 groups (4 consecutive accumulator registers) per tile
+    static_assert(NG % NW == 0 || NW % NG == 0, "slices");
+    float4 *red4 = reinterpret_cast<float4 *>(lds_all);
+#pragma unroll
+    for (int kj = 0; kj < 3; ++kj) {
+        if (kj) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x16 &v = acc[kj][i][j];
+                    red4[(wid * NG + (i * TN + j) * 4 + g4) * 64 + lane] = make_float4(v[4 * g4], v[4 * g4 + 1], v[4 * g4 + 2], v[4 * g4 + 3]);
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int tap = ki * 3 + kj;
+        for (int grp = wid; grp < NG; grp += NW) {     // NG = 16, 8 or 4 groups over NW = 8 or 4 waves
+            float4 sum = red4[grp * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                const float4 v = red4[(w * NG + grp) * 64 + lane];
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+            const int tile = grp >> 2, g4 = grp & 3;
+            const int i = tile / TN, j = tile - i * TN;
+            const int ci = ci0 + j * 32 + r;
+            const int co = co0 + i * 32 + 8 * g4 + 4 * h;    // registers 4*g4 .. 4*g4+3 are rows co .. co+3
+            if (ci < a.Cin) {
+                float *dst = slab + ((size_t)co * 9 + tap) * a.Cin + ci;
+                const size_t rs = (size_t)9 * a.Cin;
+                if (co + 0 < a.Cout) dst[0] = sum.x;
+                if (co + 1 < a.Cout) dst[rs] = sum.y;
+                if (co + 2 < a.Cout) dst[2 * rs] = sum.z;
+                if (co + 3 < a.Cout) dst[3 * rs] = sum.w;
+            }
+        }
+    }
+    DCF_STAMP(4);
+}
+
 }  // namespace
 
 // ================================================================== C ABI
@@ -683,14 +1252,50 @@ extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const
 
 static void wgrad_tiles(int Cin, int Cout, int &TM, int &TN) { TM = Cout >= 64 ? 2 : 1; TN = Cin >= 64 ? 2 : 1; }
 
-extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw)
+// 3x3 / stride-1 layers: tile of the row-sharing kernel; KR = kernel rows per wave
+static int wgrad3_nw()
 {
-    int TM, TN;
-    wgrad_tiles(Cin, Cout, TM, TN);
-    const int tiles = cdiv(Cout, TM * 32) * cdiv(Cin, TN * 32) * kh * kw;
+    static const char *e = getenv("DCF_WGRAD3_NW");
+    return (e && atoi(e) == 4) ? 4 : 8;
+}
+
+static bool wgrad3_dma(int Wo, int TM, int TN)
+{
+    static const char *e = getenv("DCF_WGRAD3_DMA");
+    if (e && atoi(e) == 0) return false;
+    return (Wo + 2 >= (TN == 2 ? 40 : 48)) && (TM * TN >= 2);   // a stage's rows wrap into the next image row at most once
+}
+
+static bool wgrad3_tiles(int Cin, int Cout, int kh, int kw, int stride, int &TM, int &TN, int &KR)
+{
+    static const char *off = getenv("DCF_WGRAD3");
+    if (off && atoi(off) == 0) return false;
+    if (!(kh == 3 && kw == 3 && stride == 1)) return false;
+    TM = Cout >= 64 ? 2 : 1; TN = Cin >= 64 ? 2 : 1;
+    KR = (TM == 1 && TN == 1) ? 3 : 1;
+    return true;
+}
+
+extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int stride)
+{
+    int TM, TN, KR;
+    int tiles;
+    int64_t want_blocks = 1024;                       // ~16 waves per CU in total (more splits measured slower)
+    bool dma = false;
+    if (wgrad3_tiles(Cin, Cout, kh, kw, stride, TM, TN, KR)) {
+        tiles = cdiv(Cout, TM * 32) * cdiv(Cin, TN * 32) * (3 / KR);
+        static const char *wb = getenv("DCF_WGRAD3_BLOCKS");
+        // the LDS-DMA kernel runs one workgroup per CU: one wave of workgroups (floor, not ceil)
+        dma = wgrad3_dma(Wo, TM, TN);
+        if (dma) { want_blocks = wb ? atoi(wb) : 256; if (tiles <= want_blocks) want_blocks -= tiles - 1; }
+        else want_blocks = 512;
+    } else {
+        wgrad_tiles(Cin, Cout, TM, TN);
+        tiles = cdiv(Cout, TM * 32) * cdiv(Cin, TN * 32) * kh * kw;
+    }
     const int64_t M = (int64_t)B * Ho * Wo;
     // nsplit = number of SLABS = workgroups along the pixel axis; each has 4 waves (own pixel ranges)
-    int64_t want = cdiv(1024, tiles);                 // ~16 waves per CU in total (more splits measured slower)
+    int64_t want = cdiv(want_blocks, tiles);
     int64_t maxs = (M + 511) / 512;                   // at least 4 stages of 32 pixels per wave
     if (want > maxs) want = maxs;
     // keep each layer's slab arena small: it is written once and re-read by dcf_wgrad_finalize
@@ -698,7 +1303,7 @@ extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout,
     const int64_t cap = (16ll << 20) / slab_bytes;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
-    if (want >= 44) want = (want + 4) / 8 * 8;        // multiples of 8 (>= 48) enable the XCD-aware work mapping
+    if (want >= 44) want = dma ? want / 8 * 8 : (want + 4) / 8 * 8;   // multiples of 8 (>= 48) enable the XCD-aware work mapping
     return (int)want;
 }
 
@@ -710,6 +1315,8 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
     if (rc) return rc;
     DCF_REQUIRE(x && gy && slabs && nsplit > 0, "dcf_conv2d_wgrad: bad arguments");
     WgArgs a;
+    static const char *dbg_env = getenv("DCF_WGRAD3_DBG");
+    a.dbg = dbg_env ? atoi(dbg_env) : 0;
     a.x = (const char *)x; a.gy = (const char *)gy; a.slabs = slabs; a.gsum = gsum;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
@@ -718,14 +1325,54 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
     DCF_REQUIRE((int64_t)B * H * W * a.pixbytes < 0xFFFFFF00ll && (int64_t)a.M * Cout * 4 < 0xFFFFFF00ll, "dcf_conv2d_wgrad: tensor exceeds the 4 GiB buffer-descriptor range");
     a.xbytes = (unsigned)((int64_t)B * H * W * a.pixbytes);
     a.gbytes = (unsigned)((int64_t)a.M * Cout * (dtype == DCF_F32 ? 4 : 2));
+    hipStream_t s = S(stream);
+    const double flops = 2.0 * a.M * Cout * (double)Cin * kh * kw;
+    int TM, TN, KR;
+    if (pad == 1 && H == Ho && W == Wo && wgrad3_tiles(Cin, Cout, kh, kw, stride, TM, TN, KR)) {
+        const bool dma = dtype == DCF_BF16 && wgrad3_dma(Wo, TM, TN) && (int64_t)B * H * W * a.pixbytes < (1ll << 31) && (int64_t)a.M * Cout * 2 < (1ll << 31);
+        if (dtype == DCF_F32 && TM == 2 && TN == 2) TN = 1;   // fp32 accumulators + fragments of 2x2x3 do not fit 256 VGPRs
+        a.M = B * Ho * (Wo + 2);                           // padded positions (see k_conv_wgrad3)
+        a.per_split = cdiv(cdiv(a.M, 4 * nsplit), 32) * 32;
+        a.co_tiles = cdiv(Cout, TM * 32);
+        a.ci_tiles = cdiv(Cin, TN * 32);
+        dim3 grid3(a.co_tiles * a.ci_tiles * (3 / KR) * nsplit);
+        if (dma) {
+            const int NW = wgrad3_nw();
+            a.per_split = cdiv(cdiv(a.M, NW * nsplit), 32) * 32;
+#define DCF_WG3G(TM_, TN_)                                                                                                                              \
+    do {                                                                                                                                                \
+        if (NW == 8) DCF_LAUNCH_W("conv_wgrad3g_bf16<" #TM_ "," #TN_ ",2,8>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3g<TM_, TN_, 2, 8>), grid3, dim3(512), 0, s, a)); \
+        else DCF_LAUNCH_W("conv_wgrad3g_bf16<" #TM_ "," #TN_ ",4,4>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3g<TM_, TN_, 4, 4>), grid3, dim3(256), 0, s, a));        \
+    } while (0)
+            if (TM == 2 && TN == 2) DCF_WG3G(2, 2);
+            else if (TM == 2) DCF_WG3G(2, 1);
+            else DCF_WG3G(1, 2);
+#undef DCF_WG3G
+            if (a.dbg & 2) {
+                long long tt[8];
+                hipStreamSynchronize(s);
+                hipMemcpyFromSymbol(tt, HIP_SYMBOL(g_dcf_dbg_t), sizeof(tt));
+                fprintf(stderr, "[wgrad3g %dx%d %d->%d ns=%d] clocks: prologue %lld loop %lld wait %lld epilogue %lld (100 MHz ticks x?)\n", Ho, Wo, Cin, Cout, nsplit,
+                        tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3]);
+            }
+            return DCF_OK;
+        }
+#define DCF_WG3(T_, NAME_)                                                                                                                           \
+    do {                                                                                                                                             \
+        if (KR == 3) DCF_LAUNCH_W(NAME_ "<1,1,3>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3<T_, 1, 1, 3>), grid3, dim3(256), 0, s, a));            \
+        else if (TM == 2 && TN == 2) DCF_LAUNCH_W(NAME_ "<2,2,1>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3<bf16_t, 2, 2, 1>), grid3, dim3(256), 0, s, a)); \
+        else if (TM == 2) DCF_LAUNCH_W(NAME_ "<2,1,1>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3<T_, 2, 1, 1>), grid3, dim3(256), 0, s, a));       \
+        else DCF_LAUNCH_W(NAME_ "<1,2,1>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3<T_, 1, 2, 1>), grid3, dim3(256), 0, s, a));                    \
+    } while (0)
+        if (dtype == DCF_F32) DCF_WG3(float, "conv_wgrad3_f32"); else DCF_WG3(bf16_t, "conv_wgrad3_bf16");
+#undef DCF_WG3
+        return DCF_OK;
+    }
     a.per_split = cdiv(cdiv(a.M, 4 * nsplit), 32) * 32;   // pixels per WAVE (4 waves reduce into one slab)
-    int TM, TN;
     wgrad_tiles(Cin, Cout, TM, TN);
     a.co_tiles = cdiv(Cout, TM * 32);
     a.ci_tiles = cdiv(Cin, TN * 32);
     dim3 grid(a.co_tiles * a.ci_tiles * kh * kw * nsplit);
-    hipStream_t s = S(stream);
-    const double flops = 2.0 * a.M * Cout * (double)Cin * kh * kw;
 #define DCF_WG(T_, NAME_)                                                                                                                       \
     do {                                                                                                                                        \
         if (TM == 2 && TN == 2) DCF_LAUNCH_W(NAME_ "<2,2>", flops, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 2, 2>), grid, dim3(256), 0, s, a));   \
@@ -769,6 +1416,7 @@ extern "C" int dcf_stem7x7_wgrad(int dtype, const void *img4, const void *gy, fl
 {
     DCF_REQUIRE(img4 && gy && slabs && nsplit > 0 && Cout % 32 == 0, "dcf_stem7x7_wgrad: bad arguments");
     WgArgs a;
+    a.dbg = 0;
     a.x = (const char *)img4; a.gy = (const char *)gy; a.slabs = slabs; a.gsum = gsum;
     a.B = B; a.H = H + 6; a.W = W + 8; a.Cin = 32; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
     a.kh = 7; a.kw = 1; a.stride = 2; a.pad = 0;

@@ -56,8 +56,8 @@ def conv2d_dgrad(dtype, gy, wt, res, in_shape, kh, kw, stride, pad, mask=None):
     return gx
 
 
-def conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, kh, kw):
-    return H.lib().dcf_conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, kh, kw)
+def conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, kh, kw, stride=1):
+    return H.lib().dcf_conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, kh, kw, stride)
 
 
 def conv2d_wgrad(dtype, x, gy, slabs, nsplit, kh, kw, stride, pad, gsum=None):

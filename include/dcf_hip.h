@@ -110,7 +110,7 @@ int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const void *res,
  * gsum (optional) fp32 [4*nsplit][Cout]: per-wave sums over pixels of gy (dL/dbeta of a folded BN),
  * accumulated by the same kernel from the gy fragments it already holds.
  * nsplit = dcf_conv2d_wgrad_splits(...). */
-int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw);
+int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int stride);
 int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float *slabs, float *gsum, int nsplit,
                      int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
                      dcf_stream_t stream);

@@ -22,6 +22,13 @@ SHAPES = [
     (2, 14, 10, 64, 96, 1, 2),
     (1, 24, 16, 256, 192, 1, 1),
     (1, 40, 52, 32, 32, 3, 1),
+    # 3x3/s1 layers wide enough for the LDS-DMA weight-gradient kernel (Wo + 2 >= 40 resp. 48)
+    (2, 12, 40, 64, 64, 3, 1),
+    (1, 9, 47, 96, 160, 3, 1),       # partial channel tiles on both operands
+    (2, 7, 50, 128, 64, 3, 1),
+    (1, 20, 46, 32, 64, 3, 1),       # 64 x 32 tile
+    (2, 5, 61, 64, 32, 3, 1),        # 32 x 64 tile
+    (3, 33, 75, 64, 64, 3, 1),       # many stages per wave, ranges crossing image boundaries
 ]
 
 
@@ -96,7 +103,7 @@ def test_conv_wgrad(shape, dtype):
     gy = q(rnd(tuple(y.shape), 32), dtype)
     y.backward(gy)
     Ho, Wo = y.shape[-2:]
-    ns = ops.conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, k, k)
+    ns = ops.conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, k, k, s)
     assert ns >= 1
     slabs = torch.full((ns, Cout, k, k, Cin), float("nan"), device="cuda")
     ops.conv2d_wgrad(dtype, to_dev(x, dtype), to_dev(gy, dtype), slabs, ns, k, k, s, pad)
@@ -138,7 +145,7 @@ def test_stem7x7(dtype):
     out = F.conv2d(xf, wv, None, 2, 3)
     gy = q(rnd(tuple(out.shape), 42), dtype)
     out.backward(gy)
-    ns = ops.conv2d_wgrad_splits(B, out.shape[2], out.shape[3], 32, Cout, 7, 1)
+    ns = ops.conv2d_wgrad_splits(B, out.shape[2], out.shape[3], 32, Cout, 7, 1, 2)
     slabs = torch.zeros((ns, Cout, 7, 8, 4), device="cuda")
     ops.stem7x7_wgrad(dtype, img4, to_dev(gy, dtype), slabs, ns, Hh, W)
     G = slabs.sum(0).cpu()[:, :, :7, :3].permute(0, 3, 1, 2)

@@ -46,7 +46,7 @@ def main():
         w = ((torch.rand((Co, k, k, Ci), device="cuda") - 0.5) * 0.1).to(td)
         wt = w.permute(3, 1, 2, 0).contiguous()
         gy = (torch.rand((B, Ho, Wo, Co), device="cuda") - 0.5).to(td)
-        ns = ops.conv2d_wgrad_splits(B, Ho, Wo, Ci, Co, k, k)
+        ns = ops.conv2d_wgrad_splits(B, Ho, Wo, Ci, Co, k, k, s)
         slabs = torch.empty((ns, Co, k, k, Ci), device="cuda")
         fl = 2.0 * B * Ho * Wo * Co * Ci * k * k
         byt = (x.numel() + gy.numel()) * es

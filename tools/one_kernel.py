@@ -16,7 +16,7 @@ x = (torch.rand((B, Hh, W, Ci), device="cuda") - 0.5).to(td)
 w = ((torch.rand((Co, k, k, Ci), device="cuda") - 0.5) * 0.1).to(td)
 wt = w.permute(3, 1, 2, 0).contiguous()
 gy = (torch.rand((B, Ho, Wo, Co), device="cuda") - 0.5).to(td)
-ns = ops.conv2d_wgrad_splits(B, Ho, Wo, Ci, Co, k, k)
+ns = ops.conv2d_wgrad_splits(B, Ho, Wo, Ci, Co, k, k, s)
 slabs = torch.empty((ns, Co, k, k, Ci), device="cuda")
 for _ in range(5):
     if kind == "fwd":
