@@ -24,6 +24,7 @@
 // used by the parity tests against the reference's fp32 CPU path).  fp32 accumulate.
 #include <stdlib.h>
 
+#include <algorithm>
 #include "dcf_common.h"
 
 namespace {
@@ -113,10 +114,15 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
     int m0 = mt * BM;                              // first (class-local when PAR) pixel of this tile
     int ph = 0, pw = 0, clsM = a.M;               // parity class of the tile, pixels in the class
     if (PAR) {
-        const int cls = (mt >= a.cls_tile[1]) + (mt >= a.cls_tile[2]) + (mt >= a.cls_tile[3]);
+        // The four classes of one image region sit next to each other in the tile list, i.e. on the same XCD at about
+        // the same time: the half-line stores of horizontally adjacent pixels (a pixel narrower than a 128-B line
+        // belongs to a different class than its neighbour) then meet in that XCD's L2 instead of reaching memory
+        // as two partial writes from two L2s.
+        const int cls = mt & 3;
         ph = cls >> 1; pw = cls & 1;
-        m0 = (mt - a.cls_tile[cls]) * BM;
+        m0 = (mt >> 2) * BM;
         clsM = a.B * a.cls_h[ph] * a.cls_w[pw];
+        if (m0 >= clsM) return;
     }
     // class-local pixel index -> linear output pixel (identity without parity classes), -1 past the end
     auto out_pixel = [&](int m) -> int {
@@ -327,10 +333,10 @@ int launch_igemm(const ConvArgs &a_in, hipStream_t s, const char *base, double f
         constexpr int BN_ = WN_ * TN_ * 32, BM_ = WM_ * TM_ * 32;                                                   \
         ConvArgs a = a_in;                                                                                          \
         int mtiles = cdiv(a.M, BM_);                                                                                \
-        if (a.parity) {                                                                                             \
-            a.cls_tile[0] = 0;                                                                                      \
-            for (int c = 0; c < 4; ++c) a.cls_tile[c + 1] = a.cls_tile[c] + cdiv((int64_t)a.B * a.cls_h[c >> 1] * a.cls_w[c & 1], BM_); \
-            mtiles = a.cls_tile[4];                                                                                 \
+        if (a.parity) {   /* tile list = (region, class) with the class fastest; every class gets the largest class's count */ \
+            int mx = 0;                                                                                             \
+            for (int c = 0; c < 4; ++c) mx = std::max(mx, cdiv((int64_t)a.B * a.cls_h[c >> 1] * a.cls_w[c & 1], BM_)); \
+            a.cls_tile[4] = mtiles = 4 * mx;                                                                        \
         }                                                                                                           \
         dim3 grid((((int64_t)mtiles * (a.Cn / BN_) + 7) / 8) * 8);                                                  \
         const bool db = (int64_t)mtiles * (a.Cn / BN_) <= 512;   /* <= 2 workgroups per CU: 1-barrier pipeline */   \
@@ -1233,8 +1239,10 @@ extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const
     ConvArgs a;
     a.x = (const char *)gy; a.w = (const char *)wt; a.shift = nullptr; a.res = (const char *)res; a.y = (char *)gx;
     a.mask = (const char *)mask;
-    // class-major order writes every other pixel of a row: only worth it when one pixel is a whole 128-B line
-    a.parity = (stride == 2 && Cin * (dtype == DCF_F32 ? 4 : 2) >= 128) ? 1 : 0;
+    static const char *par_env = getenv("DCF_DGRAD_PARITY");     // experiments: 0 = off, 1 = all stride-2 layers, 2 = full-line pixels only
+    const int par_mode = par_env ? atoi(par_env) : 1;
+    // (a 1x1 stride-2 layer has one live class and three that only store zeros: one plain pass is cheaper)
+    a.parity = (stride == 2 && kh * kw > 1 && par_mode && (par_mode == 1 || Cin * (dtype == DCF_F32 ? 4 : 2) >= 128)) ? 1 : 0;
     for (int p = 0; p < 2; ++p) {       // rows / columns of dX whose (index + pad) has parity p
         a.cls_h0[p] = (p + pad) & 1; a.cls_w0[p] = (p + pad) & 1;
         a.cls_h[p] = (H - a.cls_h0[p] + 1) / 2; a.cls_w[p] = (W - a.cls_w0[p] + 1) / 2;
