@@ -910,25 +910,26 @@ __global__ void __launch_bounds__(256, 2) k_conv_wgrad3(WgArgs a)
 //   * DMA image is lane-linear (1 KiB = 8 rows x 128 B per instruction), so rows have no pad;
 //     128-B rows are XOR-swizzled (64-B half ^= row bit 1) on the SOURCE address and on the
 //     transposed reads, which keeps the 4 rows of a ds_read_b64_tr_b16 group on distinct banks.
-//   * padding, junk rows and masked channels read a 16-byte zero page instead of being skipped.
+//   * padding, junk rows and masked channels are out-of-range buffer offsets: the DMA writes zeros for them.
 // bf16 only; Wo + 2 >= the rows one stage loads (40 or 48).
 // ------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(16))) unsigned g_dcf_zero16[4];
 __device__ long long g_dcf_dbg_t[8];     // DCF_WGRAD3_DBG & 2: phase timestamps (s_memtime) of workgroup 0, wave 0
 #define DCF_STAMP(i) do { if ((a.dbg & 2) && blockIdx.x == 0 && threadIdx.x == 0) g_dcf_dbg_t[i] = clock64(); } while (0)
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// One LDS-DMA instruction: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_dst, lds_dst + 1024).
+// One LDS-DMA instruction: 64 lanes x 16 B, lane l from buffer offset voff[l], to LDS bytes [lds_dst, lds_dst + 1024).
+// A lane whose offset is outside the descriptor's range has ZEROS written for it (probed on MI355X:
+// tools/probe/lds_dma_oob.hip) -- padding, junk rows and masked channels cost one v_cndmask.
 // Inline asm on purpose: hipcc counts a *builtin* LDS-DMA as a pending LDS write and drains it with vmcnt(0)
 // before the next ds_read, which would serialise the ring; an asm one is ours to count (wait_vmcnt above).
 // M0 (the DMA destination base) is compiler-reserved: saved and restored inside the statement.
-__device__ __forceinline__ void glds16(const char *src, unsigned lds_dst)
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_dst)
 {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(src), "s"(lds_dst)
+                 : "v"(voff), "s"(rsrc), "s"(lds_dst)
                  : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr(const void *p)
@@ -963,14 +964,21 @@ __global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g(WgArgs a)
     char *ldsB = ldsA + NS * SA;
     const unsigned ldsA0 = lds_addr(ldsA), ldsB0 = lds_addr(ldsB);
 
-    const int ninner = a.co_tiles * a.ci_tiles * 3;
-    const int L = blockIdx.x;
-    const bool xcd = ((a.nsplit & 7) == 0) && (a.nsplit >= 48);
-    const int slab_id = xcd ? (L / (8 * ninner)) * 8 + (L & 7) : L / ninner;
-    int t = xcd ? (L >> 3) % ninner : L % ninner;
-    const int ki = t % 3; t /= 3;
-    const int cit = t % a.ci_tiles;
-    const int cot = t / a.ci_tiles;
+    // XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs and this kernel runs one workgroup per
+    // CU, so XCD x = blockIdx % 8 owns the x-th contiguous run of the unit list, a unit being the three kernel rows of
+    // one (position range, co tile, ci tile), ranges slowest: the workgroups that re-read a range's gy / x rows
+    // (3 * co_tiles * ci_tiles of them) sit on one or two XCDs and find them in that L2 instead of each of the eight
+    // XCDs pulling its own copy of every range over the fabric.
+    const int tiles2 = a.co_tiles * a.ci_tiles;
+    const int units = tiles2 * a.nsplit, upx = (units + 7) >> 3;
+    const int slot = blockIdx.x >> 3;
+    const int unit = (blockIdx.x & 7) * upx + slot / 3;
+    if (unit >= units) return;
+    const int ki = slot % 3;
+    const int slab_id = unit / tiles2;
+    const int t2 = unit - slab_id * tiles2;
+    const int cit = t2 % a.ci_tiles;
+    const int cot = t2 / a.ci_tiles;
     const int co0 = cot * TM * 32, ci0 = cit * TN * 32;
     const int Wp = a.Wo + 2, BH = a.B * a.Ho;
     const int split = slab_id * NW + wid;
@@ -1001,9 +1009,11 @@ __global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g(WgArgs a)
     const int chA = (RA == 128) ? ((lane % LPA) ^ (((lrA >> 1) & 1) << 2)) : (lane % LPA);
     const int chB = (RB == 128) ? ((lane % LPB) ^ (((lrB >> 1) & 1) << 2)) : (lane % LPB);
     const bool chokA = (chA * 16 < coutA) & !(a.dbg & 1), chokB = (chB * 16 < cinB) & !(a.dbg & 1);
-    const char *gyb = opaque(a.gy + co0 * 2 + chA * 16 + (size_t)lrA * rowA);
-    const char *xb = opaque(a.x + ci0 * 2 + chB * 16 + (size_t)lrB * a.pixbytes);
-    const char *zero = reinterpret_cast<const char *>(g_dcf_zero16);
+    const __amdgpu_buffer_rsrc_t srcG = __builtin_amdgcn_make_buffer_rsrc((void *)a.gy, 0, a.gbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srcX = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFF00u;
+    const int laneA = opaque(co0 * 2 + chA * 16 + lrA * rowA);
+    const int laneB = opaque(ci0 * 2 + chB * 16 + lrB * a.pixbytes);
     const int lrAo = opaque(lrA), lrBo = opaque(lrB);
     const int wrapA = opaque(2 * rowA), wrapB = opaque(2 * a.pixbytes);
     int sq = q_begin;                                    // scalar state: gy rows start at position sq, x rows at sq - 1
@@ -1011,8 +1021,8 @@ __global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g(WgArgs a)
     int xR, xC, xOh;
     if (q_begin == 0) { xR = -1; xC = Wp - 1; xOh = a.Ho - 1; }
     else { xR = (q_begin - 1) / Wp; xC = (q_begin - 1) - xR * Wp; xOh = xR % a.Ho; }
-    auto issue = [&](int slot) {
-        const unsigned sa = __builtin_amdgcn_readfirstlane(ldsA0 + slot * SA), sb = __builtin_amdgcn_readfirstlane(ldsB0 + slot * SB);
+    auto issue = [&](int is) {
+        const unsigned sa = __builtin_amdgcn_readfirstlane(ldsA0 + is * SA), sb = __builtin_amdgcn_readfirstlane(ldsB0 + is * SB);
         {
             const int rem = q_end - sq;
             const int base = __builtin_amdgcn_readfirstlane((sR * a.Wo + sC - 1) * rowA);   // may be < 0 (lane rows make it valid); tensors < 2 GiB
@@ -1023,8 +1033,8 @@ __global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g(WgArgs a)
                 const bool w = c >= Wp;
                 const int cc = w ? c - Wp : c;
                 const bool ok = chokA & (lrAo < rem - j * RPA) & ((unsigned)(cc - 1) < (unsigned)a.Wo);
-                const int off = (base + j * RPA * rowA) - (w ? wrapA : 0);
-                glds16(ok ? gyb + (ptrdiff_t)off : zero, sa + j * 1024);
+                const int off = laneA + (base + j * RPA * rowA) - (w ? wrapA : 0);
+                glds16(srcG, ok ? (unsigned)off : OOB, sa + j * 1024);
             }
         }
         {
@@ -1041,8 +1051,8 @@ __global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g(WgArgs a)
                 const bool w = c >= Wp;
                 const int cc = w ? c - Wp : c;
                 const bool ok = chokB & (lrBo < XROWS - j * RPB) & ((unsigned)(cc - 1) < (unsigned)a.Wo) & (w ? ok1 : ok0);
-                const int off = (base + j * RPB * a.pixbytes) - (w ? wrapB : 0);
-                glds16(ok ? xb + (ptrdiff_t)off : zero, sb + j * 1024);
+                const int off = laneB + (base + j * RPB * a.pixbytes) - (w ? wrapB : 0);
+                glds16(srcX, ok ? (unsigned)off : OOB, sb + j * 1024);
             }
         }
         sq += PK;
@@ -1067,7 +1077,7 @@ __global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g(WgArgs a)
 #pragma unroll
     for (int s0 = 0; s0 < NS - 1; ++s0)
         if (s0 < nst) issue(s0);
-    int slot = 0, islot = NS - 1;
+    int rslot = 0, islot = NS - 1;
     DCF_STAMP(1);
     for (int n = 0; n < nst; ++n) {
         if (n + NS - 1 < nst) issue(islot);
@@ -1076,7 +1086,7 @@ __global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g(WgArgs a)
         else if (NS > 3 && ahead == 2) wait_vmcnt<2 * GI>();
         else if (NS > 2 && ahead == 1) wait_vmcnt<1 * GI>();
         else wait_vmcnt<0>();
-        const char *pa = ldsA + slot * SA, *pb = ldsB + slot * SB;
+        const char *pa = ldsA + rslot * SA, *pb = ldsB + rslot * SB;
 #pragma unroll
         for (int ks = 0; ks < PK / 16; ++ks) {
             uint4 fa[TM];
@@ -1115,7 +1125,7 @@ __global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g(WgArgs a)
                 }
             }
         }
-        slot = slot + 1 == NS ? 0 : slot + 1;
+        rslot = rslot + 1 == NS ? 0 : rslot + 1;
         islot = islot + 1 == NS ? 0 : islot + 1;
     }
 
@@ -1295,7 +1305,8 @@ extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout,
         static const char *wb = getenv("DCF_WGRAD3_BLOCKS");
         // the LDS-DMA kernel runs one workgroup per CU: one wave of workgroups (floor, not ceil)
         dma = wgrad3_dma(Wo, TM, TN);
-        if (dma) { want_blocks = wb ? atoi(wb) : 256; if (tiles <= want_blocks) want_blocks -= tiles - 1; }
+        // LDS-DMA kernel: one workgroup per CU, 32 CUs per XCD, 3 workgroups per unit -> 10 units per XCD, 80 in all
+        if (dma) { want_blocks = wb ? atoi(wb) : 240; if (tiles <= want_blocks) want_blocks -= tiles - 1; }
         else want_blocks = 512;
     } else {
         wgrad_tiles(Cin, Cout, TM, TN);
@@ -1311,7 +1322,7 @@ extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout,
     const int64_t cap = (16ll << 20) / slab_bytes;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
-    if (want >= 44) want = dma ? want / 8 * 8 : (want + 4) / 8 * 8;   // multiples of 8 (>= 48) enable the XCD-aware work mapping
+    if (want >= 44 && !dma) want = (want + 4) / 8 * 8;   // multiples of 8 (>= 48) enable the generic kernel's XCD-aware work mapping
     return (int)want;
 }
 
@@ -1347,6 +1358,7 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
         if (dma) {
             const int NW = wgrad3_nw();
             a.per_split = cdiv(cdiv(a.M, NW * nsplit), 32) * 32;
+            grid3 = dim3(8 * 3 * cdiv(a.co_tiles * a.ci_tiles * nsplit, 8));    // see the kernel's work mapping
 #define DCF_WG3G(TM_, TN_)                                                                                                                              \
     do {                                                                                                                                                \
         if (NW == 8) DCF_LAUNCH_W("conv_wgrad3g_bf16<" #TM_ "," #TN_ ",2,8>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3g<TM_, TN_, 2, 8>), grid3, dim3(512), 0, s, a)); \
