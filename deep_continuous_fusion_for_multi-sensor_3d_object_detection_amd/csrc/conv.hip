@@ -52,9 +52,41 @@ struct ConvArgs {
     int cls_tile[5];          // first pixel-tile of each class (prefix sums), in tiles of the launch's BM
     int cls_h[2], cls_w[2];   // rows / columns per parity
     int cls_h0[2], cls_w0[2]; // first row / column of each parity
+    int dbg;                  // experiments only (DCF_IGEMM_DBG)
 };
 
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+
+// ---- LDS-DMA helpers (used by k_conv_igemm_dma and k_conv_wgrad3g)
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// One LDS-DMA instruction: 64 lanes x 16 B, lane l from buffer offset voff[l], to LDS bytes [lds_dst, lds_dst + 1024).
+// A lane whose offset is outside the descriptor's range has ZEROS written for it (probed on MI355X:
+// tools/probe/lds_dma_oob.hip) -- padding, junk rows and masked channels cost one v_cndmask.
+// Inline asm on purpose: hipcc counts a *builtin* LDS-DMA as a pending LDS write and drains it with vmcnt(0)
+// before the next ds_read, which would serialise the ring; an asm one is ours to count (wait_vmcnt above).
+// M0 (the DMA destination base) is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+}
+
+template <typename V> __device__ __forceinline__ V opaque(V v) { asm volatile("" : "+v"(v)); return v; }   // stop re-derivation of lane constants
+
+__device__ long long g_dcf_dbg_t[8];     // DCF_WGRAD3_DBG / DCF_IGEMM_DBG & 2: phase timestamps (s_memtime) of workgroup 0, wave 0
+#define DCF_STAMP(i) do { if ((a.dbg & 2) && blockIdx.x == 0 && threadIdx.x == 0) g_dcf_dbg_t[i] = clock64(); } while (0)
+// DBG & 4: first start / last end over ALL workgroups on the 100 MHz wall clock, plus the sum of workgroup lifetimes
+__device__ unsigned long long g_dcf_dbg_w[4];
+#define DCF_WSTART() long long w_start__ = 0; do { if ((a.dbg & 4) && threadIdx.x == 0) { w_start__ = wall_clock64(); atomicMin(&g_dcf_dbg_w[0], (unsigned long long)w_start__); } } while (0)
+#define DCF_WEND() do { if ((a.dbg & 4) && threadIdx.x == 0) { const long long e__ = wall_clock64(); atomicMax(&g_dcf_dbg_w[1], (unsigned long long)e__); atomicAdd(&g_dcf_dbg_w[2], (unsigned long long)(e__ - w_start__)); atomicMax(&g_dcf_dbg_w[3], (unsigned long long)(e__ - w_start__)); } } while (0)
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -98,6 +130,8 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wn = wid / WM, wm = wid % WM;
     const int r = lane & 31, h = lane >> 5;
+    DCF_STAMP(0);
+    DCF_WSTART();
     // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, so XCD x takes
     // the x-th contiguous chunk of the (pixel-tile, channel-tile) list, channel tiles fastest: vertically
     // adjacent pixel tiles (shared halo rows) and the channel tiles of one pixel tile (same input rows)
@@ -251,11 +285,13 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
                 for (int j = 0; j < TM; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
         }
     };
+    DCF_STAMP(1);
     if (nit > 0) {
         set_tap(ki, kj);
         load_global(koff(), 0);
         store_lds(0);
     }
+    DCF_STAMP(2);
     if constexpr (DB) {
         // while the MFMAs of chunk `it` run out of buffer it&1, chunk it+1 (already in registers) is written to
         // the other buffer and chunk it+2 is requested from L2
@@ -283,6 +319,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
         }
     }
 
+    DCF_STAMP(3);
     // epilogue: lane (pixel r, half h) holds channels 8q+4h+{0..3} of each 32-channel tile.
     //   v = acc + shift + res ; relu ; (dgrad only) v *= (mask > 0), i.e. the ReLU backward of the
     //   layer that PRODUCED this tensor (its dbeta sums come out of the wgrad kernel).
@@ -318,6 +355,224 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
             }
         }
     }
+    DCF_STAMP(4);
+    DCF_WEND();
+}
+
+// ------------------------------------------------------------------------------------
+// forward / dgrad kernel with LDS-DMA staging (bf16, K chunks of 128 B).  Same tiling, tap walk, XCD-aware tile order,
+// parity classes and epilogue as k_conv_igemm; what changes is how a K chunk reaches LDS: `buffer_load ... lds` pieces
+// (8 rows x 128 B, out-of-range rows = zero padding) fill an NS-deep ring NS-1 chunks ahead of the MFMAs, so the
+// dependent chain load -> ds_write -> barrier -> ds_read of the register-staged kernel (about 900 clocks per chunk on the
+// small-M layers, against 128 clocks of MFMA) is off the critical path.  One raw barrier per chunk:
+//     wait own pieces of chunk i (counted vmcnt) -> s_barrier -> issue chunk i+NS-1 into the slot chunk i-1 just left -> MFMAs.
+// LDS rows have no pad (the DMA image is lane-linear): 16-B chunk c of row R sits at position c ^ ((R >> 1) & 7), which
+// keeps the 16 rows of a ds_read_b128 lane group on distinct banks; the swizzle is applied to the source chunk and to the reads.
+// ------------------------------------------------------------------------------------
+template <int TN, int TM, int WN, int WM, bool TRANSPOSED, int NS>
+__global__ void __launch_bounds__(256) k_conv_igemm_dma(ConvArgs a)
+{
+    typedef bf16_t T;
+    constexpr int ES = 2, KB = 128;
+    constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
+    constexpr int PW = BN / 32, PX = BM / 32;          // DMA pieces (8 rows) per wave and chunk: weights, pixels
+    constexpr int PPW = PW + PX;
+    constexpr int STAGE = (BN + BM) * KB;
+    static_assert((NS - 1) * PPW < 64, "vmcnt range");
+    __shared__ __attribute__((aligned(1024))) char lds[NS * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wid / WM, wm = wid % WM;
+    const int r = lane & 31, h = lane >> 5;
+    DCF_STAMP(0);
+    DCF_WSTART();
+    const int nt = a.Cn / BN;
+    const bool PAR = TRANSPOSED && a.parity;
+    const int mtiles = PAR ? a.cls_tile[4] : cdiv_dev(a.M, BM);
+    const int nblk = mtiles * nt;
+    const int chunk = (nblk + 7) >> 3;
+    const int gidx = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (gidx >= nblk) return;
+    const int n0 = (gidx % nt) * BN;
+    const int mt = gidx / nt;
+    int m0 = mt * BM;
+    int ph = 0, pw = 0, clsM = a.M;
+    if (PAR) {
+        const int cls = mt & 3;
+        ph = cls >> 1; pw = cls & 1;
+        m0 = (mt >> 2) * BM;
+        clsM = a.B * a.cls_h[ph] * a.cls_w[pw];
+        if (m0 >= clsM) return;
+    }
+    auto out_pixel = [&](int m) -> int {
+        if (m >= clsM) return -1;
+        if (!PAR) return m;
+        const int hwc = a.cls_h[ph] * a.cls_w[pw];
+        const int b = m / hwc;
+        const int rem = m - b * hwc;
+        const int i = rem / a.cls_w[pw], j = rem - i * a.cls_w[pw];
+        return (b * a.Ho + a.cls_h0[ph] + 2 * i) * a.Wo + a.cls_w0[pw] + 2 * j;
+    };
+    const int taps = a.kh * a.kw;
+    const int rowbytes = a.Ck * ES;
+    const int cchunks = rowbytes / KB;
+    const __amdgpu_buffer_rsrc_t srcX = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srcW = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.wbytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFF00u;
+    const unsigned lds0 = lds_addr(lds);
+
+    // DMA side: wave w owns weight pieces w*PW.. and pixel pieces w*PX..; lane = (row l8 of the piece, position chunk lc)
+    const int l8 = lane >> 3, lc = lane & 7;
+    unsigned woff[PW];
+    int xb[PX], xh[PX], xw[PX];
+    unsigned xoff[PX];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int row = (wid * PW + i) * 8 + l8;
+        woff[i] = (unsigned)(n0 + row) * (unsigned)(taps * rowbytes) + (unsigned)((lc ^ ((row >> 1) & 7)) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        const int row = (wid * PX + i) * 8 + l8;
+        const int m = out_pixel(m0 + row);
+        xoff[i] = (unsigned)((lc ^ ((row >> 1) & 7)) * 16);
+        if (m >= 0) {
+            const int b = m / (a.Ho * a.Wo);
+            const int rem = m - b * (a.Ho * a.Wo);
+            const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+            xb[i] = b * a.Hi * a.Wi;
+            if (TRANSPOSED) { xh[i] = oh + a.pad; xw[i] = ow + a.pad; }
+            else { xh[i] = oh * a.stride - a.pad; xw[i] = ow * a.stride - a.pad; }
+        } else {
+            xb[i] = -1; xh[i] = 0; xw[i] = 0;
+        }
+    }
+    unsigned pix[PX];
+    auto set_tap = [&](int ki, int kj) {
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            int ih, iw;
+            bool ok = xb[i] >= 0;
+            if (TRANSPOSED) {
+                const int th = xh[i] - ki, tw = xw[i] - kj;
+                ok = ok && (th >= 0) && (tw >= 0);
+                if (a.stride == 2) { ok = ok && !((th | tw) & 1); ih = th >> 1; iw = tw >> 1; }
+                else { ih = th; iw = tw; }
+                ok = ok && (ih < a.Hi) && (iw < a.Wi);
+            } else {
+                ih = xh[i] + ki; iw = xw[i] + kj;
+                ok = ok && (ih >= 0) && (ih < a.Hi) && (iw >= 0) && (iw < a.Wi);
+            }
+            pix[i] = ok ? (unsigned)(xb[i] + ih * a.Wi + iw) * (unsigned)a.pixbytes + xoff[i] : OOB;
+        }
+    };
+    const int tstep = PAR ? 2 : 1;
+    const int nki = PAR ? (a.kh - ph + 1) / 2 : a.kh, nkj = PAR ? (a.kw - pw + 1) / 2 : a.kw;
+    const int nit = nki * nkj * cchunks;
+    int ki = ph, kj = pw, cc = 0;
+    auto advance = [&]() {
+        if (++cc == cchunks) {
+            cc = 0;
+            kj += tstep;
+            if (kj >= a.kw) { kj = pw; ki += tstep; }
+            set_tap(ki, kj);
+        }
+    };
+    auto issue = [&](int slot) {      // chunk (ki, kj, cc) -> ring slot
+        const unsigned koff = (unsigned)((ki * a.kw + kj) * cchunks + cc) * KB, ccoff = (unsigned)cc * KB;
+        const unsigned dw = __builtin_amdgcn_readfirstlane(lds0 + slot * STAGE + wid * PW * 1024);
+        const unsigned dx = __builtin_amdgcn_readfirstlane(lds0 + slot * STAGE + BN * KB + wid * PX * 1024);
+#pragma unroll
+        for (int i = 0; i < PW; ++i) glds16(srcW, woff[i] + koff, dw + i * 1024);
+#pragma unroll
+        for (int i = 0; i < PX; ++i) glds16(srcX, pix[i] == OOB ? OOB : pix[i] + ccoff, dx + i * 1024);
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    // read side: row r of every 32-row tile has swizzle key (r >> 1) & 7; k-step ks, lane half h wants source chunk 2 ks + h
+    const int key = (r >> 1) & 7;
+    const int rdW = (wn * TN * 32 + r) * KB, rdX = BN * KB + (wm * TM * 32 + r) * KB;
+    int swz[KB / 32];
+#pragma unroll
+    for (int ks = 0; ks < KB / 32; ++ks) swz[ks] = ((2 * ks + h) ^ key) * 16;
+    auto compute = [&](int slot) {
+        const char *base = lds + slot * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < KB / 32; ++ks) {
+            uint4 fa[TN], fb[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) fa[i] = *reinterpret_cast<const uint4 *>(base + rdW + i * 32 * KB + swz[ks]);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) fb[j] = *reinterpret_cast<const uint4 *>(base + rdX + j * 32 * KB + swz[ks]);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+    };
+
+    DCF_STAMP(1);
+    if (nit > 0) set_tap(ki, kj);
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+        if (s0 < nit) { if (s0) advance(); issue(s0); }
+    DCF_STAMP(2);
+    int slot = 0, islot = NS - 1;
+    for (int it = 0; it < nit; ++it) {
+        const int ahead = min(NS - 2, nit - 1 - it);       // chunks issued after chunk `it` that may stay in flight
+        if (ahead >= 2) wait_vmcnt<(NS > 3 ? 2 : 0) * PPW>();
+        else if (ahead == 1) wait_vmcnt<(NS > 2 ? 1 : 0) * PPW>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                       // everyone's pieces of chunk `it` landed; chunk it-1 fully consumed
+        if (it + NS - 1 < nit) { advance(); issue(islot); }
+        compute(slot);
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        islot = islot + 1 == NS ? 0 : islot + 1;
+    }
+
+    DCF_STAMP(3);
+    T *y = reinterpret_cast<T *>(a.y);
+    const T *res = reinterpret_cast<const T *>(a.res);
+    const T *mask = reinterpret_cast<const T *>(a.mask);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = out_pixel(m0 + (wm * TM + j) * 32 + r);
+        if (m < 0) continue;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = n0 + (wn * TN + i) * 32 + 8 * q + 4 * h;
+                float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                if (a.shift) {
+                    const float4 s = *reinterpret_cast<const float4 *>(a.shift + c);
+                    v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+                }
+                const size_t o = (size_t)m * a.Cn + c;
+                if (res) {
+                    const float4 rr = ld4(res + o);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
+                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (mask) {
+                    const float4 mm = ld4(mask + o);
+                    v.x = mm.x > 0.f ? v.x : 0.f; v.y = mm.y > 0.f ? v.y : 0.f;
+                    v.z = mm.z > 0.f ? v.z : 0.f; v.w = mm.w > 0.f ? v.w : 0.f;
+                }
+                st4(y + o, v);
+            }
+        }
+    }
+    DCF_STAMP(4);
+    DCF_WEND();
 }
 
 template <typename T, bool TR>
@@ -332,6 +587,8 @@ int launch_igemm(const ConvArgs &a_in, hipStream_t s, const char *base, double f
     do {                                                                                                            \
         constexpr int BN_ = WN_ * TN_ * 32, BM_ = WM_ * TM_ * 32;                                                   \
         ConvArgs a = a_in;                                                                                          \
+        static const char *dbg_env = getenv("DCF_IGEMM_DBG");                                                       \
+        a.dbg = dbg_env ? atoi(dbg_env) : 0;                                                                        \
         int mtiles = cdiv(a.M, BM_);                                                                                \
         if (a.parity) {   /* tile list = (region, class) with the class fastest; every class gets the largest class's count */ \
             int mx = 0;                                                                                             \
@@ -341,8 +598,32 @@ int launch_igemm(const ConvArgs &a_in, hipStream_t s, const char *base, double f
         dim3 grid((((int64_t)mtiles * (a.Cn / BN_) + 7) / 8) * 8);                                                  \
         const bool db = (int64_t)mtiles * (a.Cn / BN_) <= 512;   /* <= 2 workgroups per CU: 1-barrier pipeline */   \
         snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d%s>", base, KB_, TN_, TM_, WN_, WM_, db ? ",db" : "");        \
-        if (db) DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR, true>), grid, dim3(256), 0, s, a)); \
+        if (a.dbg & 4) {                                                                                            \
+            unsigned long long w[4] = {~0ull, 0, 0, 0};                                                             \
+            hipMemcpyToSymbol(HIP_SYMBOL(g_dcf_dbg_w), w, sizeof(w));                                               \
+        }                                                                                                           \
+        constexpr int NS_ = (BN_ + BM_) <= 128 ? 4 : 3;                                                              \
+        static const char *dma_env = getenv("DCF_IGEMM_DMA");                                                       \
+        const int dma_mode = dma_env ? atoi(dma_env) : 1;      /* 0 off, 1 small-M tiles, 2 every bf16 KB=128 launch */ \
+        if (ES == 2 && KB_ == 128 && dma_mode && (dma_mode == 2 || db)) {                                            \
+            snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d,dma%d>", base, KB_, TN_, TM_, WN_, WM_, NS_);            \
+            DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm_dma<TN_, TM_, WN_, WM_, TR, NS_>), grid, dim3(256), 0, s, a)); \
+        } else if (db) DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR, true>), grid, dim3(256), 0, s, a)); \
         else DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR, false>), grid, dim3(256), 0, s, a)); \
+        if (a.dbg & 4) {                                                                                            \
+            unsigned long long w[4];                                                                                \
+            hipStreamSynchronize(s);                                                                                \
+            hipMemcpyFromSymbol(w, HIP_SYMBOL(g_dcf_dbg_w), sizeof(w));                                             \
+            fprintf(stderr, "[%s M=%d Ck=%d Cn=%d taps=%d blocks=%d] span %.2f us, mean workgroup life %.2f us, max %.2f us\n", name, a.M, a.Ck, a.Cn, a.kh * a.kw, (int)grid.x, \
+                    (w[1] - w[0]) * 0.01, w[2] * 0.01 / grid.x, w[3] * 0.01);                                       \
+        }                                                                                                           \
+        if (a.dbg & 2) {                                                                                            \
+            long long tt[8];                                                                                        \
+            hipStreamSynchronize(s);                                                                                \
+            hipMemcpyFromSymbol(tt, HIP_SYMBOL(g_dcf_dbg_t), sizeof(tt));                                           \
+            fprintf(stderr, "[%s M=%d Ck=%d Cn=%d taps=%d blocks=%d] clocks: setup %lld first-stage %lld loop %lld epilogue %lld\n", name, a.M, a.Ck, a.Cn, a.kh * a.kw, (int)grid.x, \
+                    tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3]);                                    \
+        }                                                                                                           \
         return DCF_OK;                                                                                              \
     } while (0)
     // tile choice: the biggest tile that still gives the chip >= ~1 workgroup per CU
@@ -913,31 +1194,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_wgrad3(WgArgs a)
 //   * padding, junk rows and masked channels are out-of-range buffer offsets: the DMA writes zeros for them.
 // bf16 only; Wo + 2 >= the rows one stage loads (40 or 48).
 // ------------------------------------------------------------------------------------
-__device__ long long g_dcf_dbg_t[8];     // DCF_WGRAD3_DBG & 2: phase timestamps (s_memtime) of workgroup 0, wave 0
-#define DCF_STAMP(i) do { if ((a.dbg & 2) && blockIdx.x == 0 && threadIdx.x == 0) g_dcf_dbg_t[i] = clock64(); } while (0)
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// One LDS-DMA instruction: 64 lanes x 16 B, lane l from buffer offset voff[l], to LDS bytes [lds_dst, lds_dst + 1024).
-// A lane whose offset is outside the descriptor's range has ZEROS written for it (probed on MI355X:
-// tools/probe/lds_dma_oob.hip) -- padding, junk rows and masked channels cost one v_cndmask.
-// Inline asm on purpose: hipcc counts a *builtin* LDS-DMA as a pending LDS write and drains it with vmcnt(0)
-// before the next ds_read, which would serialise the ring; an asm one is ours to count (wait_vmcnt above).
-// M0 (the DMA destination base) is compiler-reserved: saved and restored inside the statement.
-__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(rsrc), "s"(lds_dst)
-                 : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const void *p)
-{
-    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
-}
-
-template <typename V> __device__ __forceinline__ V opaque(V v) { asm volatile("" : "+v"(v)); return v; }   // stop re-derivation of lane constants
 
 template <int TM, int TN, int NS, int NW>
 __global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g(WgArgs a)
