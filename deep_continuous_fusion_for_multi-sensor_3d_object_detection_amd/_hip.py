@@ -117,7 +117,13 @@ def _ptr(t):
     return t
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """hipStream_t of torch's current stream on the current device (every launch goes onto it)."""
+    if _raw_stream is not None:          # one C call instead of torch.cuda.current_stream()'s Python layers (~7 us, x600 per step)
+        return _raw_stream(torch._C._cuda_getDevice())
     return torch.cuda.current_stream().cuda_stream
 
 
