@@ -195,6 +195,98 @@ __global__ void __launch_bounds__(256) k_fusion_gather_bwd(const T *P, const flo
     }
 }
 
+// Same backward with the pixel loop software-pipelined for a compile-time K: the loads of pixel p+2's neighbour ids /
+// gradient row and of pixel p+1's point rows are in flight while pixel p is evaluated, so an iteration exposes about
+// one memory latency instead of the dependent chain idx -> (xyz, P) -> use.  Same arithmetic and flush order as above.
+template <typename T, int KT>
+__global__ void __launch_bounds__(256) k_fusion_gather_bwd_pipe(const T *__restrict__ P, const float *__restrict__ xyz, const int *__restrict__ idx, FuseGeom g,
+                                                                const float *__restrict__ w1d, const float *__restrict__ b1, int C, const T *__restrict__ ghsum,
+                                                                float *gP, float *gw1d, float *gb1, int chunk)
+{
+    extern __shared__ float sm[];  // [C][4]: gw1d x3, gb1
+    for (int i = threadIdx.x; i < C * 4; i += blockDim.x) sm[i] = 0.f;
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int hw = g.h * g.w;
+    const int64_t group = t / C;
+    const int c = (int)(t - group * C);
+    const int64_t p_lo = group * chunk;
+    if (p_lo < hw) {
+        const int p_hi = (int)min((int64_t)hw, p_lo + chunk);
+        const float w0 = w1d[c * 3], w1 = w1d[c * 3 + 1], w2 = w1d[c * 3 + 2], bb = b1[c];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, ab = 0.f;
+        int cur_id[KT];
+        float cur_acc[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) { cur_id[k] = -1; cur_acc[k] = 0.f; }
+        // stage I: ids + gradient of a pixel; stage V: its point rows
+        int idI[KT], idV[KT];
+        float ggI, ggV = 0.f;
+        float pv[KT], px[KT], py[KT], pz[KT];
+        auto load_I = [&](int p) {
+            const int pc = min(p, p_hi - 1);              // past the end: a harmless re-read, never used
+#pragma unroll
+            for (int k = 0; k < KT; ++k) idI[k] = idx[(int64_t)k * hw + pc];
+            ggI = DT<T>::ld(ghsum + (int64_t)pc * C + c);
+        };
+        auto load_V = [&]() {                             // consumes stage I
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const int id = idI[k];
+                idV[k] = id;
+                const int ic = max(id, 0);
+                pv[k] = DT<T>::ld(P + (int64_t)ic * C + c);
+                px[k] = xyz[3 * ic]; py[k] = xyz[3 * ic + 1]; pz[k] = xyz[3 * ic + 2];
+            }
+            ggV = ggI;
+        };
+        load_I((int)p_lo);
+        load_V();
+        load_I((int)p_lo + 1);
+        for (int p = (int)p_lo; p < p_hi; ++p) {
+            // take pixel p's operands out of stage V, then refill the pipeline before the arithmetic
+            int id[KT];
+            float v[KT], x[KT], y[KT], z[KT];
+            const float gg = ggV;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) { id[k] = idV[k]; v[k] = pv[k]; x[k] = px[k]; y[k] = py[k]; z[k] = pz[k]; }
+            load_V();                                      // pixel p+1
+            load_I(p + 2);
+            float X, Y;
+            pixel_centre(g, p / g.w, p % g.w, X, Y);
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                if (id[k] != cur_id[k]) {
+                    if (cur_id[k] >= 0 && cur_acc[k] != 0.f) atomicAdd(gP + (int64_t)cur_id[k] * C + c, cur_acc[k]);
+                    cur_id[k] = id[k];
+                    cur_acc[k] = 0.f;
+                }
+                if (id[k] >= 0) {
+                    const float dx = x[k] - X, dy = y[k] - Y, dz = z[k];
+                    const float pre = v[k] + (w0 * dx + w1 * dy + w2 * dz) + bb;
+                    const float d = pre > 0.f ? gg : 0.f;
+                    cur_acc[k] += d;
+                    a0 += d * dx; a1 += d * dy; a2 += d * dz; ab += d;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+            if (cur_id[k] >= 0 && cur_acc[k] != 0.f) atomicAdd(gP + (int64_t)cur_id[k] * C + c, cur_acc[k]);
+        atomicAdd(&sm[c * 4 + 0], a0);
+        atomicAdd(&sm[c * 4 + 1], a1);
+        atomicAdd(&sm[c * 4 + 2], a2);
+        atomicAdd(&sm[c * 4 + 3], ab);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        atomicAdd(&gw1d[i * 3 + 0], sm[i * 4 + 0]);
+        atomicAdd(&gw1d[i * 3 + 1], sm[i * 4 + 1]);
+        atomicAdd(&gw1d[i * 3 + 2], sm[i * 4 + 2]);
+        atomicAdd(&gb1[i], sm[i * 4 + 3]);
+    }
+}
+
 }  // namespace
 
 // ================================================================== C ABI
@@ -245,9 +337,22 @@ extern "C" int dcf_fusion_gather_bwd(int dtype, const void *P, const float *xyz,
     const int64_t hw = (int64_t)h * w;
     // pixels per thread run: swept on cfg2 (div 32..512): ~256k threads is the sweet spot between
     // latency hiding (more, shorter runs) and atomic aggregation (fewer, longer runs)
-    int chunk = (int)(hw * Cb / (256 * 1024));
+    static const char *thr_env = getenv("DCF_FUSION_THREADS_K");
+    const int64_t threads = (thr_env ? atoi(thr_env) : 256) * 1024ll;
+    int chunk = (int)(hw * Cb / threads);
     if (chunk < 8) chunk = 8;
     const int64_t groups = (hw + chunk - 1) / chunk;
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("fusion_gather_bwd", s, hipLaunchKernelGGL(k_fusion_gather_bwd<T>, dim3(cdiv(groups * Cb, 256)), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, idx, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, chunk)); })
+    static const char *pipe_env = getenv("DCF_FUSION_PIPE");
+    const bool pipe = !(pipe_env && atoi(pipe_env) == 0);
+#define DCF_FGB(KT_) DCF_LAUNCH("fusion_gather_bwd", s, hipLaunchKernelGGL((k_fusion_gather_bwd_pipe<T, KT_>), dim3(cdiv(groups * Cb, 256)), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, idx, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, chunk))
+    DCF_DISPATCH_DTYPE(dtype, {
+        if (pipe && K == 1) DCF_FGB(1);
+        else if (pipe && K == 2) DCF_FGB(2);
+        else if (pipe && K == 3) DCF_FGB(3);
+        else if (pipe && K == 4) DCF_FGB(4);
+        else if (pipe && K == 5) DCF_FGB(5);
+        else DCF_LAUNCH("fusion_gather_bwd", s, hipLaunchKernelGGL(k_fusion_gather_bwd<T>, dim3(cdiv(groups * Cb, 256)), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, idx, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, chunk));
+    })
+#undef DCF_FGB
     return DCF_OK;
 }
