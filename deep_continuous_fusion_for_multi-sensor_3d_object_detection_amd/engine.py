@@ -379,7 +379,12 @@ class Plan(object):
         if geom.get("event") is not None and not geom.get("_waited"):
             K.wait_event(geom["event"])                # KNN indices produced on the geometry side stream
             geom["_waited"] = True
-        fp = K.point_sample_fwd(fmap, geom["uv"], geom["cnt"], n_max)            # [B,n_max,Cf]
+        # every site samples the same camera map at the same (u, v): the point features are computed once per step
+        fp = self.ctx.get("fuse_fp") if save else None
+        if fp is None:
+            fp = K.point_sample_fwd(fmap, geom["uv"], geom["cnt"], n_max)        # [B,n_max,Cf]
+            if save:
+                self.ctx["fuse_fp"] = fp
         P = K.conv_fwd(f["fc1_feat"], fp.view(B, n_max, 1, fp.shape[-1]), None, False).view(B, n_max, cb)
         hsum, cnt = K.fusion_gather_fwd(P, geom["xyz"], geom["idx"][site], f["stride"], geom["aff"], f["w1d_off"], f["b1_off"])
         out = K.conv_fwd(f["fc2"], hsum, x, False)                               # x + hsum.W2^T
@@ -399,5 +404,11 @@ class Plan(object):
         gPc = K.cast_like(gP, s["P"]).view(B, n_max, 1, cb)
         fp4 = s["fp"].view(B, n_max, 1, s["fp"].shape[-1])
         K.conv_wgrad(f["fc1_feat"], fp4, gPc)
-        gfp = K.conv_dgrad(f["fc1_feat"], gPc, tuple(fp4.shape), None).view(B, n_max, -1)
-        return K.point_sample_bwd(gfp, geom["uv"], geom["cnt"], n_max, s["fmap_shape"], gF)
+        # dL/dfp is summed over the sites through the dgrad kernel's residual input and scattered into the camera map
+        # once, after the last site (site 0) has added its share
+        gfp = K.conv_dgrad(f["fc1_feat"], gPc, tuple(fp4.shape), self.ctx.get("fuse_gfp"))
+        if site > 0:
+            self.ctx["fuse_gfp"] = gfp
+            return None
+        self.ctx.pop("fuse_gfp", None)
+        return K.point_sample_bwd(gfp.view(B, n_max, -1), geom["uv"], geom["cnt"], n_max, s["fmap_shape"], gF)
