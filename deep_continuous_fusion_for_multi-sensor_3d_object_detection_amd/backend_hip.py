@@ -67,6 +67,7 @@ class HipBackend(object):
                                  1 if L.kind == "stem" else 0, 0, 0)
         self.table = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.dev)
         self.nconv = len(layers)
+        self.max_cout = max(L.cout for L in layers)
 
     def _w(self, L, dgrad=False):
         off = L.wdgrad_off if dgrad else L.wfwd_off
@@ -111,7 +112,7 @@ class HipBackend(object):
         self.grads.zero_()
 
     def end_backward(self, layers):
-        H.call("dcf_wgrad_finalize", self.table, self.nconv, self.params, self.buffers, self.ssarena, self.slabs, self.gsum,
+        H.call("dcf_wgrad_finalize", self.table, self.nconv, self.max_cout, self.params, self.buffers, self.ssarena, self.slabs, self.gsum,
                self.grads, BN_EPS, H.stream_ptr())
 
     # ------------------------------------------------------------------ convolutions

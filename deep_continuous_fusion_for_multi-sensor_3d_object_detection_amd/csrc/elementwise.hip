@@ -375,38 +375,45 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_weight_prep(const dcf_conv_param *table, const float *params, const float *buffers, char *warena,
                                                      float *ssarena, float eps)
 {
-    // 32(co) x 32(ci) tiles per tap: coalesced 128-B reads of the fp32 master weights, coalesced
-    // 64/128-B writes of both images (the dgrad image goes through an LDS transpose).
-    __shared__ float tile[32][33];
+    // 64(co) x 64(ci) tiles per tap, 16 B per lane: whole 256-B rows of the fp32 master weights in, whole 128-B (bf16) rows
+    // of both images out; the dgrad image ([ci][tap][co]) goes through an LDS transpose (pitch 65: column reads conflict free).
+    __shared__ float tile[64][65];
     const dcf_conv_param d = table[blockIdx.y];
     const int K = d.taps * d.cin;
-    const int cot = d.cout_pad / 32, cit = d.cin / 32;
+    const int cot = (d.cout_pad + 63) / 64, cit = (d.cin + 63) / 64;
     const int ntiles = d.taps * cot * cit;
     T *wf = reinterpret_cast<T *>(warena + d.wfwd_off);
     T *wd = d.wdgrad_off >= 0 ? reinterpret_cast<T *>(warena + d.wdgrad_off) : nullptr;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 lanes x 4 elements per row, 16 rows per pass
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int tap = t % d.taps;
         const int r = t / d.taps;
-        const int c0 = (r % cit) * 32, o0 = (r / cit) * 32;
+        const int c0 = (r % cit) * 64, o0 = (r / cit) * 64;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int co = o0 + ty + 8 * k, ci = c0 + tx;
-            float v = 0.f;
-            if (co < d.cout) {
+            const int co = o0 + ty + 16 * k, ci = c0 + tx * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool in = (co < d.cout_pad) && (ci < d.cin);
+            if (in && co < d.cout) {
                 float scale = 1.f;
                 if (d.gamma_off >= 0) scale = params[d.gamma_off + co] * rsqrtf(buffers[d.var_off + co] + eps);
-                v = params[d.w_off + (int64_t)co * K + tap * d.cin + ci] * scale;
+                v = ld4(params + d.w_off + (int64_t)co * K + tap * d.cin + ci);
+                v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
             }
-            DT<T>::st(wf + (int64_t)co * K + tap * d.cin + ci, v);
-            tile[ty + 8 * k][tx] = v;
+            if (in) st4(wf + (int64_t)co * K + tap * d.cin + ci, v);
+            float *row = &tile[ty + 16 * k][tx * 4];
+            row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
         }
         __syncthreads();
         if (wd) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int ci = c0 + ty + 8 * k, co = o0 + tx;
-                DT<T>::st(wd + ((int64_t)ci * d.taps + tap) * d.cout_pad + co, tile[tx][ty + 8 * k]);
+                const int ci = c0 + ty + 16 * k, co = o0 + tx * 4;
+                if (ci < d.cin && co < d.cout_pad) {
+                    const int lr = ty + 16 * k;
+                    st4(wd + ((int64_t)ci * d.taps + tap) * d.cout_pad + co,
+                        make_float4(tile[tx * 4][lr], tile[tx * 4 + 1][lr], tile[tx * 4 + 2][lr], tile[tx * 4 + 3][lr]));
+                }
             }
         }
         __syncthreads();
@@ -429,7 +436,7 @@ __global__ void __launch_bounds__(256) k_weight_prep(const dcf_conv_param *table
 }
 
 // Gradient finalisation, one block per (conv, output channel): fixed-order reduction of the
-// wgrad slabs, then the folded-BN chain rule
+// wgrad slabs (16 B per lane, 4 independent partial sums), then the folded-BN chain rule
 //   dW = scale*G ; dbeta = sum g ; dgamma = (<W,G> - mean*dbeta) * rsqrt(var+eps).
 __global__ void __launch_bounds__(256) k_wgrad_finalize(const dcf_conv_param *table, const float *params, const float *buffers,
                                                         const float *ssarena, const float *slabs, const float *gsum, float *grads, float eps)
@@ -441,22 +448,36 @@ __global__ void __launch_bounds__(256) k_wgrad_finalize(const dcf_conv_param *ta
     const int64_t slab_elems = (int64_t)d.cout_pad * K;
     const float scale = ssarena[d.shift_off + co];
     float dot = 0.f;
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    for (int k = threadIdx.x * 4; k < K; k += blockDim.x * 4) {
         const int64_t e = (int64_t)co * K + k;
-        // fixed-order reduction with 8 loads in flight
         const float *sp = slabs + d.slab_off + e;
-        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int sidx = 0;
-        for (; sidx + 8 <= d.nsplit; sidx += 8) {
+        float4 part[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) part[u] += sp[(int64_t)(sidx + u) * slab_elems];
+        for (int u = 0; u < 4; ++u) part[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int sidx = 0;
+        for (; sidx + 4 <= d.nsplit; sidx += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 v = ld4(sp + (int64_t)(sidx + u) * slab_elems);
+                part[u].x += v.x; part[u].y += v.y; part[u].z += v.z; part[u].w += v.w;
+            }
         }
-        for (; sidx < d.nsplit; ++sidx) part[sidx & 7] += sp[(int64_t)sidx * slab_elems];
-        float G = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+        for (; sidx < d.nsplit; ++sidx) {
+            const float4 v = ld4(sp + (int64_t)sidx * slab_elems);
+            float4 &q = part[sidx & 3];
+            q.x += v.x; q.y += v.y; q.z += v.z; q.w += v.w;
+        }
+        float G[4] = {(part[0].x + part[1].x) + (part[2].x + part[3].x), (part[0].y + part[1].y) + (part[2].y + part[3].y),
+                      (part[0].z + part[1].z) + (part[2].z + part[3].z), (part[0].w + part[1].w) + (part[2].w + part[3].w)};
         // stem weights are stored [Cout][7][8][4]: tap kw=7 and channel 3 are structural zeros
-        if ((d.flags & 1) && ((((k & 31) >> 2) == 7) || ((k & 3) == 3))) G = 0.f;
-        grads[d.w_off + e] = d.gamma_off >= 0 ? scale * G : G;
-        dot += params[d.w_off + e] * G;
+        if (d.flags & 1) {
+            if (((k & 31) >> 2) == 7) G[0] = G[1] = G[2] = 0.f;
+            G[3] = 0.f;
+        }
+        const float4 w = ld4(params + d.w_off + e);
+        dot += (w.x * G[0] + w.y * G[1]) + (w.z * G[2] + w.w * G[3]);
+        const float sc = d.gamma_off >= 0 ? scale : 1.f;
+        st4(grads + d.w_off + e, make_float4(sc * G[0], sc * G[1], sc * G[2], sc * G[3]));
     }
     if (d.gamma_off < 0) return;
     // dbeta: per-wave partial sums written by the wgrad kernel, reduced with a fixed thread mapping
@@ -804,13 +825,13 @@ extern "C" int dcf_weight_prep(int dtype, const dcf_conv_param *table, int nconv
     return DCF_OK;
 }
 
-extern "C" int dcf_wgrad_finalize(const dcf_conv_param *table, int nconv, const float *params, const float *buffers,
+extern "C" int dcf_wgrad_finalize(const dcf_conv_param *table, int nconv, int max_cout, const float *params, const float *buffers,
                                   const float *ssarena, const float *slabs, const float *gsum, float *grads, float eps,
                                   dcf_stream_t stream)
 {
-    DCF_REQUIRE(table && nconv > 0 && params && ssarena && slabs && gsum && grads, "dcf_wgrad_finalize: bad arguments");
+    DCF_REQUIRE(table && nconv > 0 && max_cout > 0 && params && ssarena && slabs && gsum && grads, "dcf_wgrad_finalize: bad arguments");
     hipStream_t s = S(stream);
-    DCF_LAUNCH("wgrad_finalize", s, hipLaunchKernelGGL(k_wgrad_finalize, dim3(2048, nconv), dim3(256), 0, s, table, params, buffers, ssarena, slabs, gsum, grads, eps));
+    DCF_LAUNCH("wgrad_finalize", s, hipLaunchKernelGGL(k_wgrad_finalize, dim3(max_cout, nconv), dim3(256), 0, s, table, params, buffers, ssarena, slabs, gsum, grads, eps));
     return DCF_OK;
 }
 

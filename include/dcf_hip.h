@@ -142,7 +142,8 @@ int dcf_weight_prep(int dtype, const dcf_conv_param *table, int nconv, const flo
                     void *warena, float *ssarena, float eps, dcf_stream_t stream);
 /* Reduce wgrad slabs in split order and apply the folded-BN chain rule:
  * dW = scale*G, dgamma = (<W,G> - mean*dbeta)*invstd, dbeta = sum over the 4*nsplit rows of gsum[.][co]. */
-int dcf_wgrad_finalize(const dcf_conv_param *table, int nconv, const float *params, const float *buffers,
+/* max_cout = the largest cout of the table (grid width). */
+int dcf_wgrad_finalize(const dcf_conv_param *table, int nconv, int max_cout, const float *params, const float *buffers,
                        const float *ssarena, const float *slabs, const float *gsum, float *grads, float eps,
                        dcf_stream_t stream);
 

@@ -164,7 +164,7 @@ def test_weight_prep_and_finalize(dtype):
     slabs = torch.cat((rnd((ns1, cp, Cin), 22).reshape(-1), rnd((ns2, C2o, 9 * C2i), 23).reshape(-1))).cuda()
     gsum = rnd((4 * ns1 * cp + 4 * ns2 * C2o,), 24).cuda()       # [4*nsplit][cout_pad] per layer
     grads = torch.zeros_like(params)
-    H.call("dcf_wgrad_finalize", tdev, 2, params, buffers, ss, slabs, gsum, grads, 1e-5, H.stream_ptr())
+    H.call("dcf_wgrad_finalize", tdev, 2, max(Cout, C2o), params, buffers, ss, slabs, gsum, grads, 1e-5, H.stream_ptr())
     gr = grads.cpu()
     G1 = slabs.cpu()[:ns1 * cp * Cin].view(ns1, cp, Cin).sum(0)[:Cout]
     G2 = slabs.cpu()[ns1 * cp * Cin:].view(ns2, C2o, 9 * C2i).sum(0)
