@@ -448,36 +448,55 @@ __global__ void __launch_bounds__(256) k_wgrad_finalize(const dcf_conv_param *ta
     const int64_t slab_elems = (int64_t)d.cout_pad * K;
     const float scale = ssarena[d.shift_off + co];
     float dot = 0.f;
-    for (int k = threadIdx.x * 4; k < K; k += blockDim.x * 4) {
+    // Rows shorter than the block (K/4 < 256 lanes: the 1x1 and 32-channel layers, which are also the ones with hundreds
+    // of slabs) are reduced by G = 256/(K/4) thread groups, group g taking slabs g, g+G, ...; the group sums meet in LDS
+    // and are added in group order, so the result does not depend on timing.
+    __shared__ float4 gpart[256];
+    const int K4 = K >> 2;
+    const int G = K4 >= 256 ? 1 : 256 / K4;
+    const int grp = G == 1 ? 0 : threadIdx.x / K4;
+    const int kbeg = G == 1 ? threadIdx.x * 4 : (threadIdx.x - grp * K4) * 4;
+    const int kstep = G == 1 ? blockDim.x * 4 : K;             // grouped rows: one pass
+    for (int k = kbeg; k < K; k += kstep) {
         const int64_t e = (int64_t)co * K + k;
         const float *sp = slabs + d.slab_off + e;
         float4 part[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) part[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        int sidx = 0;
-        for (; sidx + 4 <= d.nsplit; sidx += 4) {
+        if (grp < G) {
+            int sidx = grp;
+            for (; sidx + 3 * G < d.nsplit; sidx += 4 * G) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float4 v = ld4(sp + (int64_t)(sidx + u) * slab_elems);
+                for (int u = 0; u < 4; ++u) {
+                    const float4 v = ld4(sp + (int64_t)(sidx + u * G) * slab_elems);
+                    part[u].x += v.x; part[u].y += v.y; part[u].z += v.z; part[u].w += v.w;
+                }
+            }
+            for (int u = 0; sidx < d.nsplit; sidx += G, ++u) {
+                const float4 v = ld4(sp + (int64_t)sidx * slab_elems);
                 part[u].x += v.x; part[u].y += v.y; part[u].z += v.z; part[u].w += v.w;
             }
         }
-        for (; sidx < d.nsplit; ++sidx) {
-            const float4 v = ld4(sp + (int64_t)sidx * slab_elems);
-            float4 &q = part[sidx & 3];
-            q.x += v.x; q.y += v.y; q.z += v.z; q.w += v.w;
+        float G4[4] = {(part[0].x + part[1].x) + (part[2].x + part[3].x), (part[0].y + part[1].y) + (part[2].y + part[3].y),
+                       (part[0].z + part[1].z) + (part[2].z + part[3].z), (part[0].w + part[1].w) + (part[2].w + part[3].w)};
+        if (G > 1) {
+            if (grp < G) gpart[threadIdx.x] = make_float4(G4[0], G4[1], G4[2], G4[3]);
+            __syncthreads();
+            if (grp != 0) break;
+            for (int g2 = 1; g2 < G; ++g2) {
+                const float4 v = gpart[g2 * K4 + threadIdx.x];
+                G4[0] += v.x; G4[1] += v.y; G4[2] += v.z; G4[3] += v.w;
+            }
         }
-        float G[4] = {(part[0].x + part[1].x) + (part[2].x + part[3].x), (part[0].y + part[1].y) + (part[2].y + part[3].y),
-                      (part[0].z + part[1].z) + (part[2].z + part[3].z), (part[0].w + part[1].w) + (part[2].w + part[3].w)};
         // stem weights are stored [Cout][7][8][4]: tap kw=7 and channel 3 are structural zeros
         if (d.flags & 1) {
-            if (((k & 31) >> 2) == 7) G[0] = G[1] = G[2] = 0.f;
-            G[3] = 0.f;
+            if (((k & 31) >> 2) == 7) G4[0] = G4[1] = G4[2] = 0.f;
+            G4[3] = 0.f;
         }
         const float4 w = ld4(params + d.w_off + e);
-        dot += (w.x * G[0] + w.y * G[1]) + (w.z * G[2] + w.w * G[3]);
+        dot += (w.x * G4[0] + w.y * G4[1]) + (w.z * G4[2] + w.w * G4[3]);
         const float sc = d.gamma_off >= 0 ? scale : 1.f;
-        st4(grads + d.w_off + e, make_float4(sc * G[0], sc * G[1], sc * G[2], sc * G[3]));
+        st4(grads + d.w_off + e, make_float4(sc * G4[0], sc * G4[1], sc * G4[2], sc * G4[3]));
     }
     if (d.gamma_off < 0) return;
     // dbeta: per-wave partial sums written by the wgrad kernel, reduced with a fixed thread mapping
