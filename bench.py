@@ -120,6 +120,27 @@ def roofline_leg(trainer, pool, B, steps):
     return roof, breakdown
 
 
+def rocprof_kernel(name):
+    """Profiler name of a launch ('conv_wgrad3g_bf16<2,2,2,8>', 'conv_fwd_bf16<128,1,1,2,2,dma4>', ...) ->
+    (kernel function, template argument list) as rocprofv3 prints them."""
+    kind, _, tmpl = name.partition("<")
+    t = tmpl.rstrip(">").split(",") if tmpl else []
+    dt = "unsignedshort" if "bf16" in kind else "float"
+    if kind.startswith("conv_wgrad3g"):
+        return "k_conv_wgrad3g", t
+    if kind.startswith("conv_wgrad3"):
+        return "k_conv_wgrad3", [dt] + t
+    if kind.startswith("conv_wgrad") or kind.startswith("stem_wgrad"):
+        return ("k_conv_wgrad", [dt] + t) if t else None
+    if kind.startswith("conv_fwd") or kind.startswith("conv_dgrad") or kind.startswith("stem_fwd"):
+        tr = "true" if "dgrad" in kind else "false"
+        if t and t[-1].startswith("dma"):
+            return "k_conv_igemm_dma", t[1:-1] + [tr, t[-1][3:]]
+        db = "true" if (t and t[-1] == "db") else "false"
+        return "k_conv_igemm", [dt] + [x for x in t if x != "db"] + [tr, db]
+    return None
+
+
 def pmc_traffic(name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
     command (profiles/*_pmc_traffic.csv; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).
@@ -128,18 +149,17 @@ def pmc_traffic(name):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.csv")))
     if not files:
         return None, None
-    kind, _, tmpl = name.partition("<")                       # e.g. conv_wgrad_bf16 <2,2>
-    want = "k_conv_wgrad" if "wgrad" in kind else "k_conv_igemm"
-    tr = ("true" if "dgrad" in kind else "false")
+    want = rocprof_kernel(name)
+    if want is None:
+        return None, None
     for row in csv.DictReader(open(files[-1])):
         k = row["kernel"]
-        if want not in k:
+        head = k.split(">(")[0] if ">(" in k else ""          # "... k_conv_wgrad3g<2, 2, 2, 8" of "...>((anonymous namespace)::WgArgs)"
+        if "<" not in head:
             continue
-        args = k[k.index("<") + 1:k.index(">")].replace(" ", "").split(",")[1:]   # drop the dtype
-        if want == "k_conv_igemm":
-            if args[-1] != tr or ",".join(args[:-1]) != tmpl.rstrip(">"):
-                continue
-        elif ",".join(args) != tmpl.rstrip(">"):
+        func = head[:head.index("<")].split("::")[-1].split()[-1]
+        args = head[head.index("<") + 1:].replace(" ", "").split(",")
+        if (func, args) != want:
             continue
         b = (2.0 * float(row["FETCH_SIZE_KB_per_launch_raw"]) + float(row["WRITE_SIZE_KB_per_launch"])) * 1024.0
         return round(b), os.path.basename(files[-1])

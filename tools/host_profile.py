@@ -27,5 +27,5 @@ for s in range(5):
 pr.disable()
 torch.cuda.synchronize()
 st = io.StringIO()
-pstats.Stats(pr, stream=st).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(32)
 print(st.getvalue()[:9000])

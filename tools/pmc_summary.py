@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Summarise two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of bench.py into profiles/<tag>_pmc_traffic.csv.
+
+usage: pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.csv>
+Each pass is `rocprofv3 --pmc X --output-format csv -d DIR -- python3 bench.py ...` (no trace flags); the
+counter_collection.csv of a pass has one row per (dispatch, counter).  Output: per kernel, launches and the
+mean counter value per launch in KB (raw; bench.py applies MI355X_MICROARCH.md's gfx950 FETCH_SIZE x2)."""
+import csv, glob, os, sys
+from collections import defaultdict
+
+
+def load(d, counter):
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        raise SystemExit("no *counter_collection.csv under %s" % d)
+    tot, n = defaultdict(float), defaultdict(int)
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != counter:
+                continue
+            k = r["Kernel_Name"]
+            tot[k] += float(r["Counter_Value"])
+            n[k] += 1
+    return tot, n
+
+
+def main():
+    fd, wd, out = sys.argv[1:4]
+    ft, fn = load(fd, "FETCH_SIZE")
+    wt, wn = load(wd, "WRITE_SIZE")
+    rows = sorted(ft, key=lambda k: -(ft[k] + wt.get(k, 0.0)))
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches", "FETCH_SIZE_KB_per_launch_raw", "WRITE_SIZE_KB_per_launch"])
+        for k in rows:
+            w.writerow([k, fn[k], round(ft[k] / fn[k], 1), round(wt.get(k, 0.0) / max(wn.get(k, 0), 1), 1)])
+    print("wrote %s (%d kernels)" % (out, len(rows)))
+
+
+if __name__ == "__main__":
+    main()
