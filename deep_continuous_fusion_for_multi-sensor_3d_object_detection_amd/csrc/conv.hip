@@ -600,7 +600,7 @@ int launch_igemm(const ConvArgs &a_in, hipStream_t s, const char *base, double f
         snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d%s>", base, KB_, TN_, TM_, WN_, WM_, db ? ",db" : "");        \
         if (a.dbg & 4) {                                                                                            \
             unsigned long long w[4] = {~0ull, 0, 0, 0};                                                             \
-            hipMemcpyToSymbol(HIP_SYMBOL(g_dcf_dbg_w), w, sizeof(w));                                               \
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dcf_dbg_w), w, sizeof(w));                                               \
         }                                                                                                           \
         constexpr int NS_ = (BN_ + BM_) <= 128 ? 4 : 3;                                                              \
         static const char *dma_env = getenv("DCF_IGEMM_DMA");                                                       \
@@ -612,15 +612,15 @@ int launch_igemm(const ConvArgs &a_in, hipStream_t s, const char *base, double f
         else DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR, false>), grid, dim3(256), 0, s, a)); \
         if (a.dbg & 4) {                                                                                            \
             unsigned long long w[4];                                                                                \
-            hipStreamSynchronize(s);                                                                                \
-            hipMemcpyFromSymbol(w, HIP_SYMBOL(g_dcf_dbg_w), sizeof(w));                                             \
+            (void)hipStreamSynchronize(s);                                                                              \
+            (void)hipMemcpyFromSymbol(w, HIP_SYMBOL(g_dcf_dbg_w), sizeof(w));                                             \
             fprintf(stderr, "[%s M=%d Ck=%d Cn=%d taps=%d blocks=%d] span %.2f us, mean workgroup life %.2f us, max %.2f us\n", name, a.M, a.Ck, a.Cn, a.kh * a.kw, (int)grid.x, \
                     (w[1] - w[0]) * 0.01, w[2] * 0.01 / grid.x, w[3] * 0.01);                                       \
         }                                                                                                           \
         if (a.dbg & 2) {                                                                                            \
             long long tt[8];                                                                                        \
-            hipStreamSynchronize(s);                                                                                \
-            hipMemcpyFromSymbol(tt, HIP_SYMBOL(g_dcf_dbg_t), sizeof(tt));                                           \
+            (void)hipStreamSynchronize(s);                                                                              \
+            (void)hipMemcpyFromSymbol(tt, HIP_SYMBOL(g_dcf_dbg_t), sizeof(tt));                                           \
             fprintf(stderr, "[%s M=%d Ck=%d Cn=%d taps=%d blocks=%d] clocks: setup %lld first-stage %lld loop %lld epilogue %lld\n", name, a.M, a.Ck, a.Cn, a.kh * a.kw, (int)grid.x, \
                     tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3]);                                    \
         }                                                                                                           \
@@ -634,6 +634,7 @@ int launch_igemm(const ConvArgs &a_in, hipStream_t s, const char *base, double f
     if (force == 1 && a.Cn % 64 == 0) { if (kb128) DCF_IGEMM(128, 2, 1, 1, 4); else DCF_IGEMM(64, 2, 1, 1, 4); }
     if (force == 2 && a.Cn % 64 == 0) { if (kb128) DCF_IGEMM(128, 1, 1, 2, 2); else DCF_IGEMM(64, 1, 1, 2, 2); }
     if (force == 3) { if (kb128) DCF_IGEMM(128, 1, 1, 1, 4); else DCF_IGEMM(64, 1, 1, 1, 4); }
+    if (force == 4 && a.Cn % 128 == 0) { if (kb128) DCF_IGEMM(128, 2, 1, 2, 2); else DCF_IGEMM(64, 2, 1, 2, 2); }      // 128 ch x 64 px
     const int64_t want_blocks = 256;
     auto blocks = [&](int bn, int bm) { return (int64_t)cdiv(a.M, bm) * (a.Cn / bn); };
     if (a.Cn % 128 == 0 && blocks(128, 128) >= want_blocks) {
@@ -1628,7 +1629,7 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
             if (a.dbg & 2) {
                 long long tt[8];
                 hipStreamSynchronize(s);
-                hipMemcpyFromSymbol(tt, HIP_SYMBOL(g_dcf_dbg_t), sizeof(tt));
+                (void)hipMemcpyFromSymbol(tt, HIP_SYMBOL(g_dcf_dbg_t), sizeof(tt));
                 fprintf(stderr, "[wgrad3g %dx%d %d->%d ns=%d] clocks: prologue %lld loop %lld wait %lld epilogue %lld (100 MHz ticks x?)\n", Ho, Wo, Cin, Cout, nsplit,
                         tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3]);
             }

@@ -3,8 +3,9 @@
 Same constructor and call surface: LossTotal(config)(bboxes [B,max,9], num_boxes [B],
 cls [B,4,h,w], reg [B,14,h,w]) -> [1] loss tensor.  Target assignment is host-side Python
 driven by numpy's global RNG exactly like loss.py:74-127 (so np.random.seed pins it); the
-gathers / cross-entropy / Smooth-L1 are a handful of tiny torch ops on the model's device
-(harness, not a HIP target this round; "next" row N1).
+device half (gathers, cross-entropy, Smooth-L1 and their gradients) is ONE HIP launch for CUDA tensors
+(csrc/loss.hip, dcf_loss_fwd_bwd -- SURVEY.md §8(f) row N1); CPU tensors (the host-logic tests) go through
+the same arithmetic as a handful of torch ops.
 
 Reference quirks are kept behind `loss_reduction: last` (default): cross-entropy on already
 soft-maxed scores (loss.py:17-20,139), 129 negatives (:125), only the last sample of the
@@ -16,6 +17,39 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .model import AnchorBoundingBoxFeature
+
+
+class _FusedLoss(torch.autograd.Function):
+    """loss = dcf_loss_fwd_bwd(head outputs, staged targets); the same launch leaves dL/d(head outputs) in dense maps,
+    which backward hands to autograd scaled by the incoming gradient.  With `base` = the [B,32,h,w] head tensor that
+    cls / reg are views of, the gradient goes straight to it (no slice-backward kernels)."""
+
+    @staticmethod
+    def forward(ctx, base, cls, reg, anc, di, df, B, HW, gain, reduction):
+        from . import _hip as H
+        src = base if base is not None else cls
+        loss = torch.zeros(1, dtype=torch.float32, device=src.device)
+        if base is not None:
+            g = torch.zeros_like(base)
+            gb = g.stride(0)
+            gcls, greg = g, g[:, 4:]
+            ctx.split = False
+        else:
+            gcls, greg = torch.zeros_like(cls), torch.zeros_like(reg)
+            g = (gcls, greg)
+            gb = None
+            ctx.split = True
+        H.call("dcf_loss_fwd_bwd", cls, cls.stride(0), reg, reg.stride(0), anc, di, df, B, HW, float(gain), int(reduction), loss,
+               gcls, gcls.stride(0), greg, greg.stride(0), H.stream_ptr())
+        ctx.g = g
+        return loss
+
+    @staticmethod
+    def backward(ctx, go):
+        g = ctx.g
+        if ctx.split:
+            return None, g[0] * go, g[1] * go, None, None, None, None, None, None, None
+        return g * go, None, None, None, None, None, None, None, None, None
 
 
 class LossTotal(nn.Module):
@@ -86,6 +120,25 @@ class LossTotal(nn.Module):
         st[2].record()
         return di, df
 
+    def _forward_hip(self, cls, reg, anc, ints, floats, plan, B, H, W):
+        """Device half as one launch: the per-sample table goes in front of the index lists (one staging copy)."""
+        head = []
+        for (o, npos, nneg, nrow, of, nb) in plan:
+            head += [o + 6 * B, npos, nneg, nrow, of, nb]
+        di, df = self._stage(head + ints, floats, cls.device)
+        HW = H * W
+        ok = lambda t, c: t.dtype == torch.float32 and t.stride(1) == HW and t.stride(2) == W and t.stride(3) == 1 and t.shape[1] == c
+        if not ok(cls, 4):
+            cls = cls.float().contiguous()
+        if not ok(reg, 14):
+            reg = reg.float().contiguous()
+        base = cls._base
+        if not (base is not None and reg._base is base and base.dim() == 4 and base.is_contiguous() and base.shape[1] >= 18
+                and cls.data_ptr() == base.data_ptr() and reg.data_ptr() == base.data_ptr() + 4 * HW * 4 and base.requires_grad):
+            base = None
+        red = {"last": 0, "sum": 1, "mean": 2}[self.reduction]
+        return _FusedLoss.apply(base, cls, reg, anc, di, df, B, HW, self.config["regress_loss_gain"], red)
+
     def forward(self, reference_bboxes_batch, num_ref_bbox_batch, predicted_class_feature_batch, predicted_regress_feature_batch):
         cls, reg = predicted_class_feature_batch, predicted_regress_feature_batch
         dev = cls.device
@@ -112,6 +165,8 @@ class LossTotal(nn.Module):
             of = len(floats)
             floats += row_w + boxes_host[b, :nb, :7].reshape(-1).tolist()
             plan.append((o, len(pos), len(neg), len(rows), of, nb))
+        if dev.type == "cuda":
+            return self._forward_hip(cls, reg, anc, ints, floats, plan, B, H, W)
         di, df = self._stage(ints, floats, dev)
         # ---- device: gathers + CE + Smooth-L1, vectorised per sample
         total = torch.zeros(1, device=dev)

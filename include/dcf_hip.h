@@ -216,6 +216,18 @@ int dcf_cast(int dtype_src, const void *src, int dtype_dst, void *dst, int64_t n
 int dcf_adam_step(float *params, const float *grads, float *m, float *v, int64_t n, float lr, float beta1,
                   float beta2, float eps, int step, float gscale, dcf_stream_t stream);
 
+/* ------------------------------------------------------------- detection objective (loss.py:129-189)
+ * Device half of LossTotal: 2-way cross-entropy at the sampled cells of both anchors + Smooth-L1 of the encoded box
+ * offsets, and their gradients (fp32 atomics into ZEROED dense maps), in one launch; *loss (zeroed) receives the scalar.
+ * cls [B][4][HW] / reg [B][14][HW] fp32 with the given batch strides (elements); anchors [2][7][HW].
+ * ints (int64) = B x {off_int, npos, nneg, nrow, off_float, nbox}, then per sample: positive cells, negative cells,
+ * regression cells, box index of each regression cell;  floats = per sample: weight of each regression cell, boxes [nbox][7].
+ * The host-side target assignment that fills them is loss.py:74-127 (numpy RNG).  reduction: 0 last sample only
+ * (reference behaviour), 1 sum, 2 mean over the batch. */
+int dcf_loss_fwd_bwd(const float *cls, int64_t cls_bstride, const float *reg, int64_t reg_bstride, const float *anchors,
+                     const int64_t *ints, const float *floats, int B, int HW, float reg_gain, int reduction,
+                     float *loss, float *gcls, int64_t gcls_bstride, float *greg, int64_t greg_bstride, dcf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -224,3 +224,46 @@ def test_checkpoint_resume_is_exact(tmp_path):
     run(b, 1, 2)
     assert torch.equal(a.model.flat_params, b.model.flat_params)
     assert b.optimizer.step_count == 3
+
+
+@pytest.mark.parametrize("reduction", ["last", "sum", "mean"])
+def test_fused_loss_kernel_matches_torch_path(reduction):
+    """dcf_loss_fwd_bwd (one launch, CUDA tensors) against the same LossTotal on CPU tensors (torch ops; that path is
+    pinned to the reference by tests/golden/loss.npz in the CPU suite): loss value and both gradients."""
+    z = load_golden("loss.npz")
+    cfg = golden_cfg(load_golden("model_tiny.npz"))
+    cfg["loss_reduction"] = reduction
+    L = pkg("loss").LossTotal(cfg)
+    boxes, nb = torch.from_numpy(z["bboxes"]), torch.from_numpy(z["nbox"])
+    for seed in (0, 1):
+        c0 = torch.from_numpy(z["cls"]).clone().requires_grad_(True)
+        r0 = torch.from_numpy(z["reg"]).clone().requires_grad_(True)
+        np.random.seed(seed)
+        ref = L(boxes, nb, c0, r0)
+        ref.backward()
+        # separate tensors
+        c1 = torch.from_numpy(z["cls"]).cuda().requires_grad_(True)
+        r1 = torch.from_numpy(z["reg"]).cuda().requires_grad_(True)
+        np.random.seed(seed)
+        got = L(boxes, nb, c1, r1)
+        got.backward()
+        assert abs(got.item() - ref.item()) < 2e-6 * max(1.0, abs(ref.item()))
+        if reduction == "last":                       # the reference's own numbers (gen_golden.py)
+            assert abs(got.item() - float(z["loss_seed%d" % seed])) < 2e-6
+            assert np.abs(c1.grad.cpu().numpy() - z["gcls_seed%d" % seed]).max() < 2e-7
+            assert np.abs(r1.grad.cpu().numpy() - z["greg_seed%d" % seed]).max() < 2e-7
+        assert torch.allclose(c1.grad.cpu(), c0.grad, rtol=1e-5, atol=1e-7)
+        assert torch.allclose(r1.grad.cpu(), r0.grad, rtol=1e-5, atol=1e-7)
+        # views of one [B,32,h,w] head tensor (what the model hands over): the gradient goes straight to the base
+        B, _, h, w = z["cls"].shape
+        base = torch.zeros(B, 32, h, w)
+        base[:, 0:4] = torch.from_numpy(z["cls"])
+        base[:, 4:18] = torch.from_numpy(z["reg"])
+        base = base.cuda().requires_grad_(True)
+        np.random.seed(seed)
+        got2 = L(boxes, nb, base[:, 0:4], base[:, 4:18])
+        got2.backward()
+        assert abs(got2.item() - ref.item()) < 2e-6 * max(1.0, abs(ref.item()))
+        assert torch.allclose(base.grad[:, 0:4].cpu(), c0.grad, rtol=1e-5, atol=1e-7)
+        assert torch.allclose(base.grad[:, 4:18].cpu(), r0.grad, rtol=1e-5, atol=1e-7)
+        assert float(base.grad[:, 18:].abs().max()) == 0.0
