@@ -61,6 +61,9 @@ SIGNATURES = {
     "dcf_point_sample_bwd": (c_int, [c_int, P, c_int, c_int, c_int, P, P, c_int, P, P]),
     "dcf_fusion_gather_fwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P, P, c_int, P, P, P]),
     "dcf_fusion_gather_bwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P, P, c_int, P, P, P, P, P]),
+    "dcf_fusion_invert_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dcf_fusion_invert": (c_int, [P, c_int, c_int, c_int, P, P, P, P, P]),
+    "dcf_fusion_gather_bwd_inv": (c_int, [c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P, P, c_int, P, P, P, P, P]),
     "dcf_rowscale_bias_fwd": (c_int, [c_int, P, P, P, c_i64, c_int, P]),
     "dcf_rowscale_bias_bwd": (c_int, [c_int, P, P, P, c_i64, c_int, P]),
     "dcf_cast": (c_int, [c_int, P, c_int, P, c_i64, P]),
@@ -75,6 +78,11 @@ class ConvParam(ctypes.Structure):
                 ("wfwd_off", c_i64), ("wdgrad_off", c_i64), ("shift_off", c_i64), ("slab_off", c_i64), ("gsum_off", c_i64),
                 ("cout", ctypes.c_int32), ("cin", ctypes.c_int32), ("taps", ctypes.c_int32), ("cout_pad", ctypes.c_int32),
                 ("nsplit", ctypes.c_int32), ("flags", ctypes.c_int32), ("pad0", ctypes.c_int32), ("pad1", ctypes.c_int32)]
+
+
+class KnnMap(ctypes.Structure):
+    """struct dcf_knn_map of include/dcf_hip.h."""
+    _fields_ = [("idx", c_void_p), ("h", ctypes.c_int32), ("w", ctypes.c_int32)]
 
 
 class DcfError(RuntimeError):

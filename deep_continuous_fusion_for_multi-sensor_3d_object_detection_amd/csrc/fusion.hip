@@ -287,6 +287,109 @@ __global__ void __launch_bounds__(256) k_fusion_gather_bwd_pipe(const T *__restr
     }
 }
 
+// Backward driven by the INVERSE of the KNN map (dcf_fusion_invert): the (pixel, point) pairs sorted by point.  A wave
+// takes a slice of 128 consecutive pairs, lane = channel (+64 j): every pair is one coalesced row read of the gradient
+// and one (L1-resident, the pairs of a point are adjacent) row read of P, all independent of each other -- no
+// idx -> point -> row chain, so a wave keeps 4 pairs' loads in flight and the kernel runs at memory rate instead of
+// one exposed latency per pixel.  A point's sum is flushed once per slice it appears in (fp32 atomics only there).
+template <typename T, int CJ>
+__global__ void __launch_bounds__(256) k_fusion_gather_bwd_inv(const T *__restrict__ P, const float *__restrict__ xyz, const int *__restrict__ e_begin, const int *__restrict__ e_end,
+                                                               const int *__restrict__ ent_pix, const int *__restrict__ ent_pt, FuseGeom g,
+                                                               const float *__restrict__ w1d, const float *__restrict__ b1, int C,
+                                                               const T *__restrict__ ghsum, float *gP, float *gw1d, float *gb1)
+{
+    constexpr int SL = 128, U = 8;
+    extern __shared__ float sm[];  // [C][4]: gw1d x3, gb1
+    for (int i = threadIdx.x; i < C * 4; i += blockDim.x) sm[i] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int E0 = *e_begin, E = *e_end;
+    const int lo = E0 + wave * SL, hi = min(E, lo + SL);
+    if (lo < hi) {
+        float w0[CJ], w1[CJ], w2[CJ], bb[CJ], a0[CJ], a1[CJ], a2[CJ], ab[CJ], cur_acc[CJ];
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int c = lane + 64 * j;
+            w0[j] = w1d[c * 3]; w1[j] = w1d[c * 3 + 1]; w2[j] = w1d[c * 3 + 2]; bb[j] = b1[c];
+            a0[j] = a1[j] = a2[j] = ab[j] = cur_acc[j] = 0.f;
+        }
+        int cur_pt = -1;
+        auto bcast_i = [](int v, int i) { return __builtin_amdgcn_readlane(v, i); };
+        auto bcast_f = [](float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); };
+        for (int base = lo; base < hi; base += 64) {
+            const int n = min(64, hi - base);
+            // lane-parallel preparation of 64 pairs (one per lane): pixel centre (IEEE division, once per pair instead of
+            // once per pair and lane), offsets to the point, row offsets; the pair loop below only broadcasts them
+            const bool live = lane < n;
+            const int l_pix = live ? ent_pix[base + lane] : 0;
+            const int l_pt = live ? ent_pt[base + lane] : 0;
+            const int pi = l_pix >> 16, pj = l_pix & 0xffff;
+            float Xc, Yc;
+            pixel_centre(g, pi, pj, Xc, Yc);
+            const float l_dx = xyz[3 * l_pt] - Xc, l_dy = xyz[3 * l_pt + 1] - Yc, l_dz = xyz[3 * l_pt + 2];
+            const int l_grow = (pi * g.w + pj) * C, l_prow = l_pt * C;
+            for (int i0 = 0; i0 < n; i0 += U) {
+                int pt[U];
+                float dx[U], dy[U], dz[U], gg[U][CJ], pv[U][CJ];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {               // issue every load of the group first
+                    const int i = min(i0 + u, n - 1);        // past the end: a harmless re-read, skipped below
+                    pt[u] = bcast_i(l_pt, i);
+                    dx[u] = bcast_f(l_dx, i); dy[u] = bcast_f(l_dy, i); dz[u] = bcast_f(l_dz, i);
+                    const int grow = bcast_i(l_grow, i), prow = bcast_i(l_prow, i);
+#pragma unroll
+                    for (int j = 0; j < CJ; ++j) {
+                        gg[u][j] = DT<T>::ld(ghsum + grow + lane + 64 * j);
+                        pv[u][j] = DT<T>::ld(P + prow + lane + 64 * j);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (i0 + u >= n) break;
+                    if (pt[u] != cur_pt) {                   // wave-uniform
+                        if (cur_pt >= 0) {
+#pragma unroll
+                            for (int j = 0; j < CJ; ++j)
+                                if (cur_acc[j] != 0.f) atomicAdd(gP + (int64_t)cur_pt * C + lane + 64 * j, cur_acc[j]);
+                        }
+                        cur_pt = pt[u];
+#pragma unroll
+                        for (int j = 0; j < CJ; ++j) cur_acc[j] = 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < CJ; ++j) {
+                        const float pre = pv[u][j] + (w0[j] * dx[u] + w1[j] * dy[u] + w2[j] * dz[u]) + bb[j];
+                        const float d = pre > 0.f ? gg[u][j] : 0.f;
+                        cur_acc[j] += d;
+                        a0[j] += d * dx[u]; a1[j] += d * dy[u]; a2[j] += d * dz[u]; ab[j] += d;
+                    }
+                }
+            }
+        }
+        if (cur_pt >= 0) {
+#pragma unroll
+            for (int j = 0; j < CJ; ++j)
+                if (cur_acc[j] != 0.f) atomicAdd(gP + (int64_t)cur_pt * C + lane + 64 * j, cur_acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int c = lane + 64 * j;
+            atomicAdd(&sm[c * 4 + 0], a0[j]);
+            atomicAdd(&sm[c * 4 + 1], a1[j]);
+            atomicAdd(&sm[c * 4 + 2], a2[j]);
+            atomicAdd(&sm[c * 4 + 3], ab[j]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        atomicAdd(&gw1d[i * 3 + 0], sm[i * 4 + 0]);
+        atomicAdd(&gw1d[i * 3 + 1], sm[i * 4 + 1]);
+        atomicAdd(&gw1d[i * 3 + 2], sm[i * 4 + 2]);
+        atomicAdd(&gb1[i], sm[i * 4 + 3]);
+    }
+}
+
 }  // namespace
 
 // ================================================================== C ABI
@@ -354,5 +457,28 @@ extern "C" int dcf_fusion_gather_bwd(int dtype, const void *P, const float *xyz,
         else DCF_LAUNCH("fusion_gather_bwd", s, hipLaunchKernelGGL(k_fusion_gather_bwd<T>, dim3(cdiv(groups * Cb, 256)), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, idx, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, chunk));
     })
 #undef DCF_FGB
+    return DCF_OK;
+}
+
+extern "C" int dcf_fusion_gather_bwd_inv(int dtype, const void *P, const float *xyz, const int32_t *e_begin, const int32_t *e_end, const int32_t *ent_pix,
+                                         const int32_t *ent_pt, int max_entries, int h, int w, int stride, float xs, float xo, float ys,
+                                         float yo, const float *w1d, const float *b1, int Cb, const void *ghsum, float *gP, float *gw1d,
+                                         float *gb1, dcf_stream_t stream)
+{
+    DCF_REQUIRE(P && xyz && e_begin && e_end && ent_pix && ent_pt && w1d && b1 && ghsum && gP && gw1d && gb1, "dcf_fusion_gather_bwd_inv: null pointer");
+    DCF_REQUIRE(Cb % 64 == 0 && Cb >= 64 && Cb <= 256, "dcf_fusion_gather_bwd_inv: Cb must be 64, 128, 192 or 256 (got %d)", Cb);
+    if (max_entries <= 0) return DCF_OK;
+    FuseGeom g;
+    g.h = h; g.w = w; g.stride = stride; g.K = 0; g.xs = xs; g.xo = xo; g.ys = ys; g.yo = yo;
+    hipStream_t s = S(stream);
+    const int waves = cdiv(max_entries, 128), blocks = cdiv(waves, 4);
+#define DCF_FGI(CJ_) DCF_LAUNCH("fusion_gather_bwd_inv", s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_>), dim3(blocks), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1))
+    DCF_DISPATCH_DTYPE(dtype, {
+        if (Cb == 64) DCF_FGI(1);
+        else if (Cb == 128) DCF_FGI(2);
+        else if (Cb == 192) DCF_FGI(3);
+        else DCF_FGI(4);
+    })
+#undef DCF_FGI
     return DCF_OK;
 }

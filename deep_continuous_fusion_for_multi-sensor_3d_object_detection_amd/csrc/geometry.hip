@@ -553,6 +553,76 @@ __global__ void __launch_bounds__(256) k_knn_search_wave(const int *count, int n
     }
 }
 
+// ------------------------------------------------------------------ inverse of the KNN maps (for the fusion backward)
+// idx [K][h][w] says which points each BEV pixel gathers; the backward wants, per point, the pixels that gathered it.
+// All maps of a step (sites x frames) are inverted together: counting sort by key (map, point id):
+// hist -> exclusive scan -> fill (atomic cursor).  ent_pix packs the pixel as (i << 16) | j.
+struct InvMaps {
+    const int *idx[DCF_MAX_KNN_MAPS];
+    int first[DCF_MAX_KNN_MAPS + 1];   // first pair slot of each map in the concatenated (K*h*w) space
+    int hw[DCF_MAX_KNN_MAPS], w[DCF_MAX_KNN_MAPS];
+    int n;
+};
+
+__device__ __forceinline__ int inv_map_of(const InvMaps &m, int e)
+{
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < DCF_MAX_KNN_MAPS; ++i) g += (i < m.n && e >= m.first[i]);
+    return g;
+}
+
+// Neighbouring pixels mostly share their nearest points (a far, isolated point owns thousands of pixels), so the
+// lanes of a wave -- consecutive pixels of one row -- are grouped into runs of equal (map, id): one atomic per run,
+// issued by its first lane, instead of one same-address atomic per pixel.
+struct InvRun { int head, len; };
+__device__ __forceinline__ InvRun inv_run(int key, int lane)
+{
+    const int prev = __shfl_up(key, 1, 64);
+    const unsigned long long heads = __ballot(lane == 0 || key != prev);
+    const unsigned long long below = heads & ((2ull << lane) - 1ull);          // heads at or below this lane
+    InvRun r;
+    r.head = 63 - __clzll(below);
+    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+    r.len = (above ? lane + 1 + (__ffsll((long long)above) - 1) : 64) - r.head;    // valid on the head lane
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_inv_hist(InvMaps m, int n_max, int *cnt)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int key = -1;
+    if (e < m.first[m.n]) {
+        const int g = inv_map_of(m, e);
+        const int id = m.idx[g][e - m.first[g]];
+        if (id >= 0 && id < n_max) key = g * (n_max + 1) + id;
+    }
+    const InvRun r = inv_run(key, lane);
+    if (key >= 0 && r.head == lane) atomicAdd(&cnt[key], r.len);
+}
+
+__global__ void __launch_bounds__(256) k_inv_fill(InvMaps m, int n_max, int *cursor, int *ent_pix, int *ent_pt)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int key = -1, g = 0, id = 0;
+    if (e < m.first[m.n]) {
+        g = inv_map_of(m, e);
+        id = m.idx[g][e - m.first[g]];
+        if (id >= 0 && id < n_max) key = g * (n_max + 1) + id;
+    }
+    const InvRun r = inv_run(key, lane);
+    int base = 0;
+    if (key >= 0 && r.head == lane) base = atomicAdd(&cursor[key], r.len);
+    base = __shfl(base, r.head, 64);
+    if (key < 0) return;
+    const int pos = base + (lane - r.head);
+    const int p = (e - m.first[g]) % m.hw[g];
+    ent_pix[pos] = ((p / m.w[g]) << 16) | (p % m.w[g]);
+    ent_pt[pos] = id;
+}
+
 }  // namespace
 
 // ================================================================== C ABI
@@ -687,5 +757,43 @@ extern "C" int dcf_knn_bev(const float *xyz, const int32_t *count_dev, int n_max
         KNN_CASE(1) KNN_CASE(2) KNN_CASE(3) KNN_CASE(4) KNN_CASE(5) KNN_CASE(6) KNN_CASE(7) KNN_CASE(8)
     }
 #undef KNN_CASE
+    return DCF_OK;
+}
+
+extern "C" size_t dcf_fusion_invert_workspace_bytes(int n_max, int nmaps)
+{
+    const size_t nscan = (size_t)nmaps * (n_max + 1);
+    return sizeof(int) * (2 * nscan + (size_t)cdiv(nscan, CP_TILE) + 8);
+}
+
+extern "C" int dcf_fusion_invert(const dcf_knn_map *maps, int nmaps, int K, int n_max, int32_t *start, int32_t *ent_pix, int32_t *ent_pt,
+                                 void *ws, dcf_stream_t stream)
+{
+    DCF_REQUIRE(maps && start && ent_pix && ent_pt && ws && K >= 1 && n_max >= 1, "dcf_fusion_invert: bad arguments");
+    DCF_REQUIRE(nmaps >= 1 && nmaps <= DCF_MAX_KNN_MAPS, "dcf_fusion_invert: 1..%d maps per call", DCF_MAX_KNN_MAPS);
+    InvMaps m;
+    m.n = nmaps;
+    int64_t tot = 0;
+    for (int i = 0; i < DCF_MAX_KNN_MAPS; ++i) {
+        m.idx[i] = nullptr; m.hw[i] = 1; m.w[i] = 1; m.first[i] = (int)tot;
+        if (i < nmaps) {
+            DCF_REQUIRE(maps[i].idx && maps[i].h >= 1 && maps[i].w >= 1 && maps[i].h < 65536 && maps[i].w < 65536,
+                        "dcf_fusion_invert: map %d: null or pixel coordinates beyond 16 bits", i);
+            m.idx[i] = maps[i].idx; m.hw[i] = maps[i].h * maps[i].w; m.w[i] = maps[i].w;
+            tot += (int64_t)K * m.hw[i];
+        }
+    }
+    m.first[DCF_MAX_KNN_MAPS] = (int)tot;
+    for (int i = nmaps; i <= DCF_MAX_KNN_MAPS; ++i) m.first[i] = (int)tot;
+    DCF_REQUIRE(tot < (1ll << 31), "dcf_fusion_invert: too many pairs");
+    hipStream_t s = S(stream);
+    const int total = (int)tot, nscan = nmaps * (n_max + 1), nsb = cdiv(nscan, CP_TILE);
+    int *cnt = (int *)ws, *cursor = cnt + nscan, *blocksum = cursor + nscan, *totp = blocksum + nsb;
+    DCF_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)nscan, s));
+    DCF_LAUNCH("inv_hist", s, hipLaunchKernelGGL(k_inv_hist, dim3(cdiv(total, 256)), dim3(256), 0, s, m, n_max, cnt));
+    DCF_LAUNCH("scan_blocksum", s, hipLaunchKernelGGL(k_scan_blocksum, dim3(nsb), dim3(CP_THREADS), 0, s, cnt, nscan, blocksum));
+    DCF_LAUNCH("compact_scan", s, hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(CP_THREADS), 0, s, blocksum, nsb, totp));
+    DCF_LAUNCH("scan_apply", s, hipLaunchKernelGGL(k_scan_apply, dim3(nsb), dim3(CP_THREADS), 0, s, cnt, nscan, blocksum, start, cursor));
+    DCF_LAUNCH("inv_fill", s, hipLaunchKernelGGL(k_inv_fill, dim3(cdiv(total, 256)), dim3(256), 0, s, m, n_max, cursor, ent_pix, ent_pt));
     return DCF_OK;
 }

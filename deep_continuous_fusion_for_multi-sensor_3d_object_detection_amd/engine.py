@@ -400,7 +400,15 @@ class Plan(object):
         K.rowscale_bias_bwd(g, s["cnt"], f["b2_off"])
         K.conv_wgrad(f["fc2"], s["hsum"], g)
         ghsum = K.conv_dgrad(f["fc2"], g, tuple(s["hsum"].shape), None)
-        gP = K.fusion_gather_bwd(s["P"], geom["xyz"], geom["idx"][site], f["stride"], geom["aff"], f["w1d_off"], f["b1_off"], ghsum)
+        inv = geom.get("inv")
+        import os
+        if os.environ.get("DCF_FUSION_INV", "1") == "2":
+            inv = None
+        if inv and geom.get("inv_event") is not None and not geom.get("_inv_waited"):
+            K.wait_event(geom["inv_event"])            # inverse KNN maps produced on the geometry side stream
+            geom["_inv_waited"] = True
+        gP = K.fusion_gather_bwd(s["P"], geom["xyz"], geom["idx"][site], f["stride"], geom["aff"], f["w1d_off"], f["b1_off"], ghsum,
+                                 inv, site)
         gPc = K.cast_like(gP, s["P"]).view(B, n_max, 1, cb)
         fp4 = s["fp"].view(B, n_max, 1, s["fp"].shape[-1])
         K.conv_wgrad(f["fc1_feat"], fp4, gPc)

@@ -313,6 +313,18 @@ class ObjectDetection_DCF(nn.Module):
                                                 self.r_max) for b in range(B)], 0))
         return dict(xyz=points.contiguous(), uv=uv.contiguous(), cnt=cnt, idx=idx, aff=self._grid.aff)
 
+    def fusion_inverse(self, geom):
+        """The fusion backward gathers by POINT: invert every site's KNN map (pairs sorted by point id).  Only the
+        backward needs it, so a caller with a side stream records its own event after this (train.geometry_async)."""
+        from . import ops
+        import os
+        if os.environ.get("DCF_FUSION_INV", "1") == "0":
+            return geom
+        n_max = geom["xyz"].shape[1]
+        maps = [t[b] for t in geom["idx"] for b in range(t.shape[0])]          # map index = site * B + frame
+        geom["inv"] = ops.fusion_invert(maps, n_max)
+        return geom
+
     def forward(self, x_lidar, x_image, points=None, uv=None, n_valid=None, geom=None):
         """geom: optional result of fusion_geometry() computed ahead of time (e.g. on a side stream, see
         train.Train.geometry_async); otherwise it is derived here from points / uv / n_valid."""
@@ -323,6 +335,8 @@ class ObjectDetection_DCF(nn.Module):
             geom = None
         elif geom is None and points is not None:
             geom = self.fusion_geometry(points, uv, n_valid)
+            if torch.is_grad_enabled():
+                self.fusion_inverse(geom)
         bn_train = self.bn_mode == "train" or (self.bn_mode == "module" and self.training)
         K.set_bn_mode(bn_train)
         if bn_train:

@@ -4,6 +4,8 @@ Each function takes torch CUDA tensors (NHWC activations, compute dtype f32 or b
 allocates the output with torch (device memory = plumbing) and enqueues the HIP kernel on
 torch's current stream.  No arithmetic happens in torch here.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -270,6 +272,33 @@ def fusion_gather_bwd(dtype, P, xyz, idx, stride, aff, w1d, b1, ghsum, gP, gw1d,
     Cb = P.shape[1]
     H.call("dcf_fusion_gather_bwd", dtype, P, xyz, idx, K, h, w, stride, float(aff[0]), float(aff[1]), float(aff[2]), float(aff[3]),
            w1d, b1, Cb, ghsum, gP, gw1d, gb1, H.stream_ptr())
+
+
+def fusion_invert(maps, n_max):
+    """maps: list of KNN maps [K,h,w] (sites x frames of a step).  Returns (start [len(maps)*(n_max+1)], ent [2, pairs]):
+    the (pixel, point) pairs of all maps sorted by (map, point) -- see dcf_fusion_invert."""
+    K = maps[0].shape[0]
+    dev = maps[0].device
+    tab = (H.KnnMap * len(maps))()
+    total = 0
+    for i, t in enumerate(maps):
+        assert t.dtype == torch.int32 and t.is_contiguous() and t.shape[0] == K
+        tab[i] = H.KnnMap(t.data_ptr(), t.shape[1], t.shape[2])
+        total += t.numel()
+    start = torch.empty((len(maps) * (n_max + 1),), dtype=torch.int32, device=dev)
+    ent = torch.empty((2, total), dtype=torch.int32, device=dev)
+    ws = torch.empty((H.lib().dcf_fusion_invert_workspace_bytes(n_max, len(maps)),), dtype=torch.uint8, device=dev)
+    H.call("dcf_fusion_invert", ctypes.addressof(tab), len(maps), K, n_max, start, ent[0], ent[1], ws, H.stream_ptr())
+    return start, ent
+
+
+def fusion_gather_bwd_inv(dtype, P, xyz, inv, g, khw, stride, aff, w1d, b1, ghsum, gP, gw1d, gb1):
+    """g: index of this (site, frame) map in the fusion_invert call; khw = (K, h, w) of the map."""
+    start, ent = inv
+    n_max, Cb = P.shape
+    seg = start[g * (n_max + 1):]
+    H.call("dcf_fusion_gather_bwd_inv", dtype, P, xyz, seg, seg[n_max:], ent[0], ent[1], khw[0] * khw[1] * khw[2], khw[1], khw[2], stride,
+           float(aff[0]), float(aff[1]), float(aff[2]), float(aff[3]), w1d, b1, Cb, ghsum, gP, gw1d, gb1, H.stream_ptr())
 
 
 def rowscale_bias_fwd(dtype, y, cnt, b2):

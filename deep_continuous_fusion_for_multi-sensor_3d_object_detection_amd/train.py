@@ -87,12 +87,18 @@ class Train(nn.Module):
                 ev = torch.cuda.Event()
                 ev.record()
                 geom["event"] = ev
+                self.model.fusion_inverse(geom)        # needed by the backward only: its own event
+                ev_inv = torch.cuda.Event()
+                ev_inv.record()
+                geom["inv_event"] = ev_inv
             else:
                 geom = {}
             geom["voxel_event"] = ev_vox
         # tensors born on the side stream are consumed on the compute stream
         x_lidar.record_stream(main)
-        for t in [geom.get("xyz"), geom.get("uv"), geom.get("cnt")] + list(geom.get("idx") or []):
+        born = [geom.get("xyz"), geom.get("uv"), geom.get("cnt")] + list(geom.get("idx") or [])
+        born += list(geom.get("inv") or [])
+        for t in born:
             if t is not None:
                 t.record_stream(main)
         return x_lidar, geom

@@ -84,6 +84,17 @@ int dcf_knn_bev(const float *xyz, const int32_t *count_dev, int n_max, int K, in
                 float xs, float xo, float ys, float yo, float rmax2, int32_t *idx_out, void *ws,
                 dcf_stream_t stream);
 
+/* Inverse of the KNN maps of a step (sites x frames) for the fusion backward: the (pixel, point) pairs of every
+ * idx [K][h][w] counting-sorted by (map, point).  start int32 [nmaps*(n_max+1)]: pairs of point q of map g are
+ * [start[g*(n_max+1)+q], start[g*(n_max+1)+q+1]); ent_pix / ent_pt int32 [sum K*h*w] (pixel packed (i<<16)|j).
+ * maps is a HOST array.  ws: dcf_fusion_invert_workspace_bytes(n_max, nmaps).  Pair order inside a point is not
+ * deterministic (atomic cursor). */
+#define DCF_MAX_KNN_MAPS 16
+typedef struct { const int32_t *idx; int32_t h, w; } dcf_knn_map;
+size_t dcf_fusion_invert_workspace_bytes(int n_max, int nmaps);
+int dcf_fusion_invert(const dcf_knn_map *maps, int nmaps, int K, int n_max, int32_t *start, int32_t *ent_pix, int32_t *ent_pt,
+                      void *ws, dcf_stream_t stream);
+
 /* ------------------------------------------------------------ layout / input
  * NCHW fp32 -> NHWC dtype (the model keeps the reference's NCHW voxel input, model.py:194). */
 int dcf_nchw_to_nhwc(int dtype, const float *x, void *y, int B, int C, int H, int W, dcf_stream_t stream);
@@ -215,6 +226,14 @@ int dcf_cast(int dtype_src, const void *src, int dtype_dst, void *dst, int64_t n
  * (1/world_size after the all-reduce). */
 int dcf_adam_step(float *params, const float *grads, float *m, float *v, int64_t n, float lr, float beta1,
                   float beta2, float eps, int step, float gscale, dcf_stream_t stream);
+
+/* dcf_fusion_gather_bwd driven by dcf_fusion_invert's pairs (Cb in {64,128,192,256}): same sums, no idx -> point -> row
+ * dependency chain.  The map's pairs are [*e_begin, *e_end) = start[g*(n_max+1)], start[g*(n_max+1)+n_max];
+ * max_entries = K*h*w sizes the grid. */
+int dcf_fusion_gather_bwd_inv(int dtype, const void *P, const float *xyz, const int32_t *e_begin, const int32_t *e_end,
+                              const int32_t *ent_pix, const int32_t *ent_pt, int max_entries, int h, int w, int stride, float xs,
+                              float xo, float ys, float yo, const float *w1d, const float *b1, int Cb, const void *ghsum, float *gP,
+                              float *gw1d, float *gb1, dcf_stream_t stream);
 
 /* ------------------------------------------------------------- detection objective (loss.py:129-189)
  * Device half of LossTotal: 2-way cross-entropy at the sampled cells of both anchors + Smooth-L1 of the encoded box
