@@ -42,9 +42,16 @@ class FrameGeometry(object):
         batch tensor to write the grid into (saves the stack copy)."""
         pts = lidar_points.to(device="cuda", dtype=torch.float32).contiguous()
         g = self.grid
-        if self.voxel_mode == H.VOXEL_COMPAT and (self._owner is None or self._owner.device != pts.device):
-            self._owner = torch.zeros((2, g.dims[0] * g.dims[1] * g.dims[2]), dtype=torch.int32, device=pts.device)
-        voxel = ops.voxelize(pts, g.lim, g.aff, g.dims, self.voxel_mode, self._owner, voxel_out)
+        owner = None
+        if self.voxel_mode == H.VOXEL_COMPAT:
+            # one owner-map workspace per (device, stream): frames voxelised on different streams must not share it
+            key = (pts.device, H.stream_ptr())
+            if self._owner is None:
+                self._owner = {}
+            owner = self._owner.get(key)
+            if owner is None:
+                owner = self._owner[key] = torch.zeros((2, g.dims[0] * g.dims[1] * g.dims[2]), dtype=torch.int32, device=pts.device)
+        voxel = ops.voxelize(pts, g.lim, g.aff, g.dims, self.voxel_mode, owner, voxel_out)
         ulim, vlim = self.limits()
         n_out = max(int(self.config["max_num_pc"]), pts.shape[0])
         uv, xyz, cnt, _ = ops.project_filter(pts, g.lim, self.crt, ulim, vlim, self.proj_mode, n_out=n_out)
