@@ -608,6 +608,9 @@ int launch_igemm(const ConvArgs &a_in, hipStream_t s, const char *base, double f
         if (ES == 2 && KB_ == 128 && dma_mode && (dma_mode == 2 || db)) {                                            \
             snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d,dma%d>", base, KB_, TN_, TM_, WN_, WM_, NS_);            \
             DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm_dma<TN_, TM_, WN_, WM_, TR, NS_>), grid, dim3(256), 0, s, a)); \
+        } else if (ES == 2 && KB_ == 128 && dma_mode == 3) {   /* many workgroups: 2-deep ring keeps 2+ of them per CU */ \
+            snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d,dma2>", base, KB_, TN_, TM_, WN_, WM_);                  \
+            DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm_dma<TN_, TM_, WN_, WM_, TR, 2>), grid, dim3(256), 0, s, a)); \
         } else if (db) DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR, true>), grid, dim3(256), 0, s, a)); \
         else DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR, false>), grid, dim3(256), 0, s, a)); \
         if (a.dbg & 4) {                                                                                            \

@@ -168,3 +168,41 @@ def test_side_stream_geometry_matches_inline():
         b = trainer.model(torch.stack(vox), img.cuda(), points=torch.stack(pcs), uv=torch.stack(uvs), n_valid=torch.cat(cnts))
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("Cb,K,case", [(64, 3, "random"), (128, 5, "random"), (192, 1, "random"), (256, 3, "random"),
+                                       (64, 3, "one_point"), (128, 3, "no_points")])
+def test_fusion_backward_by_point_matches_pixel_run_kernel(Cb, K, case):
+    """dcf_fusion_invert + dcf_fusion_gather_bwd_inv (pairs sorted by point) against dcf_fusion_gather_bwd (pixel runs)
+    on the same KNN map: dP, dW1d, db1.  Edge cases: one point owning every pixel (runs far longer than a wave's
+    slice), no valid point at all (every index -1)."""
+    ops, H = pkg("ops"), pkg("_hip")
+    g = torch.Generator().manual_seed(7)
+    h, w, stride, n_max = 24, 40, 4, 300
+    aff = (10.0, 0.0, 10.0, 400.0)
+    n = {"random": 200, "one_point": 1, "no_points": 0}[case]
+    xyz = torch.zeros(n_max, 3)
+    xyz[:n, 0] = torch.rand(n, generator=g) * (h * stride / aff[0])
+    xyz[:n, 1] = torch.rand(n, generator=g) * (w * stride / aff[2]) - aff[3] / aff[2]
+    xyz[:n, 2] = torch.rand(n, generator=g) * 2 - 1
+    xyz = xyz.cuda()
+    cnt = torch.tensor([n], dtype=torch.int32, device="cuda")
+    idx = ops.knn_bev(xyz, cnt, K, h, w, stride, aff)
+    assert int((idx >= 0).sum()) == (min(K, n) * h * w)
+    P = (torch.rand(n_max, Cb, generator=g) - 0.5).cuda()
+    ghs = (torch.rand(h, w, Cb, generator=g) - 0.5).cuda()
+    w1d = ((torch.rand(Cb, 3, generator=g) - 0.5) * 0.2).cuda().reshape(-1)
+    b1 = ((torch.rand(Cb, generator=g) - 0.5) * 0.2).cuda()
+    for dtype, tol in ((H.F32, 2e-5), (H.BF16, 2e-5)):
+        Pd = P.to(H.torch_dtype(dtype))
+        gd = ghs.to(H.torch_dtype(dtype))
+        ref = [torch.zeros(n_max, Cb, device="cuda"), torch.zeros(Cb * 3, device="cuda"), torch.zeros(Cb, device="cuda")]
+        ops.fusion_gather_bwd(dtype, Pd, xyz, idx, stride, aff, w1d, b1, gd, *ref)
+        got = [torch.zeros_like(t) for t in ref]
+        inv = ops.fusion_invert([idx], n_max)
+        start = inv[0].cpu()
+        assert int(start[0]) == 0 and int(start[n_max]) == min(K, n) * h * w
+        ops.fusion_gather_bwd_inv(dtype, Pd, xyz, inv, 0, (K, h, w), stride, aff, w1d, b1, gd, *got)
+        for a, b in zip(got, ref):
+            scale = max(float(b.abs().max()), 1e-6)
+            assert float((a - b).abs().max()) <= tol * scale * max(1.0, (h * w) ** 0.5), (case, Cb, float((a - b).abs().max()), scale)
