@@ -5,6 +5,8 @@
 //
 // All activations are NHWC; every kernel moves 8-16 B per lane and is priced against the
 // HBM roofline.  Reference lines are cited per kernel.
+#include <stdlib.h>
+
 #include "dcf_common.h"
 
 namespace {
@@ -439,7 +441,8 @@ __global__ void __launch_bounds__(256) k_weight_prep(const dcf_conv_param *table
 // wgrad slabs (16 B per lane, 4 independent partial sums), then the folded-BN chain rule
 //   dW = scale*G ; dbeta = sum g ; dgamma = (<W,G> - mean*dbeta) * rsqrt(var+eps).
 __global__ void __launch_bounds__(256) k_wgrad_finalize(const dcf_conv_param *table, const float *params, const float *buffers,
-                                                        const float *ssarena, const float *slabs, const float *gsum, float *grads, float eps)
+                                                        const float *ssarena, const float *slabs, const float *gsum, float *grads, float eps,
+                                                        int grouped)
 {
     const dcf_conv_param d = table[blockIdx.y];
     const int co = blockIdx.x;
@@ -453,7 +456,7 @@ __global__ void __launch_bounds__(256) k_wgrad_finalize(const dcf_conv_param *ta
     // and are added in group order, so the result does not depend on timing.
     __shared__ float4 gpart[256];
     const int K4 = K >> 2;
-    const int G = K4 >= 256 ? 1 : 256 / K4;
+    const int G = (K4 >= 256 || !grouped) ? 1 : 256 / K4;
     const int grp = G == 1 ? 0 : threadIdx.x / K4;
     const int kbeg = G == 1 ? threadIdx.x * 4 : (threadIdx.x - grp * K4) * 4;
     const int kstep = G == 1 ? blockDim.x * 4 : K;             // grouped rows: one pass
@@ -850,7 +853,9 @@ extern "C" int dcf_wgrad_finalize(const dcf_conv_param *table, int nconv, int ma
 {
     DCF_REQUIRE(table && nconv > 0 && max_cout > 0 && params && ssarena && slabs && gsum && grads, "dcf_wgrad_finalize: bad arguments");
     hipStream_t s = S(stream);
-    DCF_LAUNCH("wgrad_finalize", s, hipLaunchKernelGGL(k_wgrad_finalize, dim3(max_cout, nconv), dim3(256), 0, s, table, params, buffers, ssarena, slabs, gsum, grads, eps));
+    static const char *grp_env = getenv("DCF_FINALIZE_GROUPS");
+    const int grouped = grp_env ? atoi(grp_env) : 1;
+    DCF_LAUNCH("wgrad_finalize", s, hipLaunchKernelGGL(k_wgrad_finalize, dim3(max_cout, nconv), dim3(256), 0, s, table, params, buffers, ssarena, slabs, gsum, grads, eps, grouped));
     return DCF_OK;
 }
 
