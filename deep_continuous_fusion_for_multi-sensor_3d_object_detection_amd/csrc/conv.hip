@@ -1631,7 +1631,7 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
 #undef DCF_WG3G
             if (a.dbg & 2) {
                 long long tt[8];
-                hipStreamSynchronize(s);
+                (void)hipStreamSynchronize(s);
                 (void)hipMemcpyFromSymbol(tt, HIP_SYMBOL(g_dcf_dbg_t), sizeof(tt));
                 fprintf(stderr, "[wgrad3g %dx%d %d->%d ns=%d] clocks: prologue %lld loop %lld wait %lld epilogue %lld (100 MHz ticks x?)\n", Ho, Wo, Cin, Cout, nsplit,
                         tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3]);
