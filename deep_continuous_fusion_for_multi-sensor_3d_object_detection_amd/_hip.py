@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdcf_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 VOXEL_COMPAT, VOXEL_ACCUM = 0, 1
 PROJ_COMPAT, PROJ_CORRECT = 0, 1
 
@@ -151,11 +151,13 @@ def dtype_code(dt):
         return F32
     if dt in (torch.bfloat16, "bf16", BF16):
         return BF16
-    raise DcfError("unsupported compute dtype %r (f32 or bf16)" % (dt,))
+    if dt in (torch.float16, "f16", "fp16", F16):
+        return F16
+    raise DcfError("unsupported compute dtype %r (f32, bf16 or f16)" % (dt,))
 
 
 def torch_dtype(code):
-    return torch.float32 if code == F32 else torch.bfloat16
+    return {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[code]
 
 
 def host_f32(values):

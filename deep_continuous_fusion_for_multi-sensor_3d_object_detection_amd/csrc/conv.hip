@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include "dcf_common.h"
 
 namespace {
@@ -94,6 +95,13 @@ template <> struct Mma<bf16_t> {
     __device__ static __forceinline__ void run(const uint4 &a, const uint4 &b, f32x16 &acc)
     {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+};
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <> struct Mma<f16_t> {
+    __device__ static __forceinline__ void run(const uint4 &a, const uint4 &b, f32x16 &acc)
+    {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
     }
 };
 template <> struct Mma<float> {
@@ -369,10 +377,10 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
 // LDS rows have no pad (the DMA image is lane-linear): 16-B chunk c of row R sits at position c ^ ((R >> 1) & 7), which
 // keeps the 16 rows of a ds_read_b128 lane group on distinct banks; the swizzle is applied to the source chunk and to the reads.
 // ------------------------------------------------------------------------------------
-template <int TN, int TM, int WN, int WM, bool TRANSPOSED, int NS>
+template <typename T, int TN, int TM, int WN, int WM, bool TRANSPOSED, int NS>
 __global__ void __launch_bounds__(256) k_conv_igemm_dma(ConvArgs a)
 {
-    typedef bf16_t T;
+    static_assert(DT<T>::size == 2, "16-bit element types only");
     constexpr int ES = 2, KB = 128;
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
     constexpr int PW = BN / 32, PX = BM / 32;          // DMA pieces (8 rows) per wave and chunk: weights, pixels
@@ -605,12 +613,19 @@ int launch_igemm(const ConvArgs &a_in, hipStream_t s, const char *base, double f
         constexpr int NS_ = (BN_ + BM_) <= 128 ? 4 : 3;                                                              \
         static const char *dma_env = getenv("DCF_IGEMM_DMA");                                                       \
         const int dma_mode = dma_env ? atoi(dma_env) : 1;      /* 0 off, 1 small-M tiles, 2 every bf16 KB=128 launch */ \
-        if (ES == 2 && KB_ == 128 && dma_mode && (dma_mode == 2 || db)) {                                            \
-            snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d,dma%d>", base, KB_, TN_, TM_, WN_, WM_, NS_);            \
-            DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm_dma<TN_, TM_, WN_, WM_, TR, NS_>), grid, dim3(256), 0, s, a)); \
-        } else if (ES == 2 && KB_ == 128 && dma_mode == 3) {   /* many workgroups: 2-deep ring keeps 2+ of them per CU */ \
-            snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d,dma2>", base, KB_, TN_, TM_, WN_, WM_);                  \
-            DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm_dma<TN_, TM_, WN_, WM_, TR, 2>), grid, dim3(256), 0, s, a)); \
+        bool launched = false;                                                                                      \
+        if constexpr (ES == 2 && KB_ == 128) {                                                                      \
+            if (dma_mode && (dma_mode == 2 || db)) {                                                                 \
+                snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d,dma%d>", base, KB_, TN_, TM_, WN_, WM_, NS_);        \
+                DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm_dma<T, TN_, TM_, WN_, WM_, TR, NS_>), grid, dim3(256), 0, s, a)); \
+                launched = true;                                                                                    \
+            } else if (dma_mode == 3) {   /* many workgroups: 2-deep ring keeps 2+ of them per CU */                  \
+                snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d,dma2>", base, KB_, TN_, TM_, WN_, WM_);              \
+                DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm_dma<T, TN_, TM_, WN_, WM_, TR, 2>), grid, dim3(256), 0, s, a)); \
+                launched = true;                                                                                    \
+            }                                                                                                       \
+        }                                                                                                           \
+        if (launched) {                                                                                             \
         } else if (db) DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR, true>), grid, dim3(256), 0, s, a)); \
         else DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR, false>), grid, dim3(256), 0, s, a)); \
         if (a.dbg & 4) {                                                                                            \
@@ -807,14 +822,13 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgArgs a)
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
-                                                                            acc[i][j], 0, 0, 0);
+                        Mma<T>::run(fa[i], fb[j], acc[i][j]);
                 if (do_sum) {   // lane (channel r, half h) holds 8 of the 16 pixels of this step
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         const unsigned w[4] = {fa[i].x, fa[i].y, fa[i].z, fa[i].w};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) fsum[i] += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xffff0000u);
+                        for (int e = 0; e < 4; ++e) { float lo, hi; unpack2<T>(w[e], lo, hi); fsum[i] += lo + hi; }
                     }
                 }
             }
@@ -1072,15 +1086,14 @@ __global__ void __launch_bounds__(256, 2) k_conv_wgrad3(WgArgs a)
                         for (int i = 0; i < TM; ++i)
 #pragma unroll
                             for (int j = 0; j < TN; ++j)
-                                acc[kr][kj][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
-                                                                                            acc[kr][kj][i][j], 0, 0, 0);
+                                Mma<T>::run(fa[i], fb[j], acc[kr][kj][i][j]);
                     }
                 if (do_sum) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         const unsigned w[4] = {fa[i].x, fa[i].y, fa[i].z, fa[i].w};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) fsum[i] += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xffff0000u);
+                        for (int e = 0; e < 4; ++e) { float lo, hi; unpack2<T>(w[e], lo, hi); fsum[i] += lo + hi; }
                     }
                 }
             }
@@ -1200,9 +1213,10 @@ __global__ void __launch_bounds__(256, 2) k_conv_wgrad3(WgArgs a)
 // ------------------------------------------------------------------------------------
 
 
-template <int TM, int TN, int NS, int NW>
+template <typename T, int TM, int TN, int NS, int NW>
 __global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g(WgArgs a)
 {
+    static_assert(DT<T>::size == 2, "16-bit element types only");
     constexpr int PK = 32, XROWS = PK + 2;
     constexpr int RA = TM * 64, RB = TN * 64;        // row bytes = LDS pitch
     constexpr int LPA = RA / 16, LPB = RB / 16;      // lanes (16-B chunks) per row
@@ -1374,15 +1388,14 @@ __global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g(WgArgs a)
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[kj][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
-                                                                                acc[kj][i][j], 0, 0, 0);
+                        Mma<T>::run(fa[i], fb[j], acc[kj][i][j]);
             }
             if (do_sum) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const unsigned w[4] = {fa[i].x, fa[i].y, fa[i].z, fa[i].w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) fsum[i] += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xffff0000u);
+                    for (int e = 0; e < 4; ++e) { float lo, hi; unpack2<T>(w[e], lo, hi); fsum[i] += lo + hi; }
                 }
             }
         }
@@ -1468,7 +1481,7 @@ __global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g(WgArgs a)
 static int check_conv(const char *who, int dtype, int Cin, int Cout, int kh, int kw, int stride)
 {
     const int es = dtype == DCF_F32 ? 4 : 2;
-    DCF_REQUIRE(dtype == DCF_F32 || dtype == DCF_BF16, "%s: unsupported dtype %d", who, dtype);
+    DCF_REQUIRE(dtype == DCF_F32 || dtype == DCF_BF16 || dtype == DCF_F16, "%s: unsupported dtype %d", who, dtype);
     DCF_REQUIRE((Cin * es) % 64 == 0, "%s: Cin*esize must be a multiple of 64 bytes (Cin=%d)", who, Cin);
     DCF_REQUIRE(Cout % 32 == 0, "%s: Cout must be a multiple of 32 (Cout=%d)", who, Cout);
     DCF_REQUIRE(kh >= 1 && kw >= 1 && kh <= 7 && kw <= 7, "%s: kernel size %dx%d unsupported", who, kh, kw);
@@ -1496,6 +1509,7 @@ extern "C" int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const flo
     a.wbytes = (unsigned)((int64_t)Cout * kh * kw * a.pixbytes);
     const double flops = 2.0 * a.M * Cout * (double)Cin * kh * kw;
     if (dtype == DCF_F32) return launch_igemm<float, false>(a, S(stream), "conv_fwd_f32", flops);
+    if (dtype == DCF_F16) return launch_igemm<f16_t, false>(a, S(stream), "conv_fwd_f16", flops);
     return launch_igemm<bf16_t, false>(a, S(stream), "conv_fwd_bf16", flops);
 }
 
@@ -1526,6 +1540,7 @@ extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const
     a.wbytes = (unsigned)((int64_t)Cin * kh * kw * a.pixbytes);
     const double flops = 2.0 * B * Ho * Wo * Cout * (double)Cin * kh * kw;   // algorithmic (= the forward conv's)
     if (dtype == DCF_F32) return launch_igemm<float, true>(a, S(stream), "conv_dgrad_f32", flops);
+    if (dtype == DCF_F16) return launch_igemm<f16_t, true>(a, S(stream), "conv_dgrad_f16", flops);
     return launch_igemm<bf16_t, true>(a, S(stream), "conv_dgrad_bf16", flops);
 }
 
@@ -1609,7 +1624,7 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
     const double flops = 2.0 * a.M * Cout * (double)Cin * kh * kw;
     int TM, TN, KR;
     if (pad == 1 && H == Ho && W == Wo && wgrad3_tiles(Cin, Cout, kh, kw, stride, TM, TN, KR)) {
-        const bool dma = dtype == DCF_BF16 && wgrad3_dma(Wo, TM, TN) && (int64_t)B * H * W * a.pixbytes < (1ll << 31) && (int64_t)a.M * Cout * 2 < (1ll << 31);
+        const bool dma = dtype != DCF_F32 && wgrad3_dma(Wo, TM, TN) && (int64_t)B * H * W * a.pixbytes < (1ll << 31) && (int64_t)a.M * Cout * 2 < (1ll << 31);
         if (dtype == DCF_F32 && TM == 2 && TN == 2) TN = 1;   // fp32 accumulators + fragments of 2x2x3 do not fit 256 VGPRs
         a.M = B * Ho * (Wo + 2);                           // padded positions (see k_conv_wgrad3)
         a.per_split = cdiv(cdiv(a.M, 4 * nsplit), 32) * 32;
@@ -1620,15 +1635,17 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
             const int NW = wgrad3_nw();
             a.per_split = cdiv(cdiv(a.M, NW * nsplit), 32) * 32;
             grid3 = dim3(8 * 3 * cdiv(a.co_tiles * a.ci_tiles * nsplit, 8));    // see the kernel's work mapping
-#define DCF_WG3G(TM_, TN_)                                                                                                                              \
+#define DCF_WG3G_T(T_, N_, TM_, TN_)                                                                                                                    \
     do {                                                                                                                                                \
-        if (NW == 8) DCF_LAUNCH_W("conv_wgrad3g_bf16<" #TM_ "," #TN_ ",2,8>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3g<TM_, TN_, 2, 8>), grid3, dim3(512), 0, s, a)); \
-        else DCF_LAUNCH_W("conv_wgrad3g_bf16<" #TM_ "," #TN_ ",4,4>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3g<TM_, TN_, 4, 4>), grid3, dim3(256), 0, s, a));        \
+        if (NW == 8) DCF_LAUNCH_W("conv_wgrad3g_" N_ "<" #TM_ "," #TN_ ",2,8>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3g<T_, TM_, TN_, 2, 8>), grid3, dim3(512), 0, s, a)); \
+        else DCF_LAUNCH_W("conv_wgrad3g_" N_ "<" #TM_ "," #TN_ ",4,4>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3g<T_, TM_, TN_, 4, 4>), grid3, dim3(256), 0, s, a));        \
     } while (0)
+#define DCF_WG3G(TM_, TN_) do { if (dtype == DCF_F16) DCF_WG3G_T(f16_t, "f16", TM_, TN_); else DCF_WG3G_T(bf16_t, "bf16", TM_, TN_); } while (0)
             if (TM == 2 && TN == 2) DCF_WG3G(2, 2);
             else if (TM == 2) DCF_WG3G(2, 1);
             else DCF_WG3G(1, 2);
 #undef DCF_WG3G
+#undef DCF_WG3G_T
             if (a.dbg & 2) {
                 long long tt[8];
                 (void)hipStreamSynchronize(s);
@@ -1641,11 +1658,13 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
 #define DCF_WG3(T_, NAME_)                                                                                                                           \
     do {                                                                                                                                             \
         if (KR == 3) DCF_LAUNCH_W(NAME_ "<1,1,3>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3<T_, 1, 1, 3>), grid3, dim3(256), 0, s, a));            \
-        else if (TM == 2 && TN == 2) DCF_LAUNCH_W(NAME_ "<2,2,1>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3<bf16_t, 2, 2, 1>), grid3, dim3(256), 0, s, a)); \
+        else if (TM == 2 && TN == 2) DCF_LAUNCH_W(NAME_ "<2,2,1>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3<typename std::conditional<std::is_same<T_, float>::value, bf16_t, T_>::type, 2, 2, 1>), grid3, dim3(256), 0, s, a)); \
         else if (TM == 2) DCF_LAUNCH_W(NAME_ "<2,1,1>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3<T_, 2, 1, 1>), grid3, dim3(256), 0, s, a));       \
         else DCF_LAUNCH_W(NAME_ "<1,2,1>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3<T_, 1, 2, 1>), grid3, dim3(256), 0, s, a));                    \
     } while (0)
-        if (dtype == DCF_F32) DCF_WG3(float, "conv_wgrad3_f32"); else DCF_WG3(bf16_t, "conv_wgrad3_bf16");
+        if (dtype == DCF_F32) DCF_WG3(float, "conv_wgrad3_f32");
+        else if (dtype == DCF_F16) DCF_WG3(f16_t, "conv_wgrad3_f16");
+        else DCF_WG3(bf16_t, "conv_wgrad3_bf16");
 #undef DCF_WG3
         return DCF_OK;
     }
@@ -1661,7 +1680,9 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
         else if (TN == 2) DCF_LAUNCH_W(NAME_ "<1,2>", flops, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 1, 2>), grid, dim3(256), 0, s, a));         \
         else DCF_LAUNCH_W(NAME_ "<1,1>", flops, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 1, 1>), grid, dim3(256), 0, s, a));                      \
     } while (0)
-    if (dtype == DCF_F32) DCF_WG(float, "conv_wgrad_f32"); else DCF_WG(bf16_t, "conv_wgrad_bf16");
+    if (dtype == DCF_F32) DCF_WG(float, "conv_wgrad_f32");
+    else if (dtype == DCF_F16) DCF_WG(f16_t, "conv_wgrad_f16");
+    else DCF_WG(bf16_t, "conv_wgrad_bf16");
 #undef DCF_WG
     return DCF_OK;
 }
@@ -1689,6 +1710,7 @@ extern "C" int dcf_stem7x7_fwd(int dtype, const void *img4, const void *w, const
     a.wbytes = (unsigned)((int64_t)Cout * 7 * 32 * (dtype == DCF_F32 ? 4 : 2));
     const double flops = 2.0 * a.M * Cout * 147.0;   // 7x7x3 taps (the padded K of 224 is not algorithmic work)
     if (dtype == DCF_F32) return launch_igemm<float, false>(a, S(stream), "stem_fwd_f32", flops);
+    if (dtype == DCF_F16) return launch_igemm<f16_t, false>(a, S(stream), "stem_fwd_f16", flops);
     return launch_igemm<bf16_t, false>(a, S(stream), "stem_fwd_bf16", flops);
 }
 
@@ -1715,6 +1737,9 @@ extern "C" int dcf_stem7x7_wgrad(int dtype, const void *img4, const void *gy, fl
     if (dtype == DCF_F32) {
         if (TM == 2) DCF_LAUNCH_W("stem_wgrad_f32", sflops, s, hipLaunchKernelGGL((k_conv_wgrad<float, 2, 1>), grid, dim3(256), 0, s, a));
         else DCF_LAUNCH_W("stem_wgrad_f32", sflops, s, hipLaunchKernelGGL((k_conv_wgrad<float, 1, 1>), grid, dim3(256), 0, s, a));
+    } else if (dtype == DCF_F16) {
+        if (TM == 2) DCF_LAUNCH_W("stem_wgrad_f16", sflops, s, hipLaunchKernelGGL((k_conv_wgrad<f16_t, 2, 1>), grid, dim3(256), 0, s, a));
+        else DCF_LAUNCH_W("stem_wgrad_f16", sflops, s, hipLaunchKernelGGL((k_conv_wgrad<f16_t, 1, 1>), grid, dim3(256), 0, s, a));
     } else {
         if (TM == 2) DCF_LAUNCH_W("stem_wgrad_bf16", sflops, s, hipLaunchKernelGGL((k_conv_wgrad<bf16_t, 2, 1>), grid, dim3(256), 0, s, a));
         else DCF_LAUNCH_W("stem_wgrad_bf16", sflops, s, hipLaunchKernelGGL((k_conv_wgrad<bf16_t, 1, 1>), grid, dim3(256), 0, s, a));

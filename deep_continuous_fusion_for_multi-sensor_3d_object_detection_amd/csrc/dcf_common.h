@@ -63,6 +63,27 @@ __device__ __forceinline__ bf16_t f2bf(float f)
 }
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
 
+// IEEE half: raw bits in a type of its own (overloads must tell it from bf16_t)
+struct f16_t { unsigned short v; };
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float h2f(f16_t h) { return (float)__builtin_bit_cast(_Float16, h.v); }
+__device__ __forceinline__ f16_t f2h(float f)
+{
+    f16_t r;
+    r.v = __builtin_bit_cast(unsigned short, (_Float16)f);   // v_cvt_f16_f32: RNE, overflow -> inf
+    return r;
+}
+// two packed 16-bit elements of a 32-bit word -> floats (element 0 in the low half)
+template <typename T> __device__ __forceinline__ void unpack2(unsigned w, float &lo, float &hi);
+template <> __device__ __forceinline__ void unpack2<bf16_t>(unsigned w, float &lo, float &hi)
+{
+    lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack2<f16_t>(unsigned w, float &lo, float &hi)
+{
+    lo = (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); hi = (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+}
+
 template <typename T> struct DT;
 template <> struct DT<float> {
     static constexpr int size = 4;
@@ -73,6 +94,12 @@ template <> struct DT<bf16_t> {
     static constexpr int size = 2;
     __device__ static __forceinline__ float ld(const bf16_t *p) { return bf2f(*p); }
     __device__ static __forceinline__ void st(bf16_t *p, float v) { *p = f2bf(v); }
+};
+
+template <> struct DT<f16_t> {
+    static constexpr int size = 2;
+    __device__ static __forceinline__ float ld(const f16_t *p) { return h2f(*p); }
+    __device__ static __forceinline__ void st(f16_t *p, float v) { *p = f2h(v); }
 };
 
 // load/store 4 consecutive channels as float4
@@ -90,6 +117,18 @@ __device__ __forceinline__ void st4(bf16_t *p, float4 v)
     u.x = pack2bf(v.x, v.y);
     u.y = pack2bf(v.z, v.w);
     *reinterpret_cast<uint2 *>(p) = u;
+}
+
+__device__ __forceinline__ float4 ld4(const f16_t *p)
+{
+    const h16x4 v = *reinterpret_cast<const h16x4 *>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void st4(f16_t *p, float4 v)
+{
+    h16x4 h;
+    h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+    *reinterpret_cast<h16x4 *>(p) = h;
 }
 
 // wave64 reductions
@@ -112,6 +151,9 @@ __device__ __forceinline__ int wave_sum_i(int v)
         __VA_ARGS__                                           \
     } else if ((dtype) == DCF_BF16) {                         \
         typedef bf16_t T;                                     \
+        __VA_ARGS__                                           \
+    } else if ((dtype) == DCF_F16) {                          \
+        typedef f16_t T;                                      \
         __VA_ARGS__                                           \
     } else {                                                  \
         dcf_set_error("unsupported dtype %d", (int)(dtype));  \

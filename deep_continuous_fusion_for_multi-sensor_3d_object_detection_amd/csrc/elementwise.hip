@@ -878,11 +878,16 @@ extern "C" int dcf_cast(int dtype_src, const void *src, int dtype_dst, void *dst
     const int64_t n4 = n / 4;
     if (n4 == 0) return DCF_OK;
     dim3 g(cdiv(n4, 256)), b(256);
-    if (dtype_src == DCF_F32 && dtype_dst == DCF_BF16) DCF_LAUNCH("cast", s, hipLaunchKernelGGL((k_cast<float, bf16_t>), g, b, 0, s, (const float *)src, (bf16_t *)dst, n4));
-    else if (dtype_src == DCF_BF16 && dtype_dst == DCF_F32) DCF_LAUNCH("cast", s, hipLaunchKernelGGL((k_cast<bf16_t, float>), g, b, 0, s, (const bf16_t *)src, (float *)dst, n4));
-    else if (dtype_src == DCF_F32 && dtype_dst == DCF_F32) DCF_LAUNCH("cast", s, hipLaunchKernelGGL((k_cast<float, float>), g, b, 0, s, (const float *)src, (float *)dst, n4));
-    else if (dtype_src == DCF_BF16 && dtype_dst == DCF_BF16) DCF_LAUNCH("cast", s, hipLaunchKernelGGL((k_cast<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t *)src, (bf16_t *)dst, n4));
+#define DCF_CAST(TS_, TD_) DCF_LAUNCH("cast", s, hipLaunchKernelGGL((k_cast<TS_, TD_>), g, b, 0, s, (const TS_ *)src, (TD_ *)dst, n4))
+    if (dtype_src == DCF_F32 && dtype_dst == DCF_BF16) DCF_CAST(float, bf16_t);
+    else if (dtype_src == DCF_BF16 && dtype_dst == DCF_F32) DCF_CAST(bf16_t, float);
+    else if (dtype_src == DCF_F32 && dtype_dst == DCF_F32) DCF_CAST(float, float);
+    else if (dtype_src == DCF_BF16 && dtype_dst == DCF_BF16) DCF_CAST(bf16_t, bf16_t);
+    else if (dtype_src == DCF_F32 && dtype_dst == DCF_F16) DCF_CAST(float, f16_t);
+    else if (dtype_src == DCF_F16 && dtype_dst == DCF_F32) DCF_CAST(f16_t, float);
+    else if (dtype_src == DCF_F16 && dtype_dst == DCF_F16) DCF_CAST(f16_t, f16_t);
     else { dcf_set_error("dcf_cast: unsupported dtype pair"); return DCF_EUNSUPPORTED; }
+#undef DCF_CAST
     return DCF_OK;
 }
 

@@ -123,10 +123,57 @@ class Block(object):
         return K.conv_dgrad(self.conv1, g1, tuple(x.shape), g2, pm)
 
 
+class Bottleneck(object):
+    """ResNet-50 block (torchvision v1.5: the stride sits on the 3x3):
+    relu(bn3(conv3_1x1(relu(bn2(conv2_3x3_s(relu(bn1(conv1_1x1 x))))))) + shortcut(x)).  Same calling convention as Block."""
+
+    def __init__(self, conv1, conv2, conv3, down=None):
+        self.conv1, self.conv2, self.conv3, self.down = conv1, conv2, conv3, down
+        self.saved = None
+
+    def forward(self, K, x, save=True):
+        r = K.conv_fwd(self.down, x, None, False) if self.down is not None else x
+        y1 = K.conv_fwd(self.conv1, x, None, True)
+        y2 = K.conv_fwd(self.conv2, y1, None, True)
+        y = K.conv_fwd(self.conv3, y2, r, True)
+        self.saved = (x, y1, y2, y) if save else None
+        return y
+
+    def backward(self, K, g, extra=None, need_gx=True, g_masked=False, prev=None):
+        x, y1, y2, y = self.saved
+        self.saved = None
+        g3 = g if g_masked else K.relu_mask(g, y)
+        d3 = K.bn_bwd(self.conv3, g3)
+        K.conv_wgrad(self.conv3, y2, d3)
+        g2 = K.bn_bwd(self.conv2, K.conv_dgrad(self.conv3, d3, tuple(y2.shape), None, y2))   # fused ReLU mask of y2
+        K.conv_wgrad(self.conv2, y1, g2)
+        g1 = K.bn_bwd(self.conv1, K.conv_dgrad(self.conv2, g2, tuple(y1.shape), None, y1))   # fused ReLU mask of y1
+        K.conv_wgrad(self.conv1, x, g1)
+        pm = x if prev is not None else None
+        if self.down is not None:
+            dd = K.bn_bwd(self.down, g3)
+            K.conv_wgrad(self.down, x, dd)
+            if not need_gx:
+                return None
+            gx = K.conv_dgrad(self.down, dd, tuple(x.shape), extra)
+            return K.conv_dgrad(self.conv1, g1, tuple(x.shape), gx, pm)
+        if not need_gx:
+            return None
+        assert extra is None, "an identity-shortcut block cannot take an extra gradient"
+        return K.conv_dgrad(self.conv1, g1, tuple(x.shape), g3, pm)
+
+
+IMAGE_ARCHS = {   # name -> (block kind, blocks per layer, base widths, channel expansion)
+    "resnet18": ("basic", (2, 2, 2, 2), (64, 128, 256, 512), 1),
+    "resnet34": ("basic", (3, 4, 6, 3), (64, 128, 256, 512), 1),
+    "resnet50": ("bottleneck", (3, 4, 6, 3), (64, 128, 256, 512), 4),
+}
+
+
 class Plan(object):
     """Builds the layer list, the parameter table and runs forward / backward."""
 
-    def __init__(self, cfg, with_image=False, cf=64, image_blocks=(2, 2, 2, 2), image_widths=(64, 128, 256, 512)):
+    def __init__(self, cfg, with_image=False, cf=64, image_arch="resnet18", image_blocks=None, image_widths=None):
         self.cfg = cfg
         self.with_image = with_image
         self.cf = cf
@@ -146,7 +193,10 @@ class Plan(object):
         self._build_lidar()
         self.fusion = []
         if with_image:
-            self._build_image(image_blocks, image_widths)
+            if image_arch not in IMAGE_ARCHS:
+                raise ValueError("fusion.image_stream must be one of %s (got %r)" % (sorted(IMAGE_ARCHS), image_arch))
+            kind, nb, wd, exp = IMAGE_ARCHS[image_arch]
+            self._build_image(image_blocks or nb, image_widths or wd, kind, exp)
             self._build_fusion()
 
     # ------------------------------------------------------------------ construction
@@ -199,26 +249,38 @@ class Plan(object):
         self.heads = self._conv(p + "heads", w[3], 18, (1, 1), 1, names=[p + "classconv", p + "bbox3dconv"],
                                 shapes=[(4, w[3], 1, 1), (14, w[3], 1, 1)])
 
-    def _build_image(self, nblocks, widths):
-        """SURVEY.md App. D image stream: ResNet BasicBlock trunk (torchvision key names) + FPN."""
+    def _build_image(self, nblocks, widths, kind="basic", exp=1):
+        """SURVEY.md App. D image stream: ResNet trunk (BasicBlock or Bottleneck, torchvision key names) + FPN."""
         p = "image_backbone"
         self.stem = self._conv(p + ".conv1", 3, widths[0], (7, 7), 2, p + ".bn1", kind="stem", need_dgrad=False)
         self.img_stages = []
         cin = widths[0]
         for li in range(4):
-            cout = widths[li]
+            w = widths[li]
+            cout = w * exp
             blocks = []
             for bi in range(nblocks[li]):
                 q = "%s.layer%d.%d" % (p, li + 1, bi)
                 ci = cin if bi == 0 else cout
                 s = 2 if (bi == 0 and li > 0) else 1
-                c1 = self._conv(q + ".conv1", ci, cout, (3, 3), s, q + ".bn1")
-                c2 = self._conv(q + ".conv2", cout, cout, (3, 3), 1, q + ".bn2")
-                dn = self._conv(q + ".downsample.0", ci, cout, (1, 1), s, q + ".downsample.1") if (bi == 0 and li > 0) else None
-                blocks.append(Block(c1, c2, dn))
+                down = bi == 0 and (li > 0 or ci != cout)
+                dn = None
+                if kind == "basic":
+                    c1 = self._conv(q + ".conv1", ci, cout, (3, 3), s, q + ".bn1")
+                    c2 = self._conv(q + ".conv2", cout, cout, (3, 3), 1, q + ".bn2")
+                    if down:
+                        dn = self._conv(q + ".downsample.0", ci, cout, (1, 1), s, q + ".downsample.1")
+                    blocks.append(Block(c1, c2, dn))
+                else:
+                    c1 = self._conv(q + ".conv1", ci, w, (1, 1), 1, q + ".bn1")
+                    c2 = self._conv(q + ".conv2", w, w, (3, 3), s, q + ".bn2")
+                    c3 = self._conv(q + ".conv3", w, cout, (1, 1), 1, q + ".bn3")
+                    if down:
+                        dn = self._conv(q + ".downsample.0", ci, cout, (1, 1), s, q + ".downsample.1")
+                    blocks.append(Bottleneck(c1, c2, c3, dn))
             self.img_stages.append(blocks)
             cin = cout
-        self.img_lat = [self._conv("image_fpn.lat%d" % (i + 1), widths[i], self.cf, (1, 1), 1) for i in range(4)]
+        self.img_lat = [self._conv("image_fpn.lat%d" % (i + 1), widths[i] * exp, self.cf, (1, 1), 1) for i in range(4)]
         self.img_smooth = self._conv("image_fpn.smooth", self.cf, self.cf, (3, 3), 1)
 
     def _build_fusion(self):

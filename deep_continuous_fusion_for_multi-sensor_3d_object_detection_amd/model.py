@@ -166,11 +166,12 @@ class ObjectDetection_DCF(nn.Module):
         if self.bn_mode not in ("eval", "train", "module"):
             raise ValueError("bn_mode must be eval, train or module (got %r)" % (self.bn_mode,))
         stream = fu.get("image_stream", "resnet18")
-        if self.fusion_enabled and stream != "resnet18":
-            raise NotImplementedError("image_stream=%r (resnet18 only in this round)" % (stream,))
+        from .engine import IMAGE_ARCHS
+        if self.fusion_enabled and stream not in IMAGE_ARCHS:
+            raise NotImplementedError("image_stream=%r (one of %s)" % (stream, sorted(IMAGE_ARCHS)))
         self.use_graphs = bool(config.get("hip_graphs", False))
         self._graphs = None
-        self._plan = Plan(config, with_image=self.fusion_enabled, cf=self.cf)
+        self._plan = Plan(config, with_image=self.fusion_enabled, cf=self.cf, image_arch=str(fu.get("image_stream", "resnet18")))
         self._backend = None
         self._build_parameters()
         self.reset_parameters(zero_init_last=bool(fu.get("zero_init_last", False)))

@@ -14,7 +14,7 @@
  *   - returns 0 on success or a negative DCF_E* code; dcf_last_error() gives the text
  *   - never allocates, frees or synchronises; all work is enqueued on `stream`
  *     (a hipStream_t passed as void*); workspaces are caller-provided
- *   - activations are NHWC ("pixel rows of channels"); dtype DCF_F32 or DCF_BF16,
+ *   - activations are NHWC ("pixel rows of channels"); dtype DCF_F32, DCF_BF16 or DCF_F16 (IEEE half),
  *     accumulation is always fp32
  *   - counts that are produced on the device (n_valid ...) stay on the device
  */
@@ -31,7 +31,7 @@ extern "C" {
 typedef void *dcf_stream_t; /* hipStream_t */
 
 enum { DCF_OK = 0, DCF_EINVAL = -1, DCF_ELAUNCH = -2, DCF_EUNSUPPORTED = -3 };
-enum { DCF_F32 = 0, DCF_BF16 = 1 };
+enum { DCF_F32 = 0, DCF_BF16 = 1, DCF_F16 = 2 };   /* compute / storage type of activations and weight images */
 enum { DCF_VOXEL_COMPAT = 0, DCF_VOXEL_ACCUM = 1 };
 enum { DCF_PROJ_COMPAT = 0, DCF_PROJ_CORRECT = 1 };
 

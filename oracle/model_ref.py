@@ -108,8 +108,13 @@ def image_stream(sd, img_u8, bn_mode="eval", pfx="image_backbone", fpn="image_fp
                 r = _bn(sd, p + ".downsample.1", F.conv2d(x, sd[p + ".downsample.0.weight"], None, s), bn_mode)
             else:
                 r = x
-            y = F.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"], None, s, 1), bn_mode))
-            y = _bn(sd, p + ".bn2", F.conv2d(y, sd[p + ".conv2.weight"], None, 1, 1), bn_mode)
+            if (p + ".conv3.weight") in sd:          # Bottleneck (ResNet-50, torchvision v1.5: stride on the 3x3)
+                y = F.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"], None, 1, 0), bn_mode))
+                y = F.relu(_bn(sd, p + ".bn2", F.conv2d(y, sd[p + ".conv2.weight"], None, s, 1), bn_mode))
+                y = _bn(sd, p + ".bn3", F.conv2d(y, sd[p + ".conv3.weight"], None, 1, 0), bn_mode)
+            else:                                    # BasicBlock (ResNet-18/34)
+                y = F.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"], None, s, 1), bn_mode))
+                y = _bn(sd, p + ".bn2", F.conv2d(y, sd[p + ".conv2.weight"], None, 1, 1), bn_mode)
             x = F.relu(y + r)
             bi += 1
         feats.append(x)
@@ -264,8 +269,15 @@ def lidar_state_shapes(cfg):
     return shapes
 
 
-def image_state_shapes(cf=64, widths=(64, 128, 256, 512), blocks=(2, 2, 2, 2)):
-    """App. D image stream (ResNet-18 BasicBlock trunk, torchvision key names) + FPN."""
+def image_state_shapes(cf=64, widths=(64, 128, 256, 512), blocks=(2, 2, 2, 2), arch="resnet18"):
+    """App. D image stream (ResNet trunk, torchvision key names) + FPN.  arch: resnet18 / resnet34 (BasicBlock) or
+    resnet50 (Bottleneck, expansion 4)."""
+    if arch == "resnet34":
+        blocks = (3, 4, 6, 3)
+    bott = arch == "resnet50"
+    if bott:
+        blocks = (3, 4, 6, 3)
+    exp = 4 if bott else 1
     shapes = {}
 
     def bn(p, c):
@@ -276,17 +288,23 @@ def image_state_shapes(cf=64, widths=(64, 128, 256, 512), blocks=(2, 2, 2, 2)):
     shapes["image_backbone.conv1.weight"] = (widths[0], 3, 7, 7); bn("image_backbone.bn1", widths[0])
     cin = widths[0]
     for li in range(4):
-        cout = widths[li]
+        w = widths[li]
+        cout = w * exp
         for bi in range(blocks[li]):
             p = "image_backbone.layer%d.%d" % (li + 1, bi)
             ci = cin if bi == 0 else cout
-            shapes[p + ".conv1.weight"] = (cout, ci, 3, 3); bn(p + ".bn1", cout)
-            shapes[p + ".conv2.weight"] = (cout, cout, 3, 3); bn(p + ".bn2", cout)
-            if bi == 0 and li > 0:
+            if bott:
+                shapes[p + ".conv1.weight"] = (w, ci, 1, 1); bn(p + ".bn1", w)
+                shapes[p + ".conv2.weight"] = (w, w, 3, 3); bn(p + ".bn2", w)
+                shapes[p + ".conv3.weight"] = (cout, w, 1, 1); bn(p + ".bn3", cout)
+            else:
+                shapes[p + ".conv1.weight"] = (cout, ci, 3, 3); bn(p + ".bn1", cout)
+                shapes[p + ".conv2.weight"] = (cout, cout, 3, 3); bn(p + ".bn2", cout)
+            if bi == 0 and (li > 0 or ci != cout):
                 shapes[p + ".downsample.0.weight"] = (cout, ci, 1, 1); bn(p + ".downsample.1", cout)
         cin = cout
     for li in range(4):
-        shapes["image_fpn.lat%d.weight" % (li + 1)] = (cf, widths[li], 1, 1)
+        shapes["image_fpn.lat%d.weight" % (li + 1)] = (cf, widths[li] * exp, 1, 1)
     shapes["image_fpn.smooth.weight"] = (cf, cf, 3, 3)
     return shapes
 

@@ -28,10 +28,13 @@ def rnd(shape, seed, lo=-1.0, hi=1.0):
     return torch.from_numpy(det.uniform(tuple(shape), seed, lo, hi))
 
 
+TORCH_DT = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}     # DCF_F32 / DCF_BF16 / DCF_F16
+
+
 def to_dev(x_nchw, dtype):
     """NCHW fp32 CPU -> NHWC device tensor of the compute dtype."""
     t = x_nchw.permute(0, 2, 3, 1).contiguous().cuda()
-    return t.to(torch.bfloat16) if dtype == 1 else t
+    return t.to(TORCH_DT[dtype])
 
 
 def from_dev(y_nhwc):
@@ -40,7 +43,7 @@ def from_dev(y_nhwc):
 
 def q(x, dtype):
     """Quantise a CPU fp32 tensor the way the device stores it."""
-    return x.to(torch.bfloat16).float() if dtype == 1 else x
+    return x.to(TORCH_DT[dtype]).float()
 
 
 def rel_err(a, b):

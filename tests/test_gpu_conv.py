@@ -5,11 +5,11 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from _util import from_dev, pkg, q, rel_err, rnd, to_dev
+from _util import TORCH_DT, from_dev, pkg, q, rel_err, rnd, to_dev
 
 pytestmark = pytest.mark.gpu
 
-TOL = {0: 2e-4, 1: 1.2e-2}
+TOL = {0: 2e-4, 1: 1.2e-2, 2: 2e-3}        # fp32 / bf16 (8 significant bits) / fp16 (11)
 
 # (B, H, W, Cin, Cout, k, stride)  -- covers every tile dispatch (Cout%128, %64, %32; row bytes %128 or %64)
 SHAPES = [
@@ -39,7 +39,7 @@ def _mk(shape, dtype, seed):
     return x, w
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dtype", [0, 1, 2])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_conv_fwd(shape, dtype):
     ops = pkg("ops")
@@ -62,7 +62,7 @@ def test_conv_fwd(shape, dtype):
     assert float(from_dev(y2).min()) >= 0.0
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dtype", [0, 1, 2])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_conv_dgrad(shape, dtype):
     ops = pkg("ops")
@@ -74,7 +74,7 @@ def test_conv_dgrad(shape, dtype):
     gy = q(rnd(tuple(y.shape), 22), dtype)
     y.backward(gy)
     wt = w.permute(1, 2, 3, 0).contiguous().cuda()          # [Cin][kh][kw][Cout]
-    wt = wt.to(torch.bfloat16) if dtype == 1 else wt
+    wt = wt.to(TORCH_DT[dtype])
     gx = ops.conv2d_dgrad(dtype, to_dev(gy, dtype), wt, None, (B, Hh, W, Cin), k, k, s, pad)
     e = rel_err(from_dev(gx), x.grad)
     assert e < TOL[dtype], "dgrad rel err %g" % e
@@ -91,7 +91,7 @@ def test_conv_dgrad(shape, dtype):
     assert float((got3 * (mask <= 0)).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dtype", [0, 1, 2])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_conv_wgrad(shape, dtype):
     ops = pkg("ops")
@@ -123,7 +123,7 @@ def test_conv_wgrad(shape, dtype):
     assert float((got - want).abs().max()) < (1e-4 if dtype == 0 else 1e-3) * float(gy.abs().sum((0, 2, 3)).max())
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dtype", [0, 1, 2])
 def test_stem7x7(dtype):
     """7x7/2 RGB stem on the NHWC4+halo image against conv2d(x/255, w, stride 2, pad 3)."""
     ops, det = pkg("ops"), pkg("detfill")
@@ -135,7 +135,7 @@ def test_stem7x7(dtype):
     ref = F.conv2d(xf, w, None, 2, 3)
     w8 = torch.zeros(Cout, 7, 8, 4)
     w8[:, :, :7, :3] = w.permute(0, 2, 3, 1)
-    wd = w8.cuda().to(torch.bfloat16) if dtype == 1 else w8.cuda()
+    wd = w8.cuda().to(TORCH_DT[dtype])
     img4 = ops.image_to_nhwc4(img.cuda(), dtype)
     y = ops.stem7x7_fwd(dtype, img4, wd, None, False, Cout, Hh, W)
     e = rel_err(from_dev(y), ref)

@@ -18,10 +18,10 @@ def small_crt():
     return pkg("calib").crt_from(K, pkg("calib").R_LIDAR_TO_CAM)
 
 
-def setup(dtype="f32", K=3, zero_last=False):
+def setup(dtype="f32", K=3, zero_last=False, arch="resnet18"):
     cfg = golden_cfg(load_golden("model_tiny.npz"))
     cfg.update(dict(image_height=96, image_width=128, max_num_pc=2048, projection_mode="correct", dtype=dtype))
-    cfg["fusion"] = dict(enabled=True, K=K, r_max=None, image_channels=64, zero_init_last=zero_last)
+    cfg["fusion"] = dict(enabled=True, K=K, r_max=None, image_channels=64, image_stream=arch, zero_init_last=zero_last)
     det = pkg("detfill")
     lim6 = (cfg["lidar_x_min"], cfg["lidar_x_max"], cfg["lidar_y_min"], cfg["lidar_y_max"], cfg["lidar_z_min"], cfg["lidar_z_max"])
     B = 2
@@ -42,14 +42,16 @@ def oracle_inputs(cfg, pts, crt):
 def full_shapes(cfg):
     s = {}
     s.update(model_ref.lidar_state_shapes(cfg))
-    s.update(model_ref.image_state_shapes(64))
+    s.update(model_ref.image_state_shapes(64, arch=cfg["fusion"].get("image_stream", "resnet18")))
     s.update(model_ref.fusion_state_shapes(cfg, 64))
     return s
 
 
-def test_image_stream_feature_map():
-    """ResNet-18 trunk + FPN (stem7x7, max-pool, BasicBlocks, resize-add, smooth) against the CPU statement."""
-    cfg, pts, img, crt = setup("f32")
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_image_stream_feature_map(arch):
+    """ResNet-18 / ResNet-50 trunk + FPN (stem7x7, max-pool, Basic / Bottleneck blocks, resize-add, smooth) against the
+    CPU statement."""
+    cfg, pts, img, crt = setup("f32", arch=arch)
     net = pkg("model").ObjectDetection_DCF(cfg)
     pkg("detfill").fill_state_dict(net)
     net = net.cuda()
@@ -63,7 +65,7 @@ def test_image_stream_feature_map():
     assert err < 1e-3, err
 
 
-@pytest.mark.parametrize("dtype,tol,K", [("f32", 1e-3, 3), ("bf16", 6e-2, 3), ("f32", 1e-3, 5), ("f32", 1e-3, 1)])
+@pytest.mark.parametrize("dtype,tol,K", [("f32", 1e-3, 3), ("bf16", 6e-2, 3), ("f16", 8e-3, 5), ("f32", 1e-3, 5), ("f32", 1e-3, 1)])
 def test_fused_forward(dtype, tol, K):
     cfg, pts, img, crt = setup(dtype, K=K)
     net = pkg("model").ObjectDetection_DCF(cfg)
@@ -116,9 +118,10 @@ def test_zero_init_last_reproduces_lidar_only_reference():
     assert np.abs(pred - ref).max() / np.abs(ref).max() < 1e-3
 
 
-def test_fused_backward_all_parameters():
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_fused_backward_all_parameters(arch):
     """d<pred,R>/d(every parameter) of the fused model (fp32 path) against autograd through the CPU statement."""
-    cfg, pts, img, crt = setup("f32")
+    cfg, pts, img, crt = setup("f32", arch=arch)
     net = pkg("model").ObjectDetection_DCF(cfg)
     det = pkg("detfill")
     det.fill_state_dict(net)
@@ -206,3 +209,37 @@ def test_fusion_backward_by_point_matches_pixel_run_kernel(Cb, K, case):
         for a, b in zip(got, ref):
             scale = max(float(b.abs().max()), 1e-6)
             assert float((a - b).abs().max()) <= tol * scale * max(1.0, (h * w) ** 0.5), (case, Cb, float((a - b).abs().max()), scale)
+
+
+def test_cfg4_shape_model_step_fp16():
+    """BASELINE configs[3] in miniature: ResNet-50 camera stream, K=5, fp16 MFMA, batch 4 -- one fused forward against
+    the CPU statement at fp16 precision and one backward + Adam step that changes every parameter."""
+    cfg, pts, img, crt = setup("f16", K=5, arch="resnet50")
+    det = pkg("detfill")
+    pts = pts + [det.synthetic_points(1200, (cfg["lidar_x_min"], cfg["lidar_x_max"], cfg["lidar_y_min"], cfg["lidar_y_max"],
+                                             cfg["lidar_z_min"], cfg["lidar_z_max"]), 60 + b) for b in range(2)]
+    img = torch.cat([img, torch.flip(img, dims=[3])], 0)
+    net = pkg("model").ObjectDetection_DCF(cfg)
+    det.fill_state_dict(net)
+    net = net.cuda()
+    geo = pkg("data_import_carla").FrameGeometry(cfg, crt)
+    vox, pcs, uvs, cnts = [], [], [], []
+    for p in pts:
+        v, pc, uv, cnt, _ = geo(torch.from_numpy(p))
+        vox.append(v); pcs.append(pc); uvs.append(uv); cnts.append(cnt)
+    pred = net(torch.stack(vox), img.cuda(), points=torch.stack(pcs), uv=torch.stack(uvs), n_valid=torch.cat(cnts))
+    x, pc, uv, ns = oracle_inputs(cfg, pts, crt)
+    sd = model_ref.make_state_dict(full_shapes(cfg))
+    g = geometry_ref.grid_constants(cfg)
+    ref = model_ref.forward(sd, cfg, x, img, pc, uv, ns, "eval", fusion={"K": 5, "aff": g["aff"], "rmax": None})
+    err = float((pred.detach().cpu() - ref).abs().max() / ref.abs().max())
+    assert pred.shape[0] == 4 and err < 1e-2, err
+    before = net.flat_params.clone()
+    opt = pkg("train").FlatAdam(net, 1e-4, (0.9, 0.999))
+    R = torch.from_numpy(det.uniform(tuple(pred.shape), 779, -1.0, 1.0)).cuda()
+    # fp16 activations need loss scaling (the deep camera stream's gradients underflow otherwise); Adam is scale invariant
+    ((pred * R).sum() * 4096.0).backward()
+    opt.step()
+    assert torch.isfinite(net.flat_params).all()
+    # (with the deterministic fill ~55 % of the camera trunk's channels are dead ReLUs -- in the fp32 CPU statement too)
+    assert float((net.flat_params != before).float().mean()) > 0.4

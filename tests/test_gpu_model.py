@@ -29,7 +29,7 @@ def build(cfg, dtype="f32", **over):
     return net.cuda(), cfg
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 6e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("bf16", 6e-2), ("f16", 8e-3)])
 def test_tiny_forward_matches_reference(dtype, tol):
     z = load_golden("model_tiny.npz")
     net, cfg = build(golden_cfg(z), dtype)
@@ -56,7 +56,7 @@ def test_state_dict_surface_matches_reference():
     net.load_state_dict({"module." + k: v.clone() for k, v in got.items()})
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 2e-3), ("bf16", 2.5e-1)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-3), ("bf16", 2.5e-1), ("f16", 1e-1)])
 def test_tiny_backward_matches_reference(dtype, tol):
     z = load_golden("model_tiny.npz")
     net, cfg = build(golden_cfg(z), dtype)

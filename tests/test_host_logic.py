@@ -71,15 +71,20 @@ def test_plan_rejects_bad_configs():
 def test_fused_model_state_dict_names():
     from oracle import model_ref
     cfg = golden_cfg(load_golden("model_tiny.npz"))
-    cfg["fusion"] = {"enabled": True, "K": 3, "image_channels": 64}
-    net = pkg("model").ObjectDetection_DCF(cfg)
-    want = {}
-    want.update(model_ref.lidar_state_shapes(cfg))
-    want.update(model_ref.image_state_shapes(64))
-    want.update(model_ref.fusion_state_shapes(cfg, 64))
-    got = net.state_dict()
-    assert set(got.keys()) == set(want.keys())
-    assert all(tuple(got[k].shape) == tuple(want[k]) for k in want)
+    for arch in ("resnet18", "resnet50"):
+        cfg["fusion"] = {"enabled": True, "K": 3, "image_channels": 64, "image_stream": arch}
+        net = pkg("model").ObjectDetection_DCF(cfg)
+        want = {}
+        want.update(model_ref.lidar_state_shapes(cfg))
+        want.update(model_ref.image_state_shapes(64, arch=arch))
+        want.update(model_ref.fusion_state_shapes(cfg, 64))
+        got = net.state_dict()
+        assert set(got.keys()) == set(want.keys()), arch
+        assert all(tuple(got[k].shape) == tuple(want[k]) for k in want), arch
+    # torchvision's resnet50 has 23,508,032 trunk parameters without the fc layer (53 convs + 53 BN pairs)
+    n50 = sum(int(np.prod(v)) for k, v in model_ref.image_state_shapes(64, arch="resnet50").items()
+              if k.startswith("image_backbone") and "running" not in k and "num_batches" not in k)
+    assert n50 == 23508032, n50
 
 
 def test_calibration_matches_golden_crt():
