@@ -37,14 +37,14 @@ def pkg(sub):
     return importlib.import_module(PKG + "." + sub)
 
 
-def kitti_config(batch, dtype="bf16", n_points=100000, K=3):
+def kitti_config(batch, dtype="bf16", n_points=100000, K=3, image_stream="resnet18"):
     import yaml
     cfg = yaml.safe_load(open(os.path.join(ROOT, PKG, "config", "config_carla.yaml")))
     cfg.update(dict(voxel_length=704, voxel_width=800, voxel_channel=32, lidar_x_min=0.0, lidar_x_max=70.4,
                     lidar_y_min=-40.0, lidar_y_max=40.0, lidar_z_min=-2.4, lidar_z_max=0.8,
                     image_height=375, image_width=1242, max_num_pc=n_points, batch_size=batch,
                     dtype=dtype, projection_mode="correct", voxel_mode="compat"))
-    cfg["fusion"] = dict(enabled=True, K=K, r_max=None, image_channels=64, image_stream="resnet18", zero_init_last=False)
+    cfg["fusion"] = dict(enabled=True, K=K, r_max=None, image_channels=64, image_stream=image_stream, zero_init_last=False)
     return cfg
 
 
@@ -230,6 +230,8 @@ def main():
     ap.add_argument("--batch", type=int, default=2, help="frames per GPU (cfg2: 2)")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--points", type=int, default=100000)
+    ap.add_argument("--knn", type=int, default=3, help="neighbours per BEV pixel (cfg2: 3, cfg4: 5)")
+    ap.add_argument("--image-stream", default="resnet18", help="camera trunk: resnet18 (cfg2), resnet34, resnet50 (cfg4)")
     ap.add_argument("--bn-mode", default="eval", help="eval = what the reference's train.py really does (F4); train = batch statistics")
     ap.add_argument("--graphs", action="store_true", help="replay captured forward/backward HIP graphs instead of eager launches "
                     "(measured equal on this workload: the step is kernel-bound, not launch-bound)")
@@ -242,7 +244,7 @@ def main():
     rank = dist.get_rank() if ws > 1 else 0
     if ws <= 1:
         torch.cuda.set_device(0)
-    cfg = kitti_config(args.batch, args.dtype, args.points)
+    cfg = kitti_config(args.batch, args.dtype, args.points, args.knn, args.image_stream)
     cfg["bn_mode"] = args.bn_mode
     cfg["hip_graphs"] = bool(args.graphs)
     torch.manual_seed(0)
@@ -291,8 +293,12 @@ def main():
         out = {"metric": "frames/sec (train step) 100k-pt LiDAR + 1242x375 RGB", "value": round(frames / dt, 3), "unit": "frames/s",
                "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": "cfg2: grid 32x704x800, %d pts/frame, 1242x375 RGB, ResNet-18 image stream, K=3 fusion x4 sites, "
-                                      "%s-mode BN%s, batch %d/GPU" % (args.points, args.bn_mode, " (reference F4)" if args.bn_mode == "eval" else "", args.batch),
+               "config": {"workload": "%s: grid 32x704x800, %d pts/frame, 1242x375 RGB, %s image stream, K=%d fusion x4 sites, "
+                                      "%s-mode BN%s, batch %d/GPU" % (
+                                          {(100000, 3, "resnet18", 2, "bf16"): "cfg2", (120000, 5, "resnet50", 4, "f16"): "cfg4"}.get(
+                                              (args.points, args.knn, args.image_stream, args.batch, args.dtype), "custom"),
+                                          args.points, {"resnet18": "ResNet-18", "resnet34": "ResNet-34", "resnet50": "ResNet-50"}.get(args.image_stream, args.image_stream),
+                                          args.knn, args.bn_mode, " (reference F4)" if args.bn_mode == "eval" else "", args.batch),
                           "global_batch": args.batch * ws, "parallelism": "dp%d" % ws, "final_loss": round(loss, 4)},
                "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown}
         print(json.dumps(out))
