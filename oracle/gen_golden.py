@@ -304,6 +304,57 @@ def gen_full_carla(mods, cfg, crt, cases):
                         chan_abs=np.abs(p).astype(np.float64).sum((1, 2)))
 
 
+def gen_eval(mods):
+    """Evaluation post-processing of the reference's Test class (test.py:110-206) on seeded boxes: which boxes survive
+    NMS_IOU / NMS_SAT, and the precision / recall counters -- plus the IoU known-answer of IOU.py:161-167."""
+    import IOU
+    tmod = importlib.import_module("test")
+    T = tmod.Test.__new__(tmod.Test)                    # the constructor wants a network; the post-processing does not
+    T.IOU_threshold = [0.5, 0.55, 0.6, 0.65, 0.7, 0.75, 0.8, 0.85, 0.9, 0.95]
+    T.initialize_ap()
+    rng = np.random.RandomState(4242)
+    B, n = 2, 36
+    ref = np.zeros((B, 20, 9), dtype=np.float32)
+    pred = []
+    for b in range(B):
+        nb = 6 + b
+        ref[b, :nb, 0] = rng.uniform(5, 60, nb); ref[b, :nb, 1] = rng.uniform(-25, 25, nb); ref[b, :nb, 2] = rng.uniform(-1.5, -0.5, nb)
+        ref[b, :nb, 3] = rng.uniform(3.5, 4.8, nb); ref[b, :nb, 4] = rng.uniform(1.6, 2.1, nb); ref[b, :nb, 5] = rng.uniform(1.4, 1.8, nb)
+        ref[b, :nb, 6] = rng.uniform(0, np.pi, nb); ref[b, :nb, 7] = 6; ref[b, :nb, 8] = 1
+        p = np.zeros((n, 7), dtype=np.float32)
+        for i in range(n):
+            k = rng.randint(nb)
+            if rng.rand() < 0.7:        # jittered copy of a label: overlaps it and its other copies
+                p[i] = ref[b, k, :7] + rng.normal(0, [0.4, 0.3, 0.05, 0.1, 0.05, 0.05, 0.08])
+            else:                       # clutter
+                p[i] = [rng.uniform(5, 60), rng.uniform(-25, 25), rng.uniform(-1.5, -0.5), rng.uniform(3.5, 4.8),
+                        rng.uniform(1.6, 2.1), rng.uniform(1.4, 1.8), rng.uniform(0, np.pi)]
+        pred.append(torch.from_numpy(p))
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        keep_iou = T.NMS_IOU(pred, 0.01)
+    keep_sat = T.NMS_SAT(pred)
+
+    def index_of(kept, boxes):
+        return np.array([int(np.where((boxes.numpy() == k.numpy()).all(1))[0][0]) for k in kept], dtype=np.int64)
+    out = {"pred": np.stack([p.numpy() for p in pred]), "ref": ref}
+    for b in range(B):
+        out["keep_iou_%d" % b] = index_of(keep_iou[b], pred[b])
+        out["keep_sat_%d" % b] = index_of(keep_sat[b], pred[b])
+    T.precision_recall_singleshot(keep_sat, torch.from_numpy(ref))
+    out["num_T"], out["num_P"] = np.int64(T.num_T), np.int64(T.num_P)
+    out["num_TP"] = np.array([T.num_TP_set[t] for t in T.IOU_threshold], dtype=np.int64)
+    g = IOU.get_3d_box((2.882992, 1.698800, 20.785644), (1.497255, 1.644981, 3.628938), -1.531692)
+    p = IOU.get_3d_box((2.756923, 1.661275, 20.943280), (1.458242, 1.604773, 3.707947), -1.549553)
+    out["known_iou"] = np.array(IOU.box3d_iou(p, g), dtype=np.float64)
+    # pairwise IoUs of sample 0 (both flavours' inputs) for a direct check of the geometry
+    c = [IOU.get_3d_box(x[:3], x[3:6], x[6]) for x in out["pred"][0][:12].astype(np.float64)]
+    out["pair_iou3d"] = np.array([[IOU.box3d_iou(c[i], c[j])[0] for j in range(12)] for i in range(12)])
+    out["pair_iou2d"] = np.array([[IOU.box3d_iou(c[i], c[j])[1] for j in range(12)] for i in range(12)])
+    np.savez_compressed(os.path.join(OUT, "eval.npz"), **out)
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     geometry_ref.build()
@@ -315,6 +366,7 @@ def main():
     gen_loss(mods)
     gen_adam(mods, tcfg, sd)
     gen_full_carla(mods, cfg, crt, cases)
+    gen_eval(mods)
     print("golden fixtures written to", OUT)
 
 

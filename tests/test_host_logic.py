@@ -99,3 +99,46 @@ def test_gridspec_truncation_semantics():
     g = pkg("ops").GridSpec(cfg)
     assert (g.xs, g.ys, g.zs, g.xo, g.yo, g.zo) == (5, 4, 10, 0, 120, 24)
     assert g.lim.dtype == np.float32 and g.lim[1] == np.float32(69.8)
+
+
+def test_eval_postprocessing_matches_reference_golden():
+    """NMS_IOU / NMS_SAT survivors, precision-recall counters and the pairwise IoUs of tests/golden/eval.npz (produced
+    by the imported reference's Test / IOU.py) -- and the known answers printed in IOU.py:161-167."""
+    z = load_golden("eval.npz")
+    EG = pkg("evalgeom")
+    g = EG.box_corners((2.882992, 1.698800, 20.785644), (1.497255, 1.644981, 3.628938), -1.531692)
+    p = EG.box_corners((2.756923, 1.661275, 20.943280), (1.458242, 1.604773, 3.707947), -1.549553)
+    assert np.abs(np.array(EG.rotated_iou(p, g)) - z["known_iou"]).max() < 1e-12
+    assert abs(z["known_iou"][0] - 0.68796) < 1e-5 and abs(z["known_iou"][1] - 0.70037) < 1e-5
+    c = [EG.box_corners(x[:3], x[3:6], x[6]) for x in z["pred"][0][:12].astype(np.float64)]
+    got3 = np.array([[EG.rotated_iou(c[i], c[j])[0] for j in range(12)] for i in range(12)])
+    got2 = np.array([[EG.rotated_iou(c[i], c[j])[1] for j in range(12)] for i in range(12)])
+    off = ~np.eye(12, dtype=bool)
+    assert np.abs(got3 - z["pair_iou3d"])[off].max() < 1e-9 and np.abs(got2 - z["pair_iou2d"])[off].max() < 1e-9
+    # a box against ITSELF is degenerate in the reference (every vertex sits on a clip edge of the strict half-plane test:
+    # its fixture values range from -11.2 to 3.5); this implementation returns exactly 1
+    assert np.abs(np.diag(got3) - 1).max() < 1e-12 and not (np.abs(np.diag(z["pair_iou3d"]) - 1) < 1e-6).all()
+    a, b, c3 = [(0, 0), (70, 70), (70, 0), (0, 70)], [(70, 70), (150, 70), (150, 150), (70, 150)], [(30, 30), (150, 70), (70, 150)]
+    assert EG.rects_overlap(a, b) and EG.rects_overlap(a, c3) and EG.rects_overlap(b, c3)      # separation_axis_theorem.py main()
+    assert not EG.rects_overlap([(0, 0), (1, 0), (1, 1), (0, 1)], [(2, 0), (3, 0), (3, 1), (2, 1)])
+
+    T = pkg("test").Test.__new__(pkg("test").Test)
+    T.initialize_ap()
+    pred = [torch.from_numpy(z["pred"][b]) for b in range(2)]
+
+    def idx(kept, boxes):
+        return np.array([int(np.where((boxes.numpy() == k.numpy()).all(1))[0][0]) for k in kept], dtype=np.int64)
+    ki, ks = T.NMS_IOU(pred, 0.01), T.NMS_SAT(pred)
+    for b in range(2):
+        assert np.array_equal(idx(ki[b], pred[b]), z["keep_iou_%d" % b])
+        assert np.array_equal(idx(ks[b], pred[b]), z["keep_sat_%d" % b])
+    T.precision_recall_singleshot(ks, torch.from_numpy(z["ref"]))
+    assert T.get_num_T() == int(z["num_T"]) and T.get_num_P() == int(z["num_P"])
+    assert [T.get_num_TP_set()[t] for t in T.IOU_threshold] == z["num_TP"].tolist()
+    prec, rec = T.display_average_precision()
+    assert len(prec[0.5]) == T.get_num_P() + 1 and rec[0.5][-1] == T.get_num_TP_set()[0.5] / T.get_num_T()
+    # edge cases: no predictions, no labels
+    assert T.NMS_SAT([torch.zeros(0, 7)]) == [[]] and T.NMS_IOU([torch.zeros(0, 7)]) == [[]]
+    T.initialize_ap()
+    T.precision_recall_singleshot([[]], torch.zeros(1, 20, 9))
+    assert T.get_num_T() == 0 and T.get_num_P() == 0
