@@ -267,3 +267,22 @@ def test_fused_loss_kernel_matches_torch_path(reduction):
         assert torch.allclose(base.grad[:, 0:4].cpu(), c0.grad, rtol=1e-5, atol=1e-7)
         assert torch.allclose(base.grad[:, 4:18].cpu(), r0.grad, rtol=1e-5, atol=1e-7)
         assert float(base.grad[:, 18:].abs().max()) == 0.0
+
+
+def test_eval_harness_one_step():
+    """test.py surface: Test(net, cfg).get_eval_value_onestep -> loss, score-thresholded boxes, SAT suppression and the
+    precision / recall counters (host post-processing, pinned separately by tests/golden/eval.npz)."""
+    z = load_golden("model_tiny.npz")
+    lz = load_golden("loss.npz")
+    net, cfg = build(golden_cfg(z), "f32")
+    cfg["score_threshold"] = 0.5
+    T = pkg("test").Test(net, cfg)
+    x = tiny_input().cuda()
+    img = torch.zeros(x.shape[0], 3, 8, 8, dtype=torch.uint8, device="cuda")
+    boxes, nb = torch.from_numpy(lz["bboxes"]), torch.from_numpy(lz["nbox"])
+    np.random.seed(3)
+    loss, sel = T.get_eval_value_onestep(x, img, boxes, nb)
+    assert np.isfinite(loss) and len(sel) == x.shape[0]
+    assert T.get_num_T() == int((boxes[..., -1] == 1).sum())
+    assert T.get_num_P() == sum(len(k) for k in T.refined_bbox) <= sum(b.shape[0] for b in sel)
+    assert all(0 <= T.get_num_TP_set()[t] <= T.get_num_P() for t in T.IOU_threshold)
