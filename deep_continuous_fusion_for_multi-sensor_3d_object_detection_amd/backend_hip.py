@@ -204,8 +204,8 @@ class HipBackend(object):
     def maxpool_fwd(self, x):
         return ops.maxpool_fwd(self.dtype, x)
 
-    def maxpool_bwd(self, x, gy):
-        return ops.maxpool_bwd(self.dtype, x, None, gy)
+    def maxpool_bwd(self, x, gy, y=None):
+        return ops.maxpool_bwd(self.dtype, x, y, gy)
 
     def head_fwd(self, head, anchors):
         return ops.head_fwd(self.dtype, head, anchors)

@@ -278,6 +278,62 @@ __global__ void __launch_bounds__(256) k_maxpool_bwd(const T *x, const T *gy, T 
     st4(gx + e * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
 }
 
+// Same routing with the pooled output y at hand: a pixel can only be a window's arg-max if it EQUALS the window's
+// maximum, so a window costs one load of y (+ one of gy and a scan of the EARLIER window positions for ties) instead of
+// nine loads of x for every (pixel, window) pair.
+template <typename T>
+__global__ void __launch_bounds__(256) k_maxpool_bwd_y(const T *x, const T *y, const T *gy, T *gx, int B, int H, int W, int Ho, int Wo, int C4)
+{
+    const int64_t total = (int64_t)B * H * W * C4;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)(e % C4);
+    int64_t p = e / C4;
+    const int iw = (int)(p % W); p /= W;
+    const int ih = (int)(p % H);
+    const int b = (int)(p / H);
+    const int C = C4 * 4;
+    const float4 me = ld4(x + e * 4);
+    const float mev[4] = {me.x, me.y, me.z, me.w};
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int oh = (ih + 1) / 2 - 1; oh <= (ih + 1) / 2; ++oh) {
+        if (oh < 0 || oh >= Ho || ih < oh * 2 - 1 || ih > oh * 2 + 1) continue;
+        for (int ow = (iw + 1) / 2 - 1; ow <= (iw + 1) / 2; ++ow) {
+            if (ow < 0 || ow >= Wo || iw < ow * 2 - 1 || iw > ow * 2 + 1) continue;
+            const int64_t o = (((int64_t)b * Ho + oh) * Wo + ow) * C + c * 4;
+            const float4 m = ld4(y + o);
+            const float mv[4] = {m.x, m.y, m.z, m.w};
+            bool cand[4];
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { cand[k] = mev[k] == mv[k]; any |= cand[k]; }
+            if (!any) continue;
+            // ties: an earlier position (scan order dh, dw) holding the same maximum wins instead
+            const int mydh = ih - (oh * 2 - 1), mydw = iw - (ow * 2 - 1);
+            for (int dh = 0; dh <= mydh; ++dh) {
+                const int hh = oh * 2 - 1 + dh;
+                if (hh < 0) continue;
+                const int dwend = dh == mydh ? mydw : 3;
+                for (int dw = 0; dw < dwend; ++dw) {
+                    const int ww = ow * 2 - 1 + dw;
+                    if (ww < 0 || ww >= W) continue;
+                    const float4 v = ld4(x + (((int64_t)b * H + hh) * W + ww) * C + c * 4);
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) cand[k] = cand[k] && !(vv[k] == mv[k]);
+                }
+            }
+            const float4 g = ld4(gy + o);
+            const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (cand[k]) acc[k] += gv[k];
+        }
+    }
+    st4(gx + e * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+}
+
+
 // ------------------------------------------------------------------------------------
 // Detection heads.  head [B,h,w,Cp]: channels 0..3 class logits, 4..17 box offsets.
 // pred [B,32,h,w] fp32 = cat(softmax(l0,l1), softmax(l2,l3), reg14, decode(reg14)).
@@ -809,11 +865,13 @@ extern "C" int dcf_maxpool3x3s2_fwd(int dtype, const void *x, void *y, int B, in
 extern "C" int dcf_maxpool3x3s2_bwd(int dtype, const void *x, const void *y, const void *gy, void *gx, int B, int H, int W,
                                     int Ho, int Wo, int C, dcf_stream_t stream)
 {
-    (void)y;
     DCF_REQUIRE(x && gy && gx && C % 4 == 0, "dcf_maxpool3x3s2_bwd: bad arguments");
     const int64_t total = (int64_t)B * H * W * (C / 4);
     hipStream_t s = S(stream);
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("maxpool_bwd", s, hipLaunchKernelGGL(k_maxpool_bwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, (const T *)gy, (T *)gx, B, H, W, Ho, Wo, C / 4)); })
+    DCF_DISPATCH_DTYPE(dtype, {
+        if (y) DCF_LAUNCH("maxpool_bwd", s, hipLaunchKernelGGL(k_maxpool_bwd_y<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, (const T *)y, (const T *)gy, (T *)gx, B, H, W, Ho, Wo, C / 4));
+        else DCF_LAUNCH("maxpool_bwd", s, hipLaunchKernelGGL(k_maxpool_bwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, (const T *)gy, (T *)gx, B, H, W, Ho, Wo, C / 4));
+    })
     return DCF_OK;
 }
 

@@ -66,8 +66,10 @@ def test_maxpool(dtype):
         assert torch.equal(from_dev(y), ref.detach())
         gy = q(rnd(tuple(ref.shape), 11), dtype)
         ref.backward(gy)
-        gx = ops.maxpool_bwd(dtype, xd, y, to_dev(gy, dtype))
+        gx = ops.maxpool_bwd(dtype, xd, y, to_dev(gy, dtype))            # with the pooled output: equality test + tie scan
         assert rel_err(from_dev(gx), x.grad) < TOL[dtype]
+        gx0 = ops.maxpool_bwd(dtype, xd, None, to_dev(gy, dtype))        # without: arg-max recomputed per window
+        assert torch.equal(gx0, gx)
 
 
 @pytest.mark.parametrize("dtype", [0, 1, 2])
