@@ -238,14 +238,14 @@ class HipBackend(object):
             cs.append(c)
         return torch.stack(hs, 0), torch.stack(cs, 0)
 
-    def fusion_gather_bwd(self, P, xyz, idx, stride, aff, w1d_off, b1_off, ghsum, inv=None, site=0):
+    def fusion_gather_bwd(self, P, xyz, idx, stride, aff, w1d_off, b1_off, ghsum, inv=None, site=0, inv_nmax=None):
         """inv: inverse KNN maps of the step (ops.fusion_invert, map = site*B + frame) -> the point-sorted backward;
         else the pixel-run one."""
         gP = torch.zeros(P.shape, dtype=torch.float32, device=self.dev)
         use_inv = inv is not None and P.shape[2] % 64 == 0 and 64 <= P.shape[2] <= 256
         for b in range(P.shape[0]):
             if use_inv:
-                ops.fusion_gather_bwd_inv(self.dtype, P[b], xyz[b], inv, site * P.shape[0] + b, tuple(idx.shape[-3:]), stride, aff, self.params[w1d_off:],
+                ops.fusion_gather_bwd_inv(self.dtype, P[b], xyz[b], inv, inv_nmax or P.shape[1], site * P.shape[0] + b, tuple(idx.shape[-3:]), stride, aff, self.params[w1d_off:],
                                           self.params[b1_off:], ghsum[b], gP[b], self.grads[w1d_off:], self.grads[b1_off:])
             else:
                 ops.fusion_gather_bwd(self.dtype, P[b], xyz[b], idx[b], stride, aff, self.params[w1d_off:], self.params[b1_off:],

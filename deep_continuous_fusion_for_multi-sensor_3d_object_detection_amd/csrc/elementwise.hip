@@ -636,9 +636,11 @@ __global__ void __launch_bounds__(256) k_rowscale_bias_bwd(const T *gy, const fl
     if (t < stride) {
         const int cg = (int)(t % cgroups);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t e = t; e < nvec; e += stride) {
+        int64_t p = t / cgroups;                          // pixel of element e; stride is a multiple of cgroups
+        const int64_t pstep = stride / cgroups;
+        for (int64_t e = t; e < nvec; e += stride, p += pstep) {
             const float4 g = ld4(gy + e * 4);
-            const float k = cnt[e / cgroups];
+            const float k = cnt[p];
             acc.x += k * g.x; acc.y += k * g.y; acc.z += k * g.z; acc.w += k * g.w;
         }
         atomicAdd(&sm[cg * 4 + 0], acc.x);

@@ -437,10 +437,10 @@ class Plan(object):
     # ------------------------------------------------------------------ fusion
     def _fusion_forward(self, K, f, x, fmap, geom, site, save):
         B, h, w, cb = x.shape
-        n_max = geom["xyz"].shape[1]
         if geom.get("event") is not None and not geom.get("_waited"):
             K.wait_event(geom["event"])                # KNN indices produced on the geometry side stream
             geom["_waited"] = True
+        n_max = self._fusion_rows(geom)
         # every site samples the same camera map at the same (u, v): the point features are computed once per step
         fp = self.ctx.get("fuse_fp") if save else None
         if fp is None:
@@ -454,6 +454,24 @@ class Plan(object):
         if save:
             self.ctx["fuse%d" % site] = dict(fp=fp, P=P, hsum=hsum, cnt=cnt, geom=geom, fmap_shape=tuple(fmap.shape))
         return out
+
+    @staticmethod
+    def _fusion_rows(geom):
+        """Rows of the per-point fusion tensors.  xyz / uv are padded to max_num_pc, but only the first n_valid rows of a
+        frame are real (typically a third: the points inside the camera frustum).  When the producer of the geometry
+        handed over a host copy of the counts (train.geometry_async: pinned buffer + event, issued before the KNN), the
+        per-point tensors -- sampled features, the fc1 GEMMs, their gradients -- are sized to the largest count rounded
+        up to 256 rows instead.  The wait is on a copy that finished long before the host gets here (the host runs a
+        couple of ms ahead of the GPU)."""
+        n = geom.get("n_rows")
+        if n is None:
+            n = geom["xyz"].shape[1]
+            ch = geom.get("cnt_host")
+            if ch is not None:
+                geom["cnt_event"].synchronize()
+                n = min(n, max(256, (int(ch.max()) + 255) // 256 * 256))
+            geom["n_rows"] = n
+        return n
 
     def _fusion_backward(self, K, f, g, site, gF):
         s = self.ctx.pop("fuse%d" % site)
@@ -470,7 +488,7 @@ class Plan(object):
             K.wait_event(geom["inv_event"])            # inverse KNN maps produced on the geometry side stream
             geom["_inv_waited"] = True
         gP = K.fusion_gather_bwd(s["P"], geom["xyz"], geom["idx"][site], f["stride"], geom["aff"], f["w1d_off"], f["b1_off"], ghsum,
-                                 inv, site)
+                                 inv, site, geom.get("inv_nmax"))
         gPc = K.cast_like(gP, s["P"]).view(B, n_max, 1, cb)
         fp4 = s["fp"].view(B, n_max, 1, s["fp"].shape[-1])
         K.conv_wgrad(f["fc1_feat"], fp4, gPc)

@@ -324,6 +324,7 @@ class ObjectDetection_DCF(nn.Module):
         n_max = geom["xyz"].shape[1]
         maps = [t[b] for t in geom["idx"] for b in range(t.shape[0])]          # map index = site * B + frame
         geom["inv"] = ops.fusion_invert(maps, n_max)
+        geom["inv_nmax"] = n_max
         return geom
 
     def forward(self, x_lidar, x_image, points=None, uv=None, n_valid=None, geom=None):

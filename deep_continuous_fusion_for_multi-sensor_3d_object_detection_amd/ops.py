@@ -292,10 +292,11 @@ def fusion_invert(maps, n_max):
     return start, ent
 
 
-def fusion_gather_bwd_inv(dtype, P, xyz, inv, g, khw, stride, aff, w1d, b1, ghsum, gP, gw1d, gb1):
-    """g: index of this (site, frame) map in the fusion_invert call; khw = (K, h, w) of the map."""
+def fusion_gather_bwd_inv(dtype, P, xyz, inv, n_max, g, khw, stride, aff, w1d, b1, ghsum, gP, gw1d, gb1):
+    """n_max: the point-id range fusion_invert was called with; g: index of this (site, frame) map in that call;
+    khw = (K, h, w) of the map.  P / gP may hold fewer rows than n_max (only ids below the valid count occur)."""
     start, ent = inv
-    n_max, Cb = P.shape
+    Cb = P.shape[1]
     seg = start[g * (n_max + 1):]
     H.call("dcf_fusion_gather_bwd_inv", dtype, P, xyz, seg, seg[n_max:], ent[0], ent[1], khw[0] * khw[1] * khw[2], khw[1], khw[2], stride,
            float(aff[0]), float(aff[1]), float(aff[2]), float(aff[3]), w1d, b1, Cb, ghsum, gP, gw1d, gb1, H.stream_ptr())

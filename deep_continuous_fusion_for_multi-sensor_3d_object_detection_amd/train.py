@@ -81,12 +81,19 @@ class Train(nn.Module):
                 pcs.append(pc); uvs.append(uv); cnts.append(cnt)
             ev_vox = torch.cuda.Event()
             ev_vox.record()
+            # valid-point counts to the host (pinned, asynchronous, issued before the KNN): the engine sizes the per-point
+            # fusion tensors by them instead of max_num_pc (engine.Plan._fusion_rows)
+            cnt_host = torch.empty(len(points_list), dtype=torch.int32).pin_memory()
+            cnt_host.copy_(torch.cat(cnts, 0), non_blocking=True)
+            ev_cnt = torch.cuda.Event()
+            ev_cnt.record()
             geom = None
             if self.model.fusion_enabled:
                 geom = self.model.fusion_geometry(torch.stack(pcs, 0), torch.stack(uvs, 0), torch.cat(cnts, 0))
                 ev = torch.cuda.Event()
                 ev.record()
                 geom["event"] = ev
+                geom["cnt_host"], geom["cnt_event"] = cnt_host, ev_cnt
                 self.model.fusion_inverse(geom)        # needed by the backward only: its own event
                 ev_inv = torch.cuda.Event()
                 ev_inv.record()

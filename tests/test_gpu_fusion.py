@@ -171,6 +171,21 @@ def test_side_stream_geometry_matches_inline():
         b = trainer.model(torch.stack(vox), img.cuda(), points=torch.stack(pcs), uv=torch.stack(uvs), n_valid=torch.cat(cnts))
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+    # with gradients: the side-stream path sizes the per-point tensors by the valid count (a third of max_num_pc here)
+    # and inverts the KNN maps on the side stream; parameters' gradients must agree with the inline path
+    R = torch.from_numpy(pkg("detfill").uniform(tuple(a.shape), 780, -1.0, 1.0)).cuda()
+    grads = []
+    for mode in ("side", "inline"):
+        if mode == "side":
+            x_lidar, geom = trainer.geometry_async(geo, dev_pts)
+            out = trainer.model(x_lidar, img.cuda(), geom=geom)
+            assert geom["n_rows"] < geom["xyz"].shape[1] and geom["n_rows"] % 256 == 0
+        else:
+            out = trainer.model(torch.stack(vox), img.cuda(), points=torch.stack(pcs), uv=torch.stack(uvs), n_valid=torch.cat(cnts))
+        (out * R).sum().backward()
+        grads.append(trainer.model._gradflat.clone())
+    scale = float(grads[1].abs().max())
+    assert float((grads[0] - grads[1]).abs().max()) < 2e-5 * scale
 
 
 @pytest.mark.parametrize("Cb,K,case", [(64, 3, "random"), (128, 5, "random"), (192, 1, "random"), (256, 3, "random"),
@@ -205,7 +220,7 @@ def test_fusion_backward_by_point_matches_pixel_run_kernel(Cb, K, case):
         inv = ops.fusion_invert([idx], n_max)
         start = inv[0].cpu()
         assert int(start[0]) == 0 and int(start[n_max]) == min(K, n) * h * w
-        ops.fusion_gather_bwd_inv(dtype, Pd, xyz, inv, 0, (K, h, w), stride, aff, w1d, b1, gd, *got)
+        ops.fusion_gather_bwd_inv(dtype, Pd, xyz, inv, n_max, 0, (K, h, w), stride, aff, w1d, b1, gd, *got)
         for a, b in zip(got, ref):
             scale = max(float(b.abs().max()), 1e-6)
             assert float((a - b).abs().max()) <= tol * scale * max(1.0, (h * w) ** 0.5), (case, Cb, float((a - b).abs().max()), scale)
