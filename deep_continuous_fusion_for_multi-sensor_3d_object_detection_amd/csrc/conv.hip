@@ -1595,7 +1595,8 @@ extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout,
     if (want > maxs) want = maxs;
     // keep each layer's slab arena small: it is written once and re-read by dcf_wgrad_finalize
     const int64_t slab_bytes = (int64_t)cdiv(Cout, 32) * 32 * kh * kw * Cin * 4;
-    const int64_t cap = (16ll << 20) / slab_bytes;
+    static const char *cap_env = getenv("DCF_SLAB_CAP_MB");
+    const int64_t cap = ((int64_t)(cap_env ? atoi(cap_env) : 16) << 20) / slab_bytes;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     if (want >= 44 && !dma) want = (want + 4) / 8 * 8;   // multiples of 8 (>= 48) enable the generic kernel's XCD-aware work mapping
