@@ -125,9 +125,9 @@ def rocprof_kernel(name):
     (kernel function, template argument list) as rocprofv3 prints them."""
     kind, _, tmpl = name.partition("<")
     t = tmpl.rstrip(">").split(",") if tmpl else []
-    dt = "unsignedshort" if "bf16" in kind else "float"
+    dt = "unsignedshort" if "bf16" in kind else ("f16_t" if "f16" in kind else "float")
     if kind.startswith("conv_wgrad3g"):
-        return "k_conv_wgrad3g", t
+        return "k_conv_wgrad3g", [dt] + t
     if kind.startswith("conv_wgrad3"):
         return "k_conv_wgrad3", [dt] + t
     if kind.startswith("conv_wgrad") or kind.startswith("stem_wgrad"):
@@ -135,7 +135,7 @@ def rocprof_kernel(name):
     if kind.startswith("conv_fwd") or kind.startswith("conv_dgrad") or kind.startswith("stem_fwd"):
         tr = "true" if "dgrad" in kind else "false"
         if t and t[-1].startswith("dma"):
-            return "k_conv_igemm_dma", t[1:-1] + [tr, t[-1][3:]]
+            return "k_conv_igemm_dma", [dt] + t[1:-1] + [tr, t[-1][3:]]
         db = "true" if (t and t[-1] == "db") else "false"
         return "k_conv_igemm", [dt] + [x for x in t if x != "db"] + [tr, db]
     return None
