@@ -36,11 +36,12 @@ class FrameGeometry(object):
             return c["image_height"], c["image_width"]
         return c["image_width"], c["image_height"]
 
-    def __call__(self, lidar_points, want_ids=False, voxel_out=None):
-        """lidar_points [N,3] f32 (any device) -> (voxel [Cz,L,W], pointcloud_raw [max_num_pc,3],
-        uv [max_num_pc,2], n_valid int32[1] on device, ids or None).  voxel_out: optional [Cz,L,W] slice of a
-        batch tensor to write the grid into (saves the stack copy)."""
-        pts = lidar_points.to(device="cuda", dtype=torch.float32).contiguous()
+    def _pts(self, lidar_points):
+        return lidar_points.to(device="cuda", dtype=torch.float32).contiguous()
+
+    def voxelize(self, lidar_points, voxel_out=None):
+        """Voxel grid [Cz,L,W] of one frame (data_import_carla.py:236-258), optionally written into voxel_out."""
+        pts = self._pts(lidar_points)
         g = self.grid
         owner = None
         if self.voxel_mode == H.VOXEL_COMPAT:
@@ -51,16 +52,30 @@ class FrameGeometry(object):
             owner = self._owner.get(key)
             if owner is None:
                 owner = self._owner[key] = torch.zeros((2, g.dims[0] * g.dims[1] * g.dims[2]), dtype=torch.int32, device=pts.device)
-        voxel = ops.voxelize(pts, g.lim, g.aff, g.dims, self.voxel_mode, owner, voxel_out)
+        return ops.voxelize(pts, g.lim, g.aff, g.dims, self.voxel_mode, owner, voxel_out)
+
+    def project(self, lidar_points):
+        """(pointcloud_raw [max_num_pc,3], uv [max_num_pc,2], n_valid int32[1] on device) of one frame
+        (data_import_carla.py:196-210, :262-266)."""
+        pts = self._pts(lidar_points)
         ulim, vlim = self.limits()
         n_out = max(int(self.config["max_num_pc"]), pts.shape[0])
-        uv, xyz, cnt, _ = ops.project_filter(pts, g.lim, self.crt, ulim, vlim, self.proj_mode, n_out=n_out)
+        uv, xyz, cnt, _ = ops.project_filter(pts, self.grid.lim, self.crt, ulim, vlim, self.proj_mode, n_out=n_out)
+        mp = int(self.config["max_num_pc"])
+        return xyz[:mp], uv[:mp], cnt
+
+    def __call__(self, lidar_points, want_ids=False, voxel_out=None):
+        """lidar_points [N,3] f32 (any device) -> (voxel [Cz,L,W], pointcloud_raw [max_num_pc,3],
+        uv [max_num_pc,2], n_valid int32[1] on device, ids or None).  voxel_out: optional [Cz,L,W] slice of a
+        batch tensor to write the grid into (saves the stack copy)."""
+        pts = self._pts(lidar_points)
+        voxel = self.voxelize(pts, voxel_out)
+        xyz, uv, cnt = self.project(pts)
         ids = None
         if want_ids:
-            pin, _, c2 = ops.range_filter(pts, g.lim)
+            pin, _, c2 = ops.range_filter(pts, self.grid.lim)
             ids = pin  # in-range points; trunc'd voxel ids are derived on demand by getLidarImage
-        mp = int(self.config["max_num_pc"])
-        return voxel, xyz[:mp], uv[:mp], cnt, ids
+        return voxel, xyz, uv, cnt, ids
 
 
 class CarlaDataset(Dataset):

@@ -76,17 +76,19 @@ class Train(nn.Module):
             pcs, uvs, cnts = [], [], []
             Cz, L, W = frame_geometry.grid.dims
             x_lidar = torch.empty((len(points_list), Cz, L, W), dtype=torch.float32, device="cuda")
-            for b, pts in enumerate(points_list):
-                _, pc, uv, cnt, _ = frame_geometry(pts, voxel_out=x_lidar[b])     # grid written in place
+            # projection first: its valid-point counts go to the host (pinned, asynchronous) while the voxeliser and the KNN
+            # still run; the engine sizes the per-point fusion tensors by them instead of max_num_pc (Plan._fusion_rows)
+            for pts in points_list:
+                pc, uv, cnt = frame_geometry.project(pts)
                 pcs.append(pc); uvs.append(uv); cnts.append(cnt)
-            ev_vox = torch.cuda.Event()
-            ev_vox.record()
-            # valid-point counts to the host (pinned, asynchronous, issued before the KNN): the engine sizes the per-point
-            # fusion tensors by them instead of max_num_pc (engine.Plan._fusion_rows)
             cnt_host = torch.empty(len(points_list), dtype=torch.int32).pin_memory()
             cnt_host.copy_(torch.cat(cnts, 0), non_blocking=True)
             ev_cnt = torch.cuda.Event()
             ev_cnt.record()
+            for b, pts in enumerate(points_list):
+                frame_geometry.voxelize(pts, voxel_out=x_lidar[b])                # grid written in place
+            ev_vox = torch.cuda.Event()
+            ev_vox.record()
             geom = None
             if self.model.fusion_enabled:
                 geom = self.model.fusion_geometry(torch.stack(pcs, 0), torch.stack(uvs, 0), torch.cat(cnts, 0))
