@@ -208,6 +208,40 @@ __global__ void __launch_bounds__(256) k_voxel_compat_round(const float *pts, in
     }
 }
 
+// The frames of a batch are independent and each round is latency bound (a scattered read, an atomic): blockIdx.y = frame
+// runs them side by side in one launch per round.
+struct VoxBatch {
+    const float *pts[DCF_MAX_VOXEL_BATCH];
+    int n[DCF_MAX_VOXEL_BATCH];
+};
+__global__ void __launch_bounds__(256) k_voxel_compat_round_batch(VoxBatch vb, Lim6 lim, Aff6 aff, int L, int W, int nvox, int round, float *grids,
+                                                                  int *owners)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= vb.n[b]) return;
+    const float *pts = vb.pts[b];
+    float *grid = grids + (size_t)b * nvox;
+    int *owner = owners + (size_t)b * 2 * nvox;
+    const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    if (!in_range(x, y, z, lim)) return;
+    Corner8 c8;
+    corners(x, y, z, aff, L, W, c8);
+    if (round >= 1) {
+        const int c = round - 1;
+        int *ow = owner + (size_t)(c & 1) * nvox;
+        const int v = c8.vox[c];
+        if (ow[v] == i + 1) {
+            grid[v] = __fadd_rn(grid[v], c8.w[c]);
+            ow[v] = 0;
+        }
+    }
+    if (round <= 7) {
+        int *ow = owner + (size_t)(round & 1) * nvox;
+        atomicMax(&ow[c8.vox[round]], i + 1);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_voxel_accum(const float *pts, int n, Lim6 lim, Aff6 aff, int L, int W, float *grid)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -691,6 +725,33 @@ extern "C" int dcf_voxelize(const float *pts, int n, const float *lim, const flo
         dcf_set_error("dcf_voxelize: unknown mode %d", mode);
         return DCF_EINVAL;
     }
+    return DCF_OK;
+}
+
+extern "C" int dcf_voxelize_batch(const float *const *pts, const int *n, int B, const float *lim, const float *aff, int Cz, int L, int W,
+                                  float *grids, void *owner_ws, dcf_stream_t stream)
+{
+    DCF_REQUIRE(pts && n && lim && aff && grids && owner_ws && Cz > 0 && L > 0 && W > 0, "dcf_voxelize_batch: bad arguments");
+    DCF_REQUIRE(B >= 1 && B <= DCF_MAX_VOXEL_BATCH, "dcf_voxelize_batch: 1..%d frames per call", DCF_MAX_VOXEL_BATCH);
+    DCF_REQUIRE((int64_t)Cz * L * W < (1ll << 31), "dcf_voxelize_batch: grid too large for int32 voxel ids");
+    hipStream_t s = S(stream);
+    const int nvox = Cz * L * W;
+    DCF_HIP(hipMemsetAsync(grids, 0, sizeof(float) * (size_t)nvox * B, s));
+    VoxBatch vb;
+    int nmax = 0;
+    for (int b = 0; b < DCF_MAX_VOXEL_BATCH; ++b) {
+        vb.pts[b] = b < B ? pts[b] : nullptr;
+        vb.n[b] = b < B ? n[b] : 0;
+        DCF_REQUIRE(b >= B || (n[b] >= 0 && (n[b] == 0 || pts[b])), "dcf_voxelize_batch: frame %d: null points", b);
+        if (b < B && n[b] > nmax) nmax = n[b];
+    }
+    if (nmax == 0) return DCF_OK;
+    Lim6 l; Aff6 a;
+    memcpy(l.v, lim, sizeof(l.v));
+    memcpy(a.v, aff, sizeof(a.v));
+    for (int r = 0; r <= 8; ++r)
+        DCF_LAUNCH("voxel_compat_round", s, hipLaunchKernelGGL(k_voxel_compat_round_batch, dim3(cdiv(nmax, 256), B), dim3(256), 0, s, vb, l, a, L, W, nvox,
+                                                               r, grids, (int *)owner_ws));
     return DCF_OK;
 }
 

@@ -54,6 +54,23 @@ class FrameGeometry(object):
                 owner = self._owner[key] = torch.zeros((2, g.dims[0] * g.dims[1] * g.dims[2]), dtype=torch.int32, device=pts.device)
         return ops.voxelize(pts, g.lim, g.aff, g.dims, self.voxel_mode, owner, voxel_out)
 
+    def voxelize_batch(self, points_list, out):
+        """Voxel grids of the frames of a batch written into out [B,Cz,L,W]; compat mode runs all frames in one launch
+        per owner round, other modes frame by frame."""
+        if self.voxel_mode != H.VOXEL_COMPAT or len(points_list) > 8:
+            for b, p in enumerate(points_list):
+                self.voxelize(p, out[b])
+            return out
+        pts = [self._pts(p) for p in points_list]
+        g = self.grid
+        key = (pts[0].device, H.stream_ptr(), len(pts))
+        if self._owner is None:
+            self._owner = {}
+        owner = self._owner.get(key)
+        if owner is None:
+            owner = self._owner[key] = torch.zeros((len(pts), 2, g.dims[0] * g.dims[1] * g.dims[2]), dtype=torch.int32, device=pts[0].device)
+        return ops.voxelize_batch(pts, g.lim, g.aff, g.dims, owner, out)
+
     def project(self, lidar_points):
         """(pointcloud_raw [max_num_pc,3], uv [max_num_pc,2], n_valid int32[1] on device) of one frame
         (data_import_carla.py:196-210, :262-266)."""

@@ -214,6 +214,17 @@ def voxelize(pts, lim, aff, dims, mode=H.VOXEL_COMPAT, owner_ws=None, out=None):
     return grid
 
 
+def voxelize_batch(pts_list, lim, aff, dims, owner_ws, out):
+    """Compat-mode grids of B frames in one launch per round: out [B,Cz,L,W] fp32, owner_ws int32 [B,2,Cz*L*W] (zero)."""
+    Cz, L, W = dims
+    B = len(pts_list)
+    ptrs = (ctypes.c_void_p * B)(*[_chk(p, "pts").data_ptr() for p in pts_list])
+    ns = (ctypes.c_int * B)(*[p.shape[0] for p in pts_list])
+    H.call("dcf_voxelize_batch", ctypes.addressof(ptrs), ctypes.addressof(ns), B, H.host_f32(lim), H.host_f32(aff), Cz, L, W, _chk(out, "out"),
+           owner_ws, H.stream_ptr())
+    return out
+
+
 def project_filter(pts, lim, crt, ulim, vlim, mode=H.PROJ_COMPAT, n_out=None, want_src=False):
     """Returns (uv [n_out,2], xyz [n_out,3], count int32[1] (device), src or None); rows past count are zero."""
     n = pts.shape[0]

@@ -85,8 +85,7 @@ class Train(nn.Module):
             cnt_host.copy_(torch.cat(cnts, 0), non_blocking=True)
             ev_cnt = torch.cuda.Event()
             ev_cnt.record()
-            for b, pts in enumerate(points_list):
-                frame_geometry.voxelize(pts, voxel_out=x_lidar[b])                # grid written in place
+            frame_geometry.voxelize_batch(points_list, x_lidar)                  # grids written in place, frames side by side
             ev_vox = torch.cuda.Event()
             ev_vox.record()
             geom = None

@@ -181,3 +181,22 @@ def test_cfg4_cfg5_geometry_scale(npts, hw, K):
         d2.append((dx * dx).astype(np.float32) + (dy * dy).astype(np.float32))
     for k in range(K - 1):
         assert ((d2[k] < d2[k + 1]) | ((d2[k] == d2[k + 1]) & (got[k] < got[k + 1]))).all()
+
+
+def test_voxelize_batch_equals_per_frame():
+    """dcf_voxelize_batch (frames side by side in one launch per owner round) == one dcf_voxelize per frame, bit for bit,
+    for frames of different sizes (including an empty one); the owner workspace comes back zero."""
+    ops, H, det = pkg("ops"), pkg("_hip"), pkg("detfill")
+    cfg = golden_cfg(load_golden("geometry_carla.npz"))
+    g = _spec(cfg)
+    lim6 = (cfg["lidar_x_min"], cfg["lidar_x_max"], cfg["lidar_y_min"], cfg["lidar_y_max"], cfg["lidar_z_min"], cfg["lidar_z_max"])
+    frames = [torch.from_numpy(det.synthetic_points(n, lim6, 70 + i)).cuda() if n else torch.zeros(0, 3, device="cuda")
+              for i, n in enumerate((5000, 0, 12345))]
+    Cz, L, W = g.dims
+    out = torch.full((3, Cz, L, W), float("nan"), device="cuda")
+    owner = torch.zeros((3, 2, Cz * L * W), dtype=torch.int32, device="cuda")
+    ops.voxelize_batch(frames, g.lim, g.aff, g.dims, owner, out)
+    assert int(owner.abs().max()) == 0
+    for b, p in enumerate(frames):
+        ref = ops.voxelize(p, g.lim, g.aff, g.dims, H.VOXEL_COMPAT)
+        assert torch.equal(out[b].view(torch.int32), ref.view(torch.int32))
