@@ -126,6 +126,8 @@ def rocprof_kernel(name):
     kind, _, tmpl = name.partition("<")
     t = tmpl.rstrip(">").split(",") if tmpl else []
     dt = "unsignedshort" if "bf16" in kind else ("f16_t" if "f16" in kind else "float")
+    if kind.startswith("conv_wgrad3g_grp"):
+        return "k_conv_wgrad3g_grp", [dt] + t
     if kind.startswith("conv_wgrad3g"):
         return "k_conv_wgrad3g", [dt] + t
     if kind.startswith("conv_wgrad3"):

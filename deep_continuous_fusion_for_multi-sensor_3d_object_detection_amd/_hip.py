@@ -44,6 +44,8 @@ SIGNATURES = {
     "dcf_conv2d_dgrad": (c_int, [c_int, P, P, P, P, P] + [c_int] * 11 + [P]),
     "dcf_conv2d_wgrad_splits": (c_int, [c_int] * 8),
     "dcf_conv2d_wgrad": (c_int, [c_int, P, P, P, P, c_int] + [c_int] * 11 + [P]),
+    "dcf_conv2d_wgrad_groupable": (c_int, [c_int] * 10),
+    "dcf_conv2d_wgrad_group": (c_int, [P, c_int, P]),
     "dcf_stem7x7_fwd": (c_int, [c_int, P, P, P, P] + [c_int] * 7 + [P]),
     "dcf_stem7x7_wgrad": (c_int, [c_int, P, P, P, P, c_int] + [c_int] * 6 + [P]),
     "dcf_weight_prep": (c_int, [c_int, P, c_int, P, P, P, P, c_float, P]),
@@ -79,6 +81,13 @@ class ConvParam(ctypes.Structure):
                 ("wfwd_off", c_i64), ("wdgrad_off", c_i64), ("shift_off", c_i64), ("slab_off", c_i64), ("gsum_off", c_i64),
                 ("cout", ctypes.c_int32), ("cin", ctypes.c_int32), ("taps", ctypes.c_int32), ("cout_pad", ctypes.c_int32),
                 ("nsplit", ctypes.c_int32), ("flags", ctypes.c_int32), ("pad0", ctypes.c_int32), ("pad1", ctypes.c_int32)]
+
+
+class WgradItem(ctypes.Structure):
+    """struct dcf_wgrad_item of include/dcf_hip.h."""
+    _fields_ = [("dtype", ctypes.c_int32), ("nsplit", ctypes.c_int32), ("x", c_void_p), ("gy", c_void_p), ("slabs", c_void_p),
+                ("gsum", c_void_p), ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("Cin", ctypes.c_int32),
+                ("Cout", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
 class KnnMap(ctypes.Structure):
@@ -142,7 +151,7 @@ def call(name, *args):
     L = lib()
     fn = getattr(L, name)
     rc = fn(*[_ptr(a) for a in args])
-    if fn.restype is c_int and rc != 0 and name not in ("dcf_version", "dcf_conv2d_wgrad_splits", "dcf_prof_read"):
+    if fn.restype is c_int and rc != 0 and name not in ("dcf_version", "dcf_conv2d_wgrad_splits", "dcf_prof_read", "dcf_conv2d_wgrad_groupable"):
         raise DcfError("%s failed (%d): %s" % (name, rc, L.dcf_last_error().decode()))
     return rc
 

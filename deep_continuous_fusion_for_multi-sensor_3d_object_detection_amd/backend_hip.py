@@ -112,6 +112,7 @@ class HipBackend(object):
         self.grads.zero_()
 
     def end_backward(self, layers):
+        self._flush_wgrads()
         H.call("dcf_wgrad_finalize", self.table, self.nconv, self.max_cout, self.params, self.buffers, self.ssarena, self.slabs, self.gsum,
                self.grads, BN_EPS, H.stream_ptr())
 
@@ -157,7 +158,35 @@ class HipBackend(object):
     def _gs(self, L):
         return self.gsum[L.gsum_off:] if (L.bn is not None and not self.bn_train) else None
 
+    def _groupable(self, L, x):
+        g = getattr(L, "_grp", None)
+        if g is None or g[0] != tuple(x.shape):
+            B, Hh, W, Cin = x.shape
+            ok = H.call("dcf_conv2d_wgrad_groupable", self.dtype, B, Hh, W, Cin, L.cout_pad, L.kh, L.kw, L.stride, L.pad) == 1
+            L._grp = g = (tuple(x.shape), ok)
+        return g[1]
+
+    def _flush_wgrads(self):
+        """Issue the collected weight gradients together (dcf_conv2d_wgrad_group: one launch per <= 32 layers)."""
+        q = self._wq
+        if not q:
+            return
+        items = (H.WgradItem * len(q))()
+        for i, (L, x, gy) in enumerate(q):
+            B, Hh, W, Cin = x.shape
+            gs = self._gs(L)
+            items[i] = H.WgradItem(self.dtype, L.nsplit, x.data_ptr(), gy.data_ptr(), self.slabs[L.slab_off:].data_ptr(),
+                                   gs.data_ptr() if gs is not None else None, B, Hh, W, Cin, L.cout_pad, 0)
+        H.call("dcf_conv2d_wgrad_group", ctypes.addressof(items), len(q), H.stream_ptr())
+        self._wq = []                      # the launches are enqueued: x / gy may be released (same stream)
+
+    _wq = []
+
     def conv_wgrad(self, L, x, gy):
+        if self._groupable(L, x):
+            # independent of everything else in the backward: collected (x, gy kept alive) and issued together at the end
+            self._wq = self._wq + [(L, x, gy)]
+            return
         ops.conv2d_wgrad(self.dtype, x, gy, self.slabs[L.slab_off:], L.nsplit, L.kh, L.kw, L.stride, L.pad, self._gs(L))
 
     def stem_fwd(self, L, img4, Hh, W):

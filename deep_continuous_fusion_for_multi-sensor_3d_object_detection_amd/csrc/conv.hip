@@ -1214,7 +1214,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_wgrad3(WgArgs a)
 
 
 template <typename T, int TM, int TN, int NS, int NW>
-__global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g(WgArgs a)
+__device__ __forceinline__ void wgrad3g_body(const WgArgs &a, const int bid)
 {
     static_assert(DT<T>::size == 2, "16-bit element types only");
     constexpr int PK = 32, XROWS = PK + 2;
@@ -1246,8 +1246,8 @@ __global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g(WgArgs a)
     // XCDs pulling its own copy of every range over the fabric.
     const int tiles2 = a.co_tiles * a.ci_tiles;
     const int units = tiles2 * a.nsplit, upx = (units + 7) >> 3;
-    const int slot = blockIdx.x >> 3;
-    const int unit = (blockIdx.x & 7) * upx + slot / 3;
+    const int slot = bid >> 3;
+    const int unit = (bid & 7) * upx + slot / 3;
     if (unit >= units) return;
     const int ki = slot % 3;
     const int slab_id = unit / tiles2;
@@ -1475,6 +1475,32 @@ __global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g(WgArgs a)
     DCF_STAMP(4);
 }
 
+template <typename T, int TM, int TN, int NS, int NW>
+__global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g(WgArgs a)
+{
+    wgrad3g_body<T, TM, TN, NS, NW>(a, blockIdx.x);
+}
+
+// The weight gradients of a backward pass do not depend on each other: up to DCF_WG_GROUP layers in ONE launch (the
+// arguments travel in the kernel-argument segment).  Workgroups of the next layer start on CUs as the previous layer's
+// finish, so there is no drain / launch bubble and no idle tail between layers.  Per-layer grids are multiples of 8
+// workgroups, which keeps every layer's XCD mapping (workgroup index mod 8) intact.
+#define DCF_WG_GROUP 32
+struct WgGroup {
+    WgArgs a[DCF_WG_GROUP];
+    int off[DCF_WG_GROUP + 1];     // first workgroup of each layer
+    int n;
+};
+
+template <typename T, int TM, int TN, int NS, int NW>
+__global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g_grp(WgGroup g)
+{
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < DCF_WG_GROUP; ++k) i += (k < g.n && (int)blockIdx.x >= g.off[k]);
+    wgrad3g_body<T, TM, TN, NS, NW>(g.a[i], (int)blockIdx.x - g.off[i]);
+}
+
 }  // namespace
 
 // ================================================================== C ABI
@@ -1688,6 +1714,60 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
     return DCF_OK;
 }
 
+
+// ---- grouped weight gradients (3x3 / stride 1 / pad 1 layers of the LDS-DMA kernel, 64x64 tiles)
+extern "C" int dcf_conv2d_wgrad_groupable(int dtype, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad)
+{
+    static const char *e = getenv("DCF_WGRAD_GROUP");
+    if (e && atoi(e) == 0) return 0;
+    int TM, TN, KR;
+    if (dtype == DCF_F32 || pad != 1 || !wgrad3_tiles(Cin, Cout, kh, kw, stride, TM, TN, KR)) return 0;
+    if (!(TM == 2 && TN == 2 && KR == 1) || !wgrad3_dma(W, TM, TN) || wgrad3_nw() != 8) return 0;
+    const int64_t es = 2;
+    return ((int64_t)B * H * W * Cin * es < (1ll << 31) && (int64_t)B * H * W * Cout * es < (1ll << 31)) ? 1 : 0;
+}
+
+extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_stream_t stream)
+{
+    DCF_REQUIRE(items && n >= 0, "dcf_conv2d_wgrad_group: bad arguments");
+    hipStream_t s = S(stream);
+    int done = 0;
+    while (done < n) {
+        WgGroup g;
+        const int dtype = items[done].dtype;
+        int cnt = 0, blocks = 0;
+        double flops = 0.0;
+        for (; done + cnt < n && cnt < DCF_WG_GROUP && items[done + cnt].dtype == dtype; ++cnt) {
+            const dcf_wgrad_item &it = items[done + cnt];
+            DCF_REQUIRE(it.x && it.gy && it.slabs && it.nsplit > 0, "dcf_conv2d_wgrad_group: item %d: bad arguments", done + cnt);
+            DCF_REQUIRE(dcf_conv2d_wgrad_groupable(it.dtype, it.B, it.H, it.W, it.Cin, it.Cout, 3, 3, 1, 1),
+                        "dcf_conv2d_wgrad_group: item %d (%dx%d %d->%d) is not a groupable layer", done + cnt, it.H, it.W, it.Cin, it.Cout);
+            WgArgs &a = g.a[cnt];
+            a.dbg = 0;
+            a.x = (const char *)it.x; a.gy = (const char *)it.gy; a.slabs = it.slabs; a.gsum = it.gsum;
+            a.B = it.B; a.H = it.H; a.W = it.W; a.Cin = it.Cin; a.Ho = it.H; a.Wo = it.W; a.Cout = it.Cout;
+            a.kh = 3; a.kw = 3; a.stride = 1; a.pad = 1;
+            a.nsplit = it.nsplit;
+            a.pixbytes = it.Cin * 2;
+            a.xbytes = (unsigned)((int64_t)it.B * it.H * it.W * a.pixbytes);
+            a.gbytes = (unsigned)((int64_t)it.B * it.H * it.W * it.Cout * 2);
+            a.M = it.B * it.H * (it.W + 2);
+            a.per_split = cdiv(cdiv(a.M, 8 * it.nsplit), 32) * 32;
+            a.co_tiles = cdiv(it.Cout, 64);
+            a.ci_tiles = cdiv(it.Cin, 64);
+            g.off[cnt] = blocks;
+            blocks += 8 * 3 * cdiv(a.co_tiles * a.ci_tiles * it.nsplit, 8);
+            flops += 2.0 * it.B * it.H * it.W * (double)it.Cout * it.Cin * 9.0;
+        }
+        for (int k = cnt; k <= DCF_WG_GROUP; ++k) g.off[k] = blocks;
+        for (int k = cnt; k < DCF_WG_GROUP; ++k) g.a[k] = g.a[0];
+        g.n = cnt;
+        if (dtype == DCF_F16) DCF_LAUNCH_W("conv_wgrad3g_grp_f16<2,2,2,8>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3g_grp<f16_t, 2, 2, 2, 8>), dim3(blocks), dim3(512), 0, s, g));
+        else DCF_LAUNCH_W("conv_wgrad3g_grp_bf16<2,2,2,8>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3g_grp<bf16_t, 2, 2, 2, 8>), dim3(blocks), dim3(512), 0, s, g));
+        done += cnt;
+    }
+    return DCF_OK;
+}
 
 // ------------------------------------------------------------------ image stem
 // 7x7 stride-2 pad-3 convolution of the RGB image (SURVEY.md App. D image stream; the

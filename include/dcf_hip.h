@@ -131,6 +131,18 @@ int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout, int kh, in
 int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float *slabs, float *gsum, int nsplit,
                      int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
                      dcf_stream_t stream);
+/* The weight gradients of a backward pass are independent of each other: the 3x3 / stride-1 / pad-1 layers of the
+ * LDS-DMA kernel (dcf_conv2d_wgrad_groupable() == 1; 16-bit dtypes, >= 64 channels on both sides) can be collected and
+ * issued together -- up to 32 layers per launch, the next layer's workgroups starting as the previous one's finish.
+ * items is a HOST array; x / gy must stay alive and unmodified until the call.  Same slabs / gsum as dcf_conv2d_wgrad. */
+typedef struct {
+    int32_t dtype, nsplit;
+    const void *x, *gy;
+    float *slabs, *gsum;       /* gsum may be NULL */
+    int32_t B, H, W, Cin, Cout, pad_;
+} dcf_wgrad_item;
+int dcf_conv2d_wgrad_groupable(int dtype, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
+int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_stream_t stream);
 /* The 7x7/2 RGB stem of the image stream on the NHWC4+halo image. */
 int dcf_stem7x7_fwd(int dtype, const void *img4, const void *w, const float *shift, void *y,
                     int B, int H, int W, int Ho, int Wo, int Cout, int relu, dcf_stream_t stream);
