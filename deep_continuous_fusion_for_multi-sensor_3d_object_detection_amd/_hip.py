@@ -87,7 +87,8 @@ class WgradItem(ctypes.Structure):
     """struct dcf_wgrad_item of include/dcf_hip.h."""
     _fields_ = [("dtype", ctypes.c_int32), ("nsplit", ctypes.c_int32), ("x", c_void_p), ("gy", c_void_p), ("slabs", c_void_p),
                 ("gsum", c_void_p), ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("Cin", ctypes.c_int32),
-                ("Cout", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+                ("Cout", ctypes.c_int32), ("kh", ctypes.c_int32), ("kw", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32),
+                ("pad_", ctypes.c_int32)]
 
 
 class KnnMap(ctypes.Structure):

@@ -9,6 +9,7 @@ Owns (per model, per device):
 The flat parameter / gradient / buffer arenas belong to the model (model.py).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -158,16 +159,8 @@ class HipBackend(object):
     def _gs(self, L):
         return self.gsum[L.gsum_off:] if (L.bn is not None and not self.bn_train) else None
 
-    def _groupable(self, L, x):
-        g = getattr(L, "_grp", None)
-        if g is None or g[0] != tuple(x.shape):
-            B, Hh, W, Cin = x.shape
-            ok = H.call("dcf_conv2d_wgrad_groupable", self.dtype, B, Hh, W, Cin, L.cout_pad, L.kh, L.kw, L.stride, L.pad) == 1
-            L._grp = g = (tuple(x.shape), ok)
-        return g[1]
-
     def _flush_wgrads(self):
-        """Issue the collected weight gradients together (dcf_conv2d_wgrad_group: one launch per <= 32 layers)."""
+        """Issue the collected weight gradients together (dcf_conv2d_wgrad_group: one launch per <= 32 layers of a kernel class)."""
         q = self._wq
         if not q:
             return
@@ -176,14 +169,16 @@ class HipBackend(object):
             B, Hh, W, Cin = x.shape
             gs = self._gs(L)
             items[i] = H.WgradItem(self.dtype, L.nsplit, x.data_ptr(), gy.data_ptr(), self.slabs[L.slab_off:].data_ptr(),
-                                   gs.data_ptr() if gs is not None else None, B, Hh, W, Cin, L.cout_pad, 0)
+                                   gs.data_ptr() if gs is not None else None, B, Hh, W, Cin, L.cout_pad, L.kh, L.kw, L.stride, L.pad, 0)
         H.call("dcf_conv2d_wgrad_group", ctypes.addressof(items), len(q), H.stream_ptr())
         self._wq = []                      # the launches are enqueued: x / gy may be released (same stream)
 
     _wq = []
+    _group = os.environ.get("DCF_WGRAD_GROUP", "1") != "0"
 
-    def conv_wgrad(self, L, x, gy):
-        if self._groupable(L, x):
+    def conv_wgrad(self, L, x, gy, defer=True):
+        """defer=False: gy (or x) is modified in place later in the backward (e.g. masked by a ReLU) -- launch now."""
+        if self._group and defer and L.kind != "stem":
             # independent of everything else in the backward: collected (x, gy kept alive) and issued together at the end
             self._wq = self._wq + [(L, x, gy)]
             return

@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <vector>
 #include <type_traits>
 #include "dcf_common.h"
 
@@ -687,7 +688,7 @@ struct WgArgs {
 };
 
 template <typename T, int TM, int TN>
-__global__ void __launch_bounds__(256) k_conv_wgrad(WgArgs a)
+__device__ __forceinline__ void wgrad_body(const WgArgs &a, const int bid)
 {
     constexpr int ES = DT<T>::size;
     constexpr int PK = 32;                        // pixels per stage
@@ -707,9 +708,10 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgArgs a)
     // pixels 9*tiles times, and now do it out of ONE XCD's L2 instead of the fabric.
     // (Used when the number of pixel ranges is a multiple of 8; otherwise plain tile-major order.)
     const int ninner = a.co_tiles * a.ci_tiles * a.kh * a.kw;
-    const int L = blockIdx.x;
+    const int L = bid;
     const bool xcd = ((a.nsplit & 7) == 0) && (a.nsplit >= 48);   // measured: a loss for the few-range (small-M) layers
     const int slab_id = xcd ? (L / (8 * ninner)) * 8 + (L & 7) : L / ninner;
+    if (slab_id >= a.nsplit) return;          // grouped launches round a layer's grid up to a multiple of 8 workgroups
     int t = xcd ? (L >> 3) % ninner : L % ninner;
     const int tap = t % (a.kh * a.kw); t /= (a.kh * a.kw);
     const int cit = t % a.ci_tiles;
@@ -920,6 +922,12 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgArgs a)
                 if (co < a.Cout && ci < a.Cin) slab[((size_t)co * taps + tap) * a.Cin + ci] = acc[i][j][q];
             }
         }
+}
+
+template <typename T, int TM, int TN>
+__global__ void __launch_bounds__(256) k_conv_wgrad(WgArgs a)
+{
+    wgrad_body<T, TM, TN>(a, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1501,6 +1509,16 @@ __global__ void __launch_bounds__(NW * 64) k_conv_wgrad3g_grp(WgGroup g)
     wgrad3g_body<T, TM, TN, NS, NW>(g.a[i], (int)blockIdx.x - g.off[i]);
 }
 
+// same grouping for the generic weight-gradient kernel (stride-2, 1x1, fusion GEMM layers)
+template <typename T, int TM, int TN>
+__global__ void __launch_bounds__(256) k_conv_wgrad_grp(WgGroup g)
+{
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < DCF_WG_GROUP; ++k) i += (k < g.n && (int)blockIdx.x >= g.off[k]);
+    wgrad_body<T, TM, TN>(g.a[i], (int)blockIdx.x - g.off[i]);
+}
+
 }  // namespace
 
 // ================================================================== C ABI
@@ -1731,40 +1749,98 @@ extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_st
 {
     DCF_REQUIRE(items && n >= 0, "dcf_conv2d_wgrad_group: bad arguments");
     hipStream_t s = S(stream);
-    int done = 0;
-    while (done < n) {
-        WgGroup g;
-        const int dtype = items[done].dtype;
-        int cnt = 0, blocks = 0;
-        double flops = 0.0;
-        for (; done + cnt < n && cnt < DCF_WG_GROUP && items[done + cnt].dtype == dtype; ++cnt) {
-            const dcf_wgrad_item &it = items[done + cnt];
-            DCF_REQUIRE(it.x && it.gy && it.slabs && it.nsplit > 0, "dcf_conv2d_wgrad_group: item %d: bad arguments", done + cnt);
-            DCF_REQUIRE(dcf_conv2d_wgrad_groupable(it.dtype, it.B, it.H, it.W, it.Cin, it.Cout, 3, 3, 1, 1),
-                        "dcf_conv2d_wgrad_group: item %d (%dx%d %d->%d) is not a groupable layer", done + cnt, it.H, it.W, it.Cin, it.Cout);
-            WgArgs &a = g.a[cnt];
-            a.dbg = 0;
-            a.x = (const char *)it.x; a.gy = (const char *)it.gy; a.slabs = it.slabs; a.gsum = it.gsum;
-            a.B = it.B; a.H = it.H; a.W = it.W; a.Cin = it.Cin; a.Ho = it.H; a.Wo = it.W; a.Cout = it.Cout;
-            a.kh = 3; a.kw = 3; a.stride = 1; a.pad = 1;
-            a.nsplit = it.nsplit;
-            a.pixbytes = it.Cin * 2;
-            a.xbytes = (unsigned)((int64_t)it.B * it.H * it.W * a.pixbytes);
-            a.gbytes = (unsigned)((int64_t)it.B * it.H * it.W * it.Cout * 2);
-            a.M = it.B * it.H * (it.W + 2);
-            a.per_split = cdiv(cdiv(a.M, 8 * it.nsplit), 32) * 32;
-            a.co_tiles = cdiv(it.Cout, 64);
-            a.ci_tiles = cdiv(it.Cin, 64);
-            g.off[cnt] = blocks;
-            blocks += 8 * 3 * cdiv(a.co_tiles * a.ci_tiles * it.nsplit, 8);
-            flops += 2.0 * it.B * it.H * it.W * (double)it.Cout * it.Cin * 9.0;
+    // bucket 0: row-sharing LDS-DMA kernel <2,2,2,8>; buckets 1..4: generic kernel <2,2> <2,1> <1,2> <1,1>; -1: on its own
+    std::vector<int> bucket(n);
+    for (int i = 0; i < n; ++i) {
+        const dcf_wgrad_item &it = items[i];
+        DCF_REQUIRE(it.x && it.gy && it.slabs && it.nsplit > 0, "dcf_conv2d_wgrad_group: item %d: bad arguments", i);
+        const int Ho = (it.H + 2 * it.pad - it.kh) / it.stride + 1, Wo = (it.W + 2 * it.pad - it.kw) / it.stride + 1;
+        int TM, TN, KR;
+        if (it.dtype == DCF_F32) bucket[i] = -1;
+        else if (dcf_conv2d_wgrad_groupable(it.dtype, it.B, it.H, it.W, it.Cin, it.Cout, it.kh, it.kw, it.stride, it.pad)) bucket[i] = 0;
+        else if (it.pad == 1 && Ho == it.H && Wo == it.W && wgrad3_tiles(it.Cin, it.Cout, it.kh, it.kw, it.stride, TM, TN, KR)) bucket[i] = -1;
+        else {
+            wgrad_tiles(it.Cin, it.Cout, TM, TN);
+            bucket[i] = 1 + (TM == 2 ? 0 : 2) + (TN == 2 ? 0 : 1);
         }
-        for (int k = cnt; k <= DCF_WG_GROUP; ++k) g.off[k] = blocks;
-        for (int k = cnt; k < DCF_WG_GROUP; ++k) g.a[k] = g.a[0];
-        g.n = cnt;
-        if (dtype == DCF_F16) DCF_LAUNCH_W("conv_wgrad3g_grp_f16<2,2,2,8>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3g_grp<f16_t, 2, 2, 2, 8>), dim3(blocks), dim3(512), 0, s, g));
-        else DCF_LAUNCH_W("conv_wgrad3g_grp_bf16<2,2,2,8>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3g_grp<bf16_t, 2, 2, 2, 8>), dim3(blocks), dim3(512), 0, s, g));
-        done += cnt;
+        if (bucket[i] < 0) {
+            int rc = dcf_conv2d_wgrad(it.dtype, it.x, it.gy, it.slabs, it.gsum, it.nsplit, it.B, it.H, it.W, it.Cin, Ho, Wo, it.Cout, it.kh, it.kw,
+                                      it.stride, it.pad, stream);
+            if (rc) return rc;
+        }
+    }
+    static const char *gen_env = getenv("DCF_WGRAD_GROUP_GENERIC");
+    const bool group_generic = !(gen_env && atoi(gen_env) == 0);
+    for (int bk = 0; bk <= 4; ++bk) {
+        for (int dt = DCF_BF16; dt <= DCF_F16; ++dt) {
+            WgGroup g;
+            int cnt = 0, blocks = 0;
+            double flops = 0.0;
+            auto flush = [&]() -> int {
+                if (cnt == 0) return DCF_OK;
+                for (int k = cnt; k <= DCF_WG_GROUP; ++k) g.off[k] = blocks;
+                for (int k = cnt; k < DCF_WG_GROUP; ++k) g.a[k] = g.a[0];
+                g.n = cnt;
+#define DCF_GRP_GEN(TM_, TN_)                                                                                                                      \
+    do {                                                                                                                                           \
+        if (dt == DCF_F16) DCF_LAUNCH_W("conv_wgrad_grp_f16<" #TM_ "," #TN_ ">", flops, s, hipLaunchKernelGGL((k_conv_wgrad_grp<f16_t, TM_, TN_>), dim3(blocks), dim3(256), 0, s, g)); \
+        else DCF_LAUNCH_W("conv_wgrad_grp_bf16<" #TM_ "," #TN_ ">", flops, s, hipLaunchKernelGGL((k_conv_wgrad_grp<bf16_t, TM_, TN_>), dim3(blocks), dim3(256), 0, s, g)); \
+    } while (0)
+                if (bk == 0) {
+                    if (dt == DCF_F16) DCF_LAUNCH_W("conv_wgrad3g_grp_f16<2,2,2,8>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3g_grp<f16_t, 2, 2, 2, 8>), dim3(blocks), dim3(512), 0, s, g));
+                    else DCF_LAUNCH_W("conv_wgrad3g_grp_bf16<2,2,2,8>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3g_grp<bf16_t, 2, 2, 2, 8>), dim3(blocks), dim3(512), 0, s, g));
+                } else if (bk == 1) DCF_GRP_GEN(2, 2);
+                else if (bk == 2) DCF_GRP_GEN(2, 1);
+                else if (bk == 3) DCF_GRP_GEN(1, 2);
+                else DCF_GRP_GEN(1, 1);
+#undef DCF_GRP_GEN
+                cnt = 0; blocks = 0; flops = 0.0;
+                return DCF_OK;
+            };
+            for (int i = 0; i < n; ++i) {
+                const dcf_wgrad_item &it = items[i];
+                if (bucket[i] != bk || it.dtype != dt) continue;
+                const int Ho = (it.H + 2 * it.pad - it.kh) / it.stride + 1, Wo = (it.W + 2 * it.pad - it.kw) / it.stride + 1;
+                if (bk > 0 && !group_generic) {
+                    int rc = dcf_conv2d_wgrad(it.dtype, it.x, it.gy, it.slabs, it.gsum, it.nsplit, it.B, it.H, it.W, it.Cin, Ho, Wo, it.Cout, it.kh,
+                                              it.kw, it.stride, it.pad, stream);
+                    if (rc) return rc;
+                    continue;
+                }
+                WgArgs &a = g.a[cnt];
+                a.dbg = 0;
+                a.x = (const char *)it.x; a.gy = (const char *)it.gy; a.slabs = it.slabs; a.gsum = it.gsum;
+                a.B = it.B; a.H = it.H; a.W = it.W; a.Cin = it.Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = it.Cout;
+                a.kh = it.kh; a.kw = it.kw; a.stride = it.stride; a.pad = it.pad;
+                a.nsplit = it.nsplit;
+                a.pixbytes = it.Cin * 2;
+                DCF_REQUIRE((int64_t)it.B * it.H * it.W * a.pixbytes < 0xFFFFFF00ll && (int64_t)it.B * Ho * Wo * it.Cout * 4 < 0xFFFFFF00ll,
+                            "dcf_conv2d_wgrad_group: item %d: tensor exceeds the 4 GiB buffer-descriptor range", i);
+                a.xbytes = (unsigned)((int64_t)it.B * it.H * it.W * a.pixbytes);
+                a.gbytes = (unsigned)((int64_t)it.B * Ho * Wo * it.Cout * 2);
+                g.off[cnt] = blocks;
+                if (bk == 0) {
+                    a.M = it.B * it.H * (it.W + 2);
+                    a.per_split = cdiv(cdiv(a.M, 8 * it.nsplit), 32) * 32;
+                    a.co_tiles = cdiv(it.Cout, 64);
+                    a.ci_tiles = cdiv(it.Cin, 64);
+                    blocks += 8 * 3 * cdiv(a.co_tiles * a.ci_tiles * it.nsplit, 8);
+                } else {
+                    int TM, TN;
+                    wgrad_tiles(it.Cin, it.Cout, TM, TN);
+                    a.M = it.B * Ho * Wo;
+                    a.per_split = cdiv(cdiv(a.M, 4 * it.nsplit), 32) * 32;
+                    a.co_tiles = cdiv(it.Cout, TM * 32);
+                    a.ci_tiles = cdiv(it.Cin, TN * 32);
+                    // the kernel's XCD mapping wants a layer to start on a multiple of 8 workgroups; the extra ones exit at once
+                    blocks += (a.co_tiles * a.ci_tiles * it.kh * it.kw * it.nsplit + 7) / 8 * 8;
+                }
+                flops += 2.0 * it.B * Ho * Wo * (double)it.Cout * it.Cin * it.kh * it.kw;
+                if (++cnt == DCF_WG_GROUP) { int rc = flush(); if (rc) return rc; }
+            }
+            int rc = flush();
+            if (rc) return rc;
+        }
     }
     return DCF_OK;
 }

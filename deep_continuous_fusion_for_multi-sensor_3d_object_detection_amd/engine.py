@@ -478,7 +478,7 @@ class Plan(object):
         geom = s["geom"]
         B, n_max, cb = s["P"].shape
         K.rowscale_bias_bwd(g, s["cnt"], f["b2_off"])
-        K.conv_wgrad(f["fc2"], s["hsum"], g)
+        K.conv_wgrad(f["fc2"], s["hsum"], g, defer=False)      # g is masked in place by the stage's last block afterwards
         ghsum = K.conv_dgrad(f["fc2"], g, tuple(s["hsum"].shape), None)
         inv = geom.get("inv")
         import os

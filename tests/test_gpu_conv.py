@@ -169,3 +169,34 @@ def test_conv_full_size_layer_linearity():
     yb = ops.conv2d_fwd(1, x1.bfloat16(), w.bfloat16(), None, None, 3, 3, 1, 1, False, C).float()
     yr = ops.conv2d_fwd(0, x1.bfloat16().float(), w.bfloat16().float(), None, None, 3, 3, 1, 1, False, C)
     assert float((yb - yr).abs().max() / yr.abs().max()) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", [1, 2])
+def test_wgrad_group_equals_single_launches(dtype):
+    """dcf_conv2d_wgrad_group (layers collected and issued kernel class by kernel class, up to 32 per launch) writes
+    bitwise the same slabs / dbeta sums as one dcf_conv2d_wgrad per layer: row-sharing LDS-DMA layers (several, so that
+    workgroup offsets matter), generic stride-2 / 1x1 layers, and a 32-channel layer that goes out on its own."""
+    import ctypes
+    ops, H = pkg("ops"), pkg("_hip")
+    shapes = [(2, 12, 40, 64, 64, 3, 1), (1, 9, 47, 128, 64, 3, 1), (2, 7, 50, 64, 128, 3, 1), (2, 17, 13, 64, 64, 3, 2),
+              (1, 24, 16, 256, 192, 1, 1), (2, 10, 10, 128, 192, 3, 2), (1, 40, 52, 32, 32, 3, 1), (1, 8, 8, 192, 256, 1, 1)]
+    keep, items, want = [], [], []
+    for i, (B, Hh, W, Cin, Cout, k, s) in enumerate(shapes):
+        pad = k // 2
+        Ho, Wo = (Hh + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+        x = to_dev(q(rnd((B, Cin, Hh, W), 300 + i), dtype), dtype)
+        gy = to_dev(q(rnd((B, Cout, Ho, Wo), 400 + i), dtype), dtype)
+        ns = ops.conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, k, k, s)
+        ref = torch.full((ns, Cout, k, k, Cin), float("nan"), device="cuda")
+        refs = torch.full((4 * ns, Cout), float("nan"), device="cuda")
+        ops.conv2d_wgrad(dtype, x, gy, ref, ns, k, k, s, pad, refs)
+        got = torch.full_like(ref, float("nan"))
+        gots = torch.full_like(refs, float("nan"))
+        keep += [x, gy, got, gots]
+        want.append((ref, refs, got, gots))
+        items.append(H.WgradItem(dtype, ns, x.data_ptr(), gy.data_ptr(), got.data_ptr(), gots.data_ptr(), B, Hh, W, Cin, Cout, k, k, s, pad, 0))
+    arr = (H.WgradItem * len(items))(*items)
+    H.call("dcf_conv2d_wgrad_group", ctypes.addressof(arr), len(items), H.stream_ptr())
+    torch.cuda.synchronize()
+    for ref, refs, got, gots in want:
+        assert torch.equal(ref, got) and torch.equal(refs, gots)
