@@ -802,7 +802,9 @@ extern "C" int dcf_image_to_nhwc4(int dtype, const uint8_t *img, void *y, int B,
 
 static inline int64_t chan_stride(int64_t nvec, int cgroups, int &blocks)
 {
-    int64_t want = nvec < 256 * 1024 ? nvec : 256 * 1024;  // ~1024 blocks of 256 threads
+    static const char *env = getenv("DCF_CHANSUM_KTHREADS");
+    const int64_t cap = (env ? atoi(env) : 256) * 1024ll;
+    int64_t want = nvec < cap ? nvec : cap;                // 256 k threads = ~1024 blocks of 256 threads
     if (want < cgroups) want = cgroups;
     const int64_t stride = want / cgroups * cgroups;
     blocks = cdiv(stride, 256);

@@ -12,6 +12,8 @@
 // passes are scatter-adds with fp32 atomics.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "dcf_common.h"
 
 namespace {
@@ -296,17 +298,17 @@ template <typename T, int CJ>
 __global__ void __launch_bounds__(256) k_fusion_gather_bwd_inv(const T *__restrict__ P, const float *__restrict__ xyz, const int *__restrict__ e_begin, const int *__restrict__ e_end,
                                                                const int *__restrict__ ent_pix, const int *__restrict__ ent_pt, FuseGeom g,
                                                                const float *__restrict__ w1d, const float *__restrict__ b1, int C,
-                                                               const T *__restrict__ ghsum, float *gP, float *gw1d, float *gb1)
+                                                               const T *__restrict__ ghsum, float *gP, float *gw1d, float *gb1, int SL)
 {
-    constexpr int SL = 128, U = 8;
+    constexpr int U = 8;
     extern __shared__ float sm[];  // [C][4]: gw1d x3, gb1
     for (int i = threadIdx.x; i < C * 4; i += blockDim.x) sm[i] = 0.f;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int E0 = *e_begin, E = *e_end;
-    const int lo = E0 + wave * SL, hi = min(E, lo + SL);
-    if (lo < hi) {
+    const int nwaves = gridDim.x * 4;                    // the grid is capped: a wave takes slices wave, wave + nwaves, ...
+    if (E0 + wave * SL < E) {                             // (fewer workgroups = fewer same-address atomics on dW1d / db1)
         float w0[CJ], w1[CJ], w2[CJ], bb[CJ], a0[CJ], a1[CJ], a2[CJ], ab[CJ], cur_acc[CJ];
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
@@ -314,6 +316,8 @@ __global__ void __launch_bounds__(256) k_fusion_gather_bwd_inv(const T *__restri
             w0[j] = w1d[c * 3]; w1[j] = w1d[c * 3 + 1]; w2[j] = w1d[c * 3 + 2]; bb[j] = b1[c];
             a0[j] = a1[j] = a2[j] = ab[j] = cur_acc[j] = 0.f;
         }
+      for (int sidx = wave; E0 + sidx * SL < E; sidx += nwaves) {
+        const int lo = E0 + sidx * SL, hi = min(E, lo + SL);
         int cur_pt = -1;
         auto bcast_i = [](int v, int i) { return __builtin_amdgcn_readlane(v, i); };
         auto bcast_f = [](float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); };
@@ -372,6 +376,9 @@ __global__ void __launch_bounds__(256) k_fusion_gather_bwd_inv(const T *__restri
             for (int j = 0; j < CJ; ++j)
                 if (cur_acc[j] != 0.f) atomicAdd(gP + (int64_t)cur_pt * C + lane + 64 * j, cur_acc[j]);
         }
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) cur_acc[j] = 0.f;
+      }
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
             const int c = lane + 64 * j;
@@ -471,8 +478,15 @@ extern "C" int dcf_fusion_gather_bwd_inv(int dtype, const void *P, const float *
     FuseGeom g;
     g.h = h; g.w = w; g.stride = stride; g.K = 0; g.xs = xs; g.xo = xo; g.ys = ys; g.yo = yo;
     hipStream_t s = S(stream);
-    const int waves = cdiv(max_entries, 128), blocks = cdiv(waves, 4);
-#define DCF_FGI(CJ_) DCF_LAUNCH("fusion_gather_bwd_inv", s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_>), dim3(blocks), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1))
+    // pairs per wave: 128 on the big sites; the coarse sites have few pairs (6.6 k at stride 16) and would otherwise run on
+    // a few dozen waves, one exposed latency after the other
+    int sl = cdiv(cdiv(max_entries, 4096), 16) * 16;
+    sl = sl < 16 ? 16 : (sl > 128 ? 128 : sl);
+    const int waves = cdiv(max_entries, sl);
+    static const char *cap_env = getenv("DCF_FUSION_BWD_BLOCKS");
+    const int cap = cap_env ? atoi(cap_env) : 256;     // swept: 128 / 256 / 512 / uncapped = 0.52 / 0.34 / 0.36 / 0.44 ms per step
+    const int blocks = std::min(cdiv(waves, 4), cap);
+#define DCF_FGI(CJ_) DCF_LAUNCH("fusion_gather_bwd_inv", s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_>), dim3(blocks), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, sl))
     DCF_DISPATCH_DTYPE(dtype, {
         if (Cb == 64) DCF_FGI(1);
         else if (Cb == 128) DCF_FGI(2);
