@@ -1618,15 +1618,20 @@ extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout,
 {
     int TM, TN, KR;
     int tiles;
-    int64_t want_blocks = 1024;                       // ~16 waves per CU in total (more splits measured slower)
+    static const char *gb = getenv("DCF_WGRAD_BLOCKS");
+    // Workgroups per layer.  The backward issues the weight gradients in grouped launches (dcf_conv2d_wgrad_group), where
+    // the layers overlap each other: a layer does not have to fill the chip on its own, and fewer pixel ranges mean fewer
+    // slabs to write / reduce and fewer in-kernel epilogues.  Swept on cfg2 (40-step runs): 240/1024 -> 264.8 frames/s,
+    // 160/512 -> 266.4, 120/512 -> 270.5, 80/512 -> 270.5, 120/384 -> 270.0.
+    int64_t want_blocks = gb ? atoi(gb) : 512;
     bool dma = false;
     if (wgrad3_tiles(Cin, Cout, kh, kw, stride, TM, TN, KR)) {
         tiles = cdiv(Cout, TM * 32) * cdiv(Cin, TN * 32) * (3 / KR);
         static const char *wb = getenv("DCF_WGRAD3_BLOCKS");
         // the LDS-DMA kernel runs one workgroup per CU: one wave of workgroups (floor, not ceil)
         dma = wgrad3_dma(Wo, TM, TN);
-        // LDS-DMA kernel: one workgroup per CU, 32 CUs per XCD, 3 workgroups per unit -> 10 units per XCD, 80 in all
-        if (dma) { want_blocks = wb ? atoi(wb) : 240; if (tiles <= want_blocks) want_blocks -= tiles - 1; }
+        // LDS-DMA kernel: one workgroup per CU, 3 workgroups per unit; 120 workgroups = 5 units per XCD (see below)
+        if (dma) { want_blocks = wb ? atoi(wb) : 120; if (tiles <= want_blocks) want_blocks -= tiles - 1; }
         else want_blocks = 512;
     } else {
         wgrad_tiles(Cin, Cout, TM, TN);
