@@ -227,8 +227,8 @@ def cpu_baseline(cfg, pool_seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=2, help="frames per GPU (cfg2: 2)")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--points", type=int, default=100000)
