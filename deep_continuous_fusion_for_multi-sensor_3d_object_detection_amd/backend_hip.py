@@ -111,6 +111,7 @@ class HipBackend(object):
             self._upload_table(layers)
             self._sig = sig
         self.grads.zero_()
+        self._wq = []                      # weight gradients collected by a backward that did not finish are dropped
 
     def end_backward(self, layers):
         self._flush_wgrads()
