@@ -116,7 +116,7 @@ def roofline_leg(trainer, pool, B, steps):
                  "gpu_ms_per_step_all_kernels": round(total_ms / steps, 3), "event_bracket_us_subtracted": round(bracket_ms * 1e3, 2)})
     roof["traffic"], roof["traffic_source"] = pmc_traffic(name)
     breakdown = [{"kernel": n, "ms_per_step": round(m / steps, 4), "calls_per_step": c / steps,
-                  "tflops": round(w / (m * 1e-3) / 1e12, 1) if w > 0 and m > 0 else None} for n, m, c, w in table[:16]]
+                  "tflops": round(w / (m * 1e-3) / 1e12, 1) if w > 0 and m > 0 else None} for n, m, c, w in table[:40]]
     return roof, breakdown
 
 

@@ -58,6 +58,8 @@ SIGNATURES = {
     "dcf_resize_bilinear_bwd": (c_int, [c_int, P, P] + [c_int] * 7 + [P]),
     "dcf_maxpool3x3s2_fwd": (c_int, [c_int, P, P] + [c_int] * 6 + [P]),
     "dcf_maxpool3x3s2_bwd": (c_int, [c_int, P, P, P, P] + [c_int] * 6 + [P]),
+    "dcf_maxpool3x3s2_fwd_idx": (c_int, [c_int, P, P, P] + [c_int] * 6 + [P]),
+    "dcf_maxpool3x3s2_bwd_idx": (c_int, [c_int, P, P, P] + [c_int] * 6 + [P]),
     "dcf_head_fwd": (c_int, [c_int, P, c_int, P, P, c_int, c_int, c_int, P]),
     "dcf_head_bwd": (c_int, [c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
     "dcf_point_sample_fwd": (c_int, [c_int, P, c_int, c_int, c_int, P, P, c_int, P, P]),

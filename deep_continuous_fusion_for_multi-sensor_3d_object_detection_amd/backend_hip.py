@@ -229,7 +229,12 @@ class HipBackend(object):
     def maxpool_fwd(self, x):
         return ops.maxpool_fwd(self.dtype, x)
 
-    def maxpool_bwd(self, x, gy, y=None):
+    def maxpool_fwd_idx(self, x):
+        return ops.maxpool_fwd_idx(self.dtype, x)
+
+    def maxpool_bwd(self, x, gy, y=None, idx=None):
+        if idx is not None:
+            return ops.maxpool_bwd_idx(self.dtype, idx, gy, tuple(x.shape))
         return ops.maxpool_bwd(self.dtype, x, y, gy)
 
     def head_fwd(self, head, anchors):

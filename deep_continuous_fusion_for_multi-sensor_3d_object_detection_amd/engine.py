@@ -390,7 +390,10 @@ class Plan(object):
         B, _, Hh, W = x_image.shape
         img4 = K.image_to_nhwc4(x_image)
         c1 = K.stem_fwd(self.stem, img4, Hh, W)
-        x = pool = K.maxpool_fwd(c1)
+        if save:
+            x, pool_idx = K.maxpool_fwd_idx(c1)
+        else:
+            x, pool_idx = K.maxpool_fwd(c1), None
         feats = []
         for blocks in self.img_stages:
             for b in blocks:
@@ -405,7 +408,7 @@ class Plan(object):
                 p2 = p
         fmap = K.conv_fwd(self.img_smooth, p2, None, False)
         if save:
-            self.ctx["img"] = dict(img4=img4, hw=(Hh, W), c1=c1, pool=pool, feats=feats, p2=p2)
+            self.ctx["img"] = dict(img4=img4, hw=(Hh, W), c1=c1, pool_idx=pool_idx, feats=feats, p2=p2)
         return fmap
 
     def _image_backward(self, K, gF):
@@ -430,7 +433,7 @@ class Plan(object):
                 g = blocks[bi].backward(K, g, extra, need_gx=True, g_masked=masked, prev=prev)
                 masked = prev is not None
         # g = gradient at the max-pool output
-        gc1 = K.maxpool_bwd(im["c1"], g, im.get("pool"))
+        gc1 = K.maxpool_bwd(im["c1"], g, None, im.get("pool_idx"))
         gc1 = K.bn_bwd(self.stem, K.relu_mask(gc1, im["c1"]))
         K.stem_wgrad(self.stem, im["img4"], gc1, im["hw"][0], im["hw"][1])
 

@@ -138,6 +138,24 @@ def maxpool_fwd(dtype, x):
     return y
 
 
+def maxpool_fwd_idx(dtype, x):
+    """(y, idx): pooled output and the arg-max positions (uint32 [B,Ho,Wo,C/4], one byte per channel)."""
+    B, Hh, W, C = x.shape
+    Ho, Wo = (Hh - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((B, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    idx = torch.empty((B, Ho, Wo, C // 4), dtype=torch.int32, device=x.device)
+    H.call("dcf_maxpool3x3s2_fwd_idx", dtype, x, y, idx, B, Hh, W, Ho, Wo, C, H.stream_ptr())
+    return y, idx
+
+
+def maxpool_bwd_idx(dtype, idx, gy, in_shape):
+    B, Hh, W, C = in_shape
+    _, Ho, Wo, _ = gy.shape
+    gx = torch.empty(in_shape, dtype=gy.dtype, device=gy.device)
+    H.call("dcf_maxpool3x3s2_bwd_idx", dtype, idx, gy, gx, B, Hh, W, Ho, Wo, C, H.stream_ptr())
+    return gx
+
+
 def maxpool_bwd(dtype, x, y, gy):
     B, Hh, W, C = x.shape
     _, Ho, Wo, _ = gy.shape

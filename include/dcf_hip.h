@@ -195,6 +195,12 @@ int dcf_maxpool3x3s2_fwd(int dtype, const void *x, void *y, int B, int H, int W,
                          dcf_stream_t stream);
 int dcf_maxpool3x3s2_bwd(int dtype, const void *x, const void *y, const void *gy, void *gx, int B, int H, int W,
                          int Ho, int Wo, int C, dcf_stream_t stream);
+/* Same pooling with the arg-max recorded: idx uint32 [B][Ho][Wo][C/4], one byte per channel = window position dh*3+dw of
+ * the first maximum in scan order; the backward is then a gather over (idx, gy) that never re-reads x. */
+int dcf_maxpool3x3s2_fwd_idx(int dtype, const void *x, void *y, uint32_t *idx, int B, int H, int W, int Ho, int Wo, int C,
+                             dcf_stream_t stream);
+int dcf_maxpool3x3s2_bwd_idx(int dtype, const uint32_t *idx, const void *gy, void *gx, int B, int H, int W, int Ho, int Wo, int C,
+                             dcf_stream_t stream);
 /* Heads (model.py:168-172 softmax pairs, :116-137 box decode, :204 concat):
  * head [B,h,w,Cp] (first 18 channels = 4 class logits + 14 offsets) ->
  * pred [B,32,h,w] fp32 NCHW = cat(softmax2,softmax2, reg14, decode(reg14, anchors[14,h,w])). */

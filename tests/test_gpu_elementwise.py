@@ -70,6 +70,9 @@ def test_maxpool(dtype):
         assert rel_err(from_dev(gx), x.grad) < TOL[dtype]
         gx0 = ops.maxpool_bwd(dtype, xd, None, to_dev(gy, dtype))        # without: arg-max recomputed per window
         assert torch.equal(gx0, gx)
+        y2, idx = ops.maxpool_fwd_idx(dtype, xd)                         # arg-max recorded by the forward: plain gather
+        assert torch.equal(y2, y) and int(idx.view(torch.uint8).max()) <= 8
+        assert torch.equal(ops.maxpool_bwd_idx(dtype, idx, to_dev(gy, dtype), tuple(xd.shape)), gx)
 
 
 @pytest.mark.parametrize("dtype", [0, 1, 2])
