@@ -37,12 +37,12 @@ def pkg(sub):
     return importlib.import_module(PKG + "." + sub)
 
 
-def kitti_config(batch, dtype="bf16", n_points=100000, K=3, image_stream="resnet18"):
+def kitti_config(batch, dtype="bf16", n_points=100000, K=3, image_stream="resnet18", image_wh=(1242, 375)):
     import yaml
     cfg = yaml.safe_load(open(os.path.join(ROOT, PKG, "config", "config_carla.yaml")))
     cfg.update(dict(voxel_length=704, voxel_width=800, voxel_channel=32, lidar_x_min=0.0, lidar_x_max=70.4,
                     lidar_y_min=-40.0, lidar_y_max=40.0, lidar_z_min=-2.4, lidar_z_max=0.8,
-                    image_height=375, image_width=1242, max_num_pc=n_points, batch_size=batch,
+                    image_height=image_wh[1], image_width=image_wh[0], max_num_pc=n_points, batch_size=batch,
                     dtype=dtype, projection_mode="correct", voxel_mode="compat"))
     cfg["fusion"] = dict(enabled=True, K=K, r_max=None, image_channels=64, image_stream=image_stream, zero_init_last=False)
     return cfg
@@ -53,7 +53,9 @@ class FramePool(object):
 
     def __init__(self, cfg, n_frames, n_points, seed0):
         D = pkg("data_import_carla")
-        ds = D.SyntheticDataset(cfg, length=n_frames, num_points=n_points, crt=pkg("calib").kitti_like_crt(),
+        calib = pkg("calib")
+        crt = calib.hd_crt() if cfg["image_width"] == 1920 else calib.kitti_like_crt()     # SURVEY.md 8(d) calibrations
+        ds = D.SyntheticDataset(cfg, length=n_frames, num_points=n_points, crt=crt,
                                 image_hw=(cfg["image_height"], cfg["image_width"]))
         self.geometry = ds.geometry
         self.pts, self.img, self.boxes, self.nb = [], [], [], []
@@ -143,12 +145,17 @@ def rocprof_kernel(name):
     return None
 
 
+PMC_TAG = ""          # profiles/rNNx_<tag>pmc_traffic.csv of the workload being run ("" = cfg2, the default)
+
+
 def pmc_traffic(name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
     command (profiles/*_pmc_traffic.csv; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).
     A bench run cannot collect PMC counters itself; returns (None, None) when no matching row exists."""
     import csv, glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.csv")))
+    if PMC_TAG is None:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9][a-z]_" + PMC_TAG + "pmc_traffic.csv")))
     if not files:
         return None, None
     want = rocprof_kernel(name)
@@ -234,6 +241,7 @@ def main():
     ap.add_argument("--points", type=int, default=100000)
     ap.add_argument("--knn", type=int, default=3, help="neighbours per BEV pixel (cfg2: 3, cfg4: 5)")
     ap.add_argument("--image-stream", default="resnet18", help="camera trunk: resnet18 (cfg2), resnet34, resnet50 (cfg4)")
+    ap.add_argument("--image", default="1242x375", help="camera frame WxH (cfg2/cfg4: 1242x375, cfg5: 1920x1080)")
     ap.add_argument("--bn-mode", default="eval", help="eval = what the reference's train.py really does (F4); train = batch statistics")
     ap.add_argument("--graphs", action="store_true", help="replay captured forward/backward HIP graphs instead of eager launches "
                     "(measured equal on this workload: the step is kernel-bound, not launch-bound)")
@@ -246,8 +254,12 @@ def main():
     rank = dist.get_rank() if ws > 1 else 0
     if ws <= 1:
         torch.cuda.set_device(0)
-    cfg = kitti_config(args.batch, args.dtype, args.points, args.knn, args.image_stream)
+    image_wh = tuple(int(v) for v in args.image.lower().split("x"))
+    cfg = kitti_config(args.batch, args.dtype, args.points, args.knn, args.image_stream, image_wh)
     cfg["bn_mode"] = args.bn_mode
+    global PMC_TAG
+    key = (args.points, args.knn, args.image_stream, args.batch, args.dtype, args.image.lower())
+    PMC_TAG = {(100000, 3, "resnet18", 2, "bf16", "1242x375"): "", (300000, 3, "resnet18", 1, "bf16", "1920x1080"): "cfg5shape_bf16_"}.get(key)
     cfg["hip_graphs"] = bool(args.graphs)
     torch.manual_seed(0)
     np.random.seed(1234 + rank)
@@ -295,11 +307,12 @@ def main():
         out = {"metric": "frames/sec (train step) 100k-pt LiDAR + 1242x375 RGB", "value": round(frames / dt, 3), "unit": "frames/s",
                "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": "%s: grid 32x704x800, %d pts/frame, 1242x375 RGB, %s image stream, K=%d fusion x4 sites, "
+               "config": {"workload": "%s: grid 32x704x800, %d pts/frame, %s RGB, %s image stream, K=%d fusion x4 sites, "
                                       "%s-mode BN%s, batch %d/GPU" % (
-                                          {(100000, 3, "resnet18", 2, "bf16"): "cfg2", (120000, 5, "resnet50", 4, "f16"): "cfg4"}.get(
-                                              (args.points, args.knn, args.image_stream, args.batch, args.dtype), "custom"),
-                                          args.points, {"resnet18": "ResNet-18", "resnet34": "ResNet-34", "resnet50": "ResNet-50"}.get(args.image_stream, args.image_stream),
+                                          {(100000, 3, "resnet18", 2, "bf16", "1242x375"): "cfg2", (120000, 5, "resnet50", 4, "f16", "1242x375"): "cfg4",
+                                           (300000, 3, "resnet18", 1, "bf16", "1920x1080"): "cfg5 shape at bf16 (fp8 convs not built)"}.get(
+                                              (args.points, args.knn, args.image_stream, args.batch, args.dtype, args.image.lower()), "custom"),
+                                          args.points, args.image.lower(), {"resnet18": "ResNet-18", "resnet34": "ResNet-34", "resnet50": "ResNet-50"}.get(args.image_stream, args.image_stream),
                                           args.knn, args.bn_mode, " (reference F4)" if args.bn_mode == "eval" else "", args.batch),
                           "global_batch": args.batch * ws, "parallelism": "dp%d" % ws, "final_loss": round(loss, 4)},
                "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown}
