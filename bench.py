@@ -60,7 +60,7 @@ class FramePool(object):
         self.geometry = ds.geometry
         self.pts, self.img, self.boxes, self.nb = [], [], [], []
         for i in range(n_frames):
-            p, im, b, nb = ds.raw(seed0 + i)
+            p, im, b, nb = ds.raw_frame(seed0 + i)
             self.pts.append(p.cuda())
             self.img.append(im.cuda())
             self.boxes.append(b)

@@ -6,7 +6,10 @@ pinhole projection + compaction (data_import_carla.py:196-267), which the refere
 the CPU inside the DataLoader -- runs here as HIP kernels on the GPU (ops.voxelize /
 ops.project_filter), bit-exact with the reference under deterministic algorithms.
 
-HDF5 reading itself is out of scope for the hot path (no dataset ships with either repo);
+HDF5 scenarios (data_import_carla.py:84-104, :163-171) are read through h5py when it is installed (it is not in
+the build image: constructing a CarlaDataset over a directory that holds .hdf5 files raises ImportError there);
+file handles are opened per process, so the dataset can sit behind DataLoader workers.  raw=True returns the raw
+point list instead of a voxel grid -- the FrameLoader path (frame_loader.py).
 SyntheticDataset produces frames of the same contract for benchmarks and tests.
 """
 import os
@@ -71,13 +74,14 @@ class FrameGeometry(object):
             owner = self._owner[key] = torch.zeros((len(pts), 2, g.dims[0] * g.dims[1] * g.dims[2]), dtype=torch.int32, device=pts[0].device)
         return ops.voxelize_batch(pts, g.lim, g.aff, g.dims, owner, out)
 
-    def project(self, lidar_points):
+    def project(self, lidar_points, crt=None):
         """(pointcloud_raw [max_num_pc,3], uv [max_num_pc,2], n_valid int32[1] on device) of one frame
-        (data_import_carla.py:196-210, :262-266)."""
+        (data_import_carla.py:196-210, :262-266).  crt: this frame's own [4,3] matrix (KITTI calibrates per frame)."""
         pts = self._pts(lidar_points)
         ulim, vlim = self.limits()
         n_out = max(int(self.config["max_num_pc"]), pts.shape[0])
-        uv, xyz, cnt, _ = ops.project_filter(pts, self.grid.lim, self.crt, ulim, vlim, self.proj_mode, n_out=n_out)
+        crt = self.crt if crt is None else np.ascontiguousarray(crt, dtype=np.float32)
+        uv, xyz, cnt, _ = ops.project_filter(pts, self.grid.lim, crt, ulim, vlim, self.proj_mode, n_out=n_out)
         mp = int(self.config["max_num_pc"])
         return xyz[:mp], uv[:mp], cnt
 
@@ -96,13 +100,17 @@ class FrameGeometry(object):
 
 
 class CarlaDataset(Dataset):
-    def __init__(self, config, mode="train", want_bev_image=False):
+    def __init__(self, config, mode="train", want_bev_image=False, raw=False):
         super(CarlaDataset, self).__init__()
         self.config = config
+        self.mode = mode
+        self.raw = bool(raw)
         self.want_bev_image = bool(want_bev_image)
-        self.geometry = FrameGeometry(config)
-        self.CRT_tensor = torch.from_numpy(self.geometry.crt)
+        self._geometry = None
+        self.CRT_tensor = torch.from_numpy(calib.carla_crt())
+        self._pid = None
         self.hdf5_files = self.load_dataset(mode)
+        self._pid = os.getpid()
         self.hdf5_id_dict = dict((k, list(v.keys())) for k, v in self.hdf5_files.items())
         self.scenario_name = list(self.hdf5_files.keys())
         self.scenario_length = [len(self.hdf5_files[k]) for k in self.scenario_name]
@@ -110,6 +118,24 @@ class CarlaDataset(Dataset):
 
     def __len__(self):
         return self.length
+
+    @property
+    def geometry(self):
+        """Device-side voxeliser / projector, created on first use: raw-mode worker processes never touch the GPU."""
+        if self._geometry is None:
+            self._geometry = FrameGeometry(self.config)
+        return self._geometry
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["hdf5_files"], d["_pid"], d["_geometry"] = {}, None, None      # handles and device state are per process
+        return d
+
+    def _files(self):
+        if self._pid != os.getpid():                    # forked / spawned worker: its own read-only handles
+            self.hdf5_files = self.load_dataset(self.mode)
+            self._pid = os.getpid()
+        return self.hdf5_files
 
     def load_dataset(self, mode="train"):
         if mode not in ("train", "test"):
@@ -184,8 +210,11 @@ class CarlaDataset(Dataset):
                 k -= n
                 continue
             fid = self.hdf5_id_dict[name][k].strip()
-            obj, lidar, image = self.getOneStepData(self.hdf5_files[name], fid)
+            obj, lidar, image = self.getOneStepData(self._files()[name], fid)
             boxes, nb = self.arangeLabelData(obj)
+            if self.raw:
+                return {"image": image.permute(2, 0, 1).contiguous(), "bboxes": boxes, "num_bboxes": nb,
+                        "lidar_points": lidar.contiguous(), "crt": None}
             voxel, pc, uv, cnt, ids = self.Voxelization_Projection(lidar)
             sample = {"image": image.permute(2, 0, 1), "bboxes": boxes, "num_bboxes": nb, "pointcloud_raw": pc,
                       "projected_loc_uv": uv, "num_points_raw": cnt, "pointcloud": voxel}
@@ -210,10 +239,10 @@ def synthetic_boxes(config, seed, n=8):
 class SyntheticDataset(Dataset):
     """Frames of the CarlaDataset contract from the deterministic generator of SURVEY.md 8(d)."""
 
-    def __init__(self, config, length=16, num_points=None, crt=None, image_hw=None):
-        self.config, self.length = config, length
+    def __init__(self, config, length=16, num_points=None, crt=None, image_hw=None, raw=False):
+        self.config, self.length, self.raw = config, length, bool(raw)
         self.num_points = num_points or config["max_num_pc"]
-        self.geometry = FrameGeometry(config, crt)
+        self._crt, self._geometry = crt, None
         self.image_hw = image_hw or (config["image_height"], config["image_width"])
         c = config
         self.lim6 = (c["lidar_x_min"], c["lidar_x_max"], c["lidar_y_min"], c["lidar_y_max"], c["lidar_z_min"], c["lidar_z_max"])
@@ -221,14 +250,27 @@ class SyntheticDataset(Dataset):
     def __len__(self):
         return self.length
 
-    def raw(self, idx):
+    @property
+    def geometry(self):
+        if self._geometry is None:
+            self._geometry = FrameGeometry(self.config, self._crt)
+        return self._geometry
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_geometry"] = None
+        return d
+
+    def raw_frame(self, idx):
         pts = torch.from_numpy(detfill.synthetic_points(self.num_points, self.lim6, 1234 + idx))
         img = torch.from_numpy(detfill.synthetic_image(self.image_hw[0], self.image_hw[1], 1234 + idx))
         boxes, nb = synthetic_boxes(self.config, 1234 + idx)
         return pts, img, boxes, nb
 
     def __getitem__(self, idx):
-        pts, img, boxes, nb = self.raw(idx)
+        pts, img, boxes, nb = self.raw_frame(idx)
+        if self.raw:
+            return {"image": img, "bboxes": boxes, "num_bboxes": nb, "lidar_points": pts, "crt": None}
         voxel, pc, uv, cnt, _ = self.geometry(pts)
         return {"image": img, "bboxes": boxes, "num_bboxes": nb, "pointcloud_raw": pc, "projected_loc_uv": uv,
                 "num_points_raw": cnt, "pointcloud": voxel}

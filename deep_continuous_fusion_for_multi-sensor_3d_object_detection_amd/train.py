@@ -65,10 +65,11 @@ class Train(nn.Module):
             dist.broadcast(self.model._bufflat, 0)
         self._side = None
 
-    def geometry_async(self, frame_geometry, points_list):
+    def geometry_async(self, frame_geometry, points_list, crts=None):
         """Per-frame geometry (voxelise, project, KNN of the fusion sites) on a side HIP stream, so that these
         small latency-bound kernels overlap the camera stream's convolutions on the compute stream.
-        Returns (x_lidar [B,Cz,L,W], geom) where geom carries the events the engine waits on."""
+        Returns (x_lidar [B,Cz,L,W], geom) where geom carries the events the engine waits on.
+        crts: optional per-frame [4,3] projection matrices (KITTI calibrates every frame)."""
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream()
@@ -78,8 +79,8 @@ class Train(nn.Module):
             x_lidar = torch.empty((len(points_list), Cz, L, W), dtype=torch.float32, device="cuda")
             # projection first: its valid-point counts go to the host (pinned, asynchronous) while the voxeliser and the KNN
             # still run; the engine sizes the per-point fusion tensors by them instead of max_num_pc (Plan._fusion_rows)
-            for pts in points_list:
-                pc, uv, cnt = frame_geometry.project(pts)
+            for b, pts in enumerate(points_list):
+                pc, uv, cnt = frame_geometry.project(pts, crt=None if crts is None else crts[b])
                 pcs.append(pc); uvs.append(uv); cnts.append(cnt)
             cnt_host = torch.empty(len(points_list), dtype=torch.int32).pin_memory()
             cnt_host.copy_(torch.cat(cnts, 0), non_blocking=True)
@@ -123,6 +124,12 @@ class Train(nn.Module):
         n = allreduce_grads(self.model.flat_grads)
         self.optimizer.step(1.0 / n)
 
+    def one_step_raw(self, frame_geometry, batch):
+        """One train step from a FrameLoader batch (raw points + image in HBM): geometry on the side stream, then one_step."""
+        batch.wait()
+        x_lidar, geom = self.geometry_async(frame_geometry, batch["points"], crts=batch.get("crt"))
+        self.one_step(x_lidar, batch["image"], batch["bboxes"], batch["num_bboxes"], geom=geom)
+
     # ------------------------------------------------------------------ checkpoint / resume (SURVEY.md 8(f) N4)
     def save_checkpoint(self, path, epoch=0):
         """Model state_dict (the reference's key names, train.py:79) plus what the reference never saved:
@@ -164,27 +171,43 @@ def init_distributed():
     return ws
 
 
+def make_dataset(config, mode="train"):
+    """train.py:58-65: CarlaDataset or KittiDataset by config["dataset_name"], in raw mode for the FrameLoader;
+    synthetic frames when the data directory does not exist."""
+    from .data_import_carla import CarlaDataset, SyntheticDataset
+    from .data_import_kitti import KittiDataset
+    if config.get("dataset_name") == "kitti":
+        ds = KittiDataset(config, mode=mode, raw=True)
+        if len(ds):
+            return ds
+    elif os.path.isdir(config["train_data_dir" if mode == "train" else "test_data_dir"]):
+        ds = CarlaDataset(config, mode=mode, raw=True)
+        if len(ds):
+            return ds
+    print("no %s frames under the configured data directory: synthetic frames" % mode)
+    return SyntheticDataset(config, length=64, raw=True)
+
+
 def main():
     import yaml
-    from .data_import_carla import CarlaDataset, SyntheticDataset
+    from .frame_loader import FrameLoader
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "config", "config_carla.yaml")) as f:
         config = yaml.safe_load(f)
     init_distributed()
-    if os.path.isdir(config["train_data_dir"]):
-        dataset = CarlaDataset(config)
-    else:
-        print("train_data_dir not found: training on synthetic frames")
-        dataset = SyntheticDataset(config, length=64)
+    dataset = make_dataset(config)
     sampler = torch.utils.data.distributed.DistributedSampler(dataset, shuffle=True) if world() > 1 else None
-    loader = torch.utils.data.DataLoader(dataset, batch_size=config["batch_size"], sampler=sampler, shuffle=sampler is None)
+    loader = FrameLoader(dataset, config["batch_size"], sampler=sampler, shuffle=True, num_workers=int(config.get("num_workers", 4)),
+                         drop_last=True)
     training = Train(config)
     os.makedirs("./saved_model", exist_ok=True)
     for epoch in range(config["num_epoch"]):
+        if sampler is not None:
+            sampler.set_epoch(epoch)
         if not dist.is_initialized() or dist.get_rank() == 0:
             torch.save(training.model.state_dict(), "./saved_model/" + config["saved_model_name"])
-        for batch_ndx, sample in enumerate(loader):
-            training.one_step(sample["pointcloud"].cuda(), sample["image"].cuda(), sample["bboxes"].cuda(), sample["num_bboxes"])
+        for batch_ndx, batch in enumerate(loader):
+            training.one_step_raw(dataset.geometry, batch)
             if batch_ndx % 100 == 0:
                 print("training at ", batch_ndx, "is processed, loss %.4f" % training.loss_value.item())
 
