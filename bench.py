@@ -108,7 +108,7 @@ def roofline_leg(trainer, pool, B, steps):
     name, ms, calls, work = table[0]                       # dominant kernel by GPU time
     if work > 0:
         achieved = work / (ms * 1e-3) / 1e12
-        peak = 2500.0 if "bf16" in name else 157.3           # dense MFMA peaks, MI355X_MICROARCH.md
+        peak = 5000.0 if "fp8" in name else (2500.0 if ("bf16" in name or "f16" in name) else 157.3)   # dense MFMA peaks, MI355X_MICROARCH.md
         roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": None}
     else:
@@ -310,7 +310,8 @@ def main():
                "config": {"workload": "%s: grid 32x704x800, %d pts/frame, %s RGB, %s image stream, K=%d fusion x4 sites, "
                                       "%s-mode BN%s, batch %d/GPU" % (
                                           {(100000, 3, "resnet18", 2, "bf16", "1242x375"): "cfg2", (120000, 5, "resnet50", 4, "f16", "1242x375"): "cfg4",
-                                           (300000, 3, "resnet18", 1, "bf16", "1920x1080"): "cfg5 shape at bf16 (fp8 convs not built)"}.get(
+                                           (300000, 3, "resnet18", 1, "fp8", "1920x1080"): "cfg5 (fp8 e4m3 forward convs with Cin>=128, bf16 storage and backward)",
+                                           (300000, 3, "resnet18", 1, "bf16", "1920x1080"): "cfg5 shape at bf16"}.get(
                                               (args.points, args.knn, args.image_stream, args.batch, args.dtype, args.image.lower()), "custom"),
                                           args.points, args.image.lower(), {"resnet18": "ResNet-18", "resnet34": "ResNet-34", "resnet50": "ResNet-50"}.get(args.image_stream, args.image_stream),
                                           args.knn, args.bn_mode, " (reference F4)" if args.bn_mode == "eval" else "", args.batch),

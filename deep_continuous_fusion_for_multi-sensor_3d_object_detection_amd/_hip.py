@@ -42,6 +42,10 @@ SIGNATURES = {
     "dcf_image_to_nhwc4": (c_int, [c_int, P, P, c_int, c_int, c_int, P]),
     "dcf_conv2d_fwd": (c_int, [c_int, P, P, P, P, P] + [c_int] * 12 + [P]),
     "dcf_conv2d_dgrad": (c_int, [c_int, P, P, P, P, P] + [c_int] * 11 + [P]),
+    "dcf_fp8_act_scale": (c_int, [c_float, P]),
+    "dcf_cast_fp8": (c_int, [c_int, P, P, P, P, c_i64, P]),
+    "dcf_weight_prep_fp8": (c_int, [P, P, c_int, c_int, P, P, P, P, P, c_float, P]),
+    "dcf_conv2d_fwd_fp8": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P] + [c_int] * 12 + [P]),
     "dcf_conv2d_wgrad_splits": (c_int, [c_int] * 8),
     "dcf_conv2d_wgrad": (c_int, [c_int, P, P, P, P, c_int] + [c_int] * 11 + [P]),
     "dcf_conv2d_wgrad_groupable": (c_int, [c_int] * 10),
@@ -83,6 +87,14 @@ class ConvParam(ctypes.Structure):
                 ("wfwd_off", c_i64), ("wdgrad_off", c_i64), ("shift_off", c_i64), ("slab_off", c_i64), ("gsum_off", c_i64),
                 ("cout", ctypes.c_int32), ("cin", ctypes.c_int32), ("taps", ctypes.c_int32), ("cout_pad", ctypes.c_int32),
                 ("nsplit", ctypes.c_int32), ("flags", ctypes.c_int32), ("pad0", ctypes.c_int32), ("pad1", ctypes.c_int32)]
+
+
+F8_AMAX_STRIDE = 80          # DCF_F8_AMAX_STRIDE: 64 partial maxima + the previous step's maximum (+ padding) per conv
+
+
+class F8Param(ctypes.Structure):
+    """struct dcf_f8_param of include/dcf_hip.h."""
+    _fields_ = [("w8_off", c_i64), ("wscale_off", c_i64)]
 
 
 class WgradItem(ctypes.Structure):

@@ -21,7 +21,7 @@ BN_EPS = 1e-5  # nn.BatchNorm2d(eps=1e-05), model.py:20
 
 
 class HipBackend(object):
-    def __init__(self, plan, params, grads, buffers, dtype):
+    def __init__(self, plan, params, grads, buffers, dtype, fp8_min_cin=0, fp8_min_blocks=512):
         if not params.is_cuda:
             raise H.DcfError("the HIP hot path needs CUDA/HIP tensors (got %s); there is no CPU fallback" % params.device)
         H.lib()  # fail loudly right here when the extension is missing
@@ -31,6 +31,13 @@ class HipBackend(object):
         self.es = 4 if self.dtype == H.F32 else 2
         self.dev = params.device
         self.bn_train = False          # batch statistics instead of running statistics (train-mode BatchNorm)
+        # fp8 forward path (0 = off): convolutions with cin >= fp8_min_cin (and cin % 64 == 0) read e4m3 images
+        self.fp8_min_cin = int(os.environ.get("DCF_FP8_MIN_CIN", fp8_min_cin))
+        # ... and enough output tiles that the launch is MFMA-bound rather than latency-bound: small launches stay on the
+        # 16-bit LDS-DMA kernel, which hides the global-load latency better than the fp8 kernel's register staging
+        self.fp8_min_blocks = int(os.environ.get("DCF_FP8_MIN_BLOCKS", fp8_min_blocks))
+        if self.fp8_min_cin and self.dtype == H.F32:
+            raise H.DcfError("the fp8 forward path keeps its activations in bf16 / fp16, not f32")
         self._bn_ws = {}
         self._layout(plan.layers)
         self._sig = None
@@ -56,6 +63,24 @@ class HipBackend(object):
         self.warena = torch.zeros(max(woff, 16), dtype=torch.uint8, device=self.dev)
         self.ssarena = torch.zeros(max(ssoff, 4), dtype=torch.float32, device=self.dev)
         self.gsum = None
+        # fp8 weight images, per-channel dequantisation factors and the activation maxima of the delayed scaling
+        w8off = wsoff = 0
+        f8 = (H.F8Param * len(layers))()
+        for i, L in enumerate(layers):
+            L.idx = i
+            ok = self.fp8_min_cin > 0 and L.kind != "stem" and L.cin % 64 == 0 and L.cin >= self.fp8_min_cin
+            L.w8_off, L.wscale_off = (w8off, wsoff) if ok else (-1, -1)
+            if ok:
+                w8off += (L.cout_pad * L.taps * L.cin + 255) // 256 * 256
+                wsoff += L.cout_pad
+            f8[i] = H.F8Param(L.w8_off, L.wscale_off)
+        self.has_fp8 = w8off > 0
+        if self.has_fp8:
+            self.w8arena = torch.zeros(w8off, dtype=torch.uint8, device=self.dev)
+            self.wsarena = torch.zeros(wsoff, dtype=torch.float32, device=self.dev)
+            self.amax = torch.zeros(len(layers) * H.F8_AMAX_STRIDE, dtype=torch.float32, device=self.dev)
+            self.f8table = torch.frombuffer(bytearray(bytes(f8)), dtype=torch.uint8).to(self.dev)
+            self.max_cout_pad = max(L.cout_pad for L in layers)
 
     def _upload_table(self, layers):
         tab = (H.ConvParam * len(layers))()
@@ -91,6 +116,9 @@ class HipBackend(object):
         """Once per step, before forward: fold BN into the compute-dtype weight images."""
         H.call("dcf_weight_prep", self.dtype, self.table, self.nconv, self.params, self.buffers, self.warena, self.ssarena,
                BN_EPS, H.stream_ptr())
+        if self.has_fp8 and not self.bn_train:
+            H.call("dcf_weight_prep_fp8", self.table, self.f8table, self.nconv, self.max_cout_pad, self.params, self.buffers,
+                   self.w8arena, self.wsarena, self.amax, BN_EPS, H.stream_ptr())
 
     def begin_backward(self, layers):
         sig = tuple(L.out_shape for L in layers)
@@ -119,7 +147,42 @@ class HipBackend(object):
                self.grads, BN_EPS, H.stream_ptr())
 
     # ------------------------------------------------------------------ convolutions
-    def conv_fwd(self, L, x, res, relu):
+    def _amax(self, L):
+        """(partial maxima [64], previous step's maximum [1]) of the tensor convolution L reads."""
+        a = self.amax[L.idx * H.F8_AMAX_STRIDE:]
+        return a[:64], a[64:65]
+
+    def _use_fp8(self, L, in_shape):
+        """Does convolution L take the fp8 kernel for an input of (B, H, W)?"""
+        if not self.has_fp8 or L.w8_off < 0 or self.bn_train:
+            return False
+        B, Hh, W = in_shape
+        M = B * ops.conv_out_size(Hh, L.kh, L.stride, L.pad) * ops.conv_out_size(W, L.kw, L.stride, L.pad)
+        return (M + 127) // 128 * (L.cout_pad // 64) >= self.fp8_min_blocks
+
+    def _conv_fwd_fp8(self, L, x, res, relu, nxt):
+        f8 = getattr(x, "_f8", None)
+        if f8 is None:                       # no producer wrote the image: cast here (and let x's other consumers share it)
+            cur, prev = self._amax(L)
+            f8 = (ops.cast_fp8(self.dtype, x, prev, cur), prev)
+            x._f8 = f8
+        want = nxt is not None and self._use_fp8(nxt, y_shape := (x.shape[0], ops.conv_out_size(x.shape[1], L.kh, L.stride, L.pad),
+                                                                    ops.conv_out_size(x.shape[2], L.kw, L.stride, L.pad)))
+        ncur, nprev = self._amax(nxt) if want else (None, None)
+        out = ops.conv2d_fwd_fp8(self.dtype, f8[0], self.w8arena[L.w8_off:], self.wsarena[L.wscale_off:], f8[1], self._shift(L), res,
+                                 L.kh, L.kw, L.stride, L.pad, relu, L.cout_pad, want_y8=want, y8amax=nprev, y8cur=ncur)
+        if want:
+            y, y8 = out
+            y._f8 = (y8, nprev)
+            return y
+        return out
+
+    def conv_fwd(self, L, x, res, relu, nxt=None):
+        """nxt: the convolution that will read the result (fp8 path: its e4m3 image is written by this epilogue)."""
+        if self._use_fp8(L, x.shape[:3]):
+            y = self._conv_fwd_fp8(L, x, res, relu, nxt)
+            L.out_shape = (y.shape[0], y.shape[1], y.shape[2])
+            return y
         if self.bn_train and L.bn is not None:
             raw = ops.conv2d_fwd(self.dtype, x, self._w(L), None, None, L.kh, L.kw, L.stride, L.pad, False, L.cout_pad)
             L.out_shape = (raw.shape[0], raw.shape[1], raw.shape[2])

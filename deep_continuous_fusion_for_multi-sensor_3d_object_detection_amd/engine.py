@@ -89,11 +89,13 @@ class Block(object):
     def __init__(self, conv1, conv2, down=None):
         self.conv1, self.conv2, self.down = conv1, conv2, down
         self.saved = None
+        self.next_conv = None          # conv1 of the block that consumes this block's output (same stage), if any
 
     def forward(self, K, x, save=True):
         r = K.conv_fwd(self.down, x, None, False) if self.down is not None else x
-        y1 = K.conv_fwd(self.conv1, x, None, True)
-        y = K.conv_fwd(self.conv2, y1, r, True)
+        y1 = K.conv_fwd(self.conv1, x, None, True, self.conv2)
+        y = K.conv_fwd(self.conv2, y1, r, True, self.next_conv)
+        x._f8 = y1._f8 = None          # fp8 images (fp8 path) are dead once their consumers ran
         self.saved = (x, y1, y) if save else None
         return y
 
@@ -130,12 +132,14 @@ class Bottleneck(object):
     def __init__(self, conv1, conv2, conv3, down=None):
         self.conv1, self.conv2, self.conv3, self.down = conv1, conv2, conv3, down
         self.saved = None
+        self.next_conv = None
 
     def forward(self, K, x, save=True):
         r = K.conv_fwd(self.down, x, None, False) if self.down is not None else x
-        y1 = K.conv_fwd(self.conv1, x, None, True)
-        y2 = K.conv_fwd(self.conv2, y1, None, True)
-        y = K.conv_fwd(self.conv3, y2, r, True)
+        y1 = K.conv_fwd(self.conv1, x, None, True, self.conv2)
+        y2 = K.conv_fwd(self.conv2, y1, None, True, self.conv3)
+        y = K.conv_fwd(self.conv3, y2, r, True, self.next_conv)
+        x._f8 = y1._f8 = y2._f8 = None
         self.saved = (x, y1, y2, y) if save else None
         return y
 
@@ -237,6 +241,8 @@ class Plan(object):
                 c2 = self._conv(p + ".conv2", cout, cout, (3, 3), 1, p + ".bn2")
                 dn = self._conv(p + ".down_conv", ci, cout, (1, 1), 2, p + ".down_bn", need_dgrad=not first) if ci != cout else None
                 blocks.append(Block(c1, c2, dn))
+            for a_, b_ in zip(blocks[:-1], blocks[1:]):
+                a_.next_conv = b_.conv1                # the consumer of a block's output inside its stage
             self.stages.append(blocks)
             cin = cout
         w = self.widths
@@ -278,6 +284,8 @@ class Plan(object):
                     if down:
                         dn = self._conv(q + ".downsample.0", ci, cout, (1, 1), s, q + ".downsample.1")
                     blocks.append(Bottleneck(c1, c2, c3, dn))
+            for a_, b_ in zip(blocks[:-1], blocks[1:]):
+                a_.next_conv = b_.conv1                # the consumer of a block's output inside its stage
             self.img_stages.append(blocks)
             cin = cout
         self.img_lat = [self._conv("image_fpn.lat%d" % (i + 1), widths[i] * exp, self.cf, (1, 1), 1) for i in range(4)]

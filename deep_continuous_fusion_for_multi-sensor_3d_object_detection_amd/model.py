@@ -158,7 +158,11 @@ class ObjectDetection_DCF(nn.Module):
         self.K = int(fu.get("K", 3))
         self.r_max = fu.get("r_max", None)
         self.cf = int(fu.get("image_channels", 64))
-        self.dtype = H.dtype_code(config.get("dtype", "f32"))
+        dt = config.get("dtype", "f32")
+        # "fp8": forward convolutions with Cin >= fp8_min_cin take e4m3 operands (csrc/conv_fp8.hip); storage, the
+        # backward and everything else are bf16 (BASELINE.json configs[4])
+        self.fp8 = dt in ("fp8", "f8", "e4m3")
+        self.dtype = H.dtype_code("bf16" if self.fp8 else dt)
         # "eval": running statistics always -- what train.py effectively does (test.py:37 puts the trained module in
         # eval mode before the first step); "train": batch statistics always; "module": follow
         # nn.Module.training exactly like nn.BatchNorm2d would.
@@ -296,7 +300,9 @@ class ObjectDetection_DCF(nn.Module):
                 raise H.DcfError("ObjectDetection_DCF runs on the HIP device only: move the module with .cuda() "
                                  "(no CPU fallback exists for the hot path)")
             from .backend_hip import HipBackend
-            self._backend = HipBackend(self._plan, self._flat, self._gradflat, self._bufflat, self.dtype)
+            self._backend = HipBackend(self._plan, self._flat, self._gradflat, self._bufflat, self.dtype,
+                                       fp8_min_cin=int(self.config.get("fp8_min_cin", 128)) if self.fp8 else 0,
+                                       fp8_min_blocks=int(self.config.get("fp8_min_blocks", 512)))
         return self._backend
 
     def fusion_geometry(self, points, uv, n_valid):

@@ -50,6 +50,32 @@ def conv2d_fwd(dtype, x, w, shift, res, kh, kw, stride, pad, relu, cout):
     return y
 
 
+def fp8_act_scale(amax):
+    """The activation scale rule of the fp8 path (largest power of two s with amax*s <= 224)."""
+    import ctypes
+    out = ctypes.c_float(0.0)
+    H.call("dcf_fp8_act_scale", float(amax), ctypes.addressof(out))
+    return float(out.value)
+
+
+def cast_fp8(dtype, x, amax_prev=None, amax_cur=None):
+    """uint8 image (OCP e4m3 bits) of x * scale(amax_prev); amax_cur (device float[64]) collects partial maxima of |x|."""
+    x8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    H.call("dcf_cast_fp8", dtype, x, x8, amax_prev, amax_cur, x.numel(), H.stream_ptr())
+    return x8
+
+
+def conv2d_fwd_fp8(out_dtype, x8, w8, wscale, xamax, shift, res, kh, kw, stride, pad, relu, cout, want_y8=False, y8amax=None, y8cur=None):
+    """want_y8: also return the fp8 image of y (scale from y8amax, partial maxima into y8cur[64]) -> (y, y8)."""
+    B, Hh, W, Cin = x8.shape
+    Ho, Wo = conv_out_size(Hh, kh, stride, pad), conv_out_size(W, kw, stride, pad)
+    y = torch.empty((B, Ho, Wo, cout), dtype=H.torch_dtype(out_dtype), device=x8.device)
+    y8 = torch.empty((B, Ho, Wo, cout), dtype=torch.uint8, device=x8.device) if want_y8 else None
+    H.call("dcf_conv2d_fwd_fp8", out_dtype, x8, w8, wscale, xamax, shift, res, y, y8, y8amax, y8cur, B, Hh, W, Cin, Ho, Wo, cout, kh, kw,
+           stride, pad, int(relu), H.stream_ptr())
+    return (y, y8) if want_y8 else y
+
+
 def conv2d_dgrad(dtype, gy, wt, res, in_shape, kh, kw, stride, pad, mask=None):
     B, Hh, W, Cin = in_shape
     _, Ho, Wo, Cout = gy.shape

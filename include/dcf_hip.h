@@ -178,6 +178,37 @@ int dcf_wgrad_finalize(const dcf_conv_param *table, int nconv, int max_cout, con
                        const float *ssarena, const float *slabs, const float *gsum, float *grads, float eps,
                        dcf_stream_t stream);
 
+/* ------------------------------------------------------------- fp8 forward convolutions (csrc/conv_fp8.hip)
+ * BASELINE.json configs[4] / SURVEY.md 8(d) cfg5 ("fp8 MFMA convs, fp32 accumulate, bf16 epilogue"); the reference has
+ * no counterpart (model.py runs fp32 nn.Conv2d, model.py:16-19).  Operands are OCP e4m3 on
+ * v_mfma_scale_f32_32x32x64_f8f6f4; weights carry one scale per output channel, activations one power-of-two scale per
+ * tensor derived on the device from the tensor's absolute maximum one step earlier (delayed scaling, no host sync):
+ *   y = act((sum_k q(x*sx) q(w*sw[co])) / (sx*sw[co]) + shift[co] + res)
+ * dcf_fp8_act_scale: the scale rule (largest power of two s with amax*s <= 224; 1 when amax is 0 / not finite). */
+int dcf_fp8_act_scale(float amax, float *scale);
+/* x8[i] = q(x[i] * dcf_fp8_act_scale(*amax_prev)) (amax_prev null: scale 1).  amax_cur (optional): 64 device floats
+ * holding partial maxima of |x| -- each workgroup raises one of them, so the tensor's maximum is the max over the 64
+ * (one hot address would serialise the atomics).  n multiple of 8. */
+int dcf_cast_fp8(int dtype, const void *x, void *x8, const float *amax_prev, float *amax_cur, int64_t n, dcf_stream_t stream);
+/* Per-conv fp8 weight images: w8 [cout_pad][taps][cin] = q(bn_scale*W * 448/amax_co) at byte offset w8_off of w8arena,
+ * dequantisation factors amax_co/448 at element offset wscale_off of wsarena (w8_off < 0: conv not on the fp8 path).
+ * Also rolls each conv's activation maxima: amax holds DCF_F8_AMAX_STRIDE floats per conv, [0..63] the partial maxima of
+ * the current step and [64] the previous step's maximum (the scale source): prev <- max(cur[0..63]), cur <- 0. */
+#define DCF_F8_AMAX_STRIDE 80
+typedef struct dcf_f8_param {
+    int64_t w8_off;
+    int64_t wscale_off;
+} dcf_f8_param;
+int dcf_weight_prep_fp8(const dcf_conv_param *table, const dcf_f8_param *f8table, int nconv, int max_cout_pad, const float *params,
+                        const float *buffers, void *w8arena, float *wsarena, float *amax, float eps, dcf_stream_t stream);
+/* Forward convolution over fp8 images: x8 [B][H][W][Cin], w8 [Cout][kh][kw][Cin], wscale [Cout], xamax = the device
+ * scalar dcf_cast_fp8 derived x8's scale from (null: 1); shift / res / relu as dcf_conv2d_fwd; y, res in out_dtype.
+ * Optional second output for the convolution that consumes y: y8 = dcf_cast_fp8(y) with the scale of *y8amax, partial
+ * maxima of |y| raised in y8cur[64] (either may be null).  Cin multiple of 64, Cout multiple of 32. */
+int dcf_conv2d_fwd_fp8(int out_dtype, const void *x8, const void *w8, const float *wscale, const float *xamax, const float *shift,
+                       const void *res, void *y, void *y8, const float *y8amax, float *y8cur, int B, int H, int W, int Cin,
+                       int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int relu, dcf_stream_t stream);
+
 /* ------------------------------------------------------------- elementwise
  * g = gy * (y > 0) in place on gy (ReLU backward, model.py:21,25) and per-channel sums
  * gsum[c] += sum_p g[p][c] (the BN-beta gradient).  gsum fp32 [C], pre-zeroed by caller. */

@@ -258,3 +258,67 @@ def test_cfg4_shape_model_step_fp16():
     assert torch.isfinite(net.flat_params).all()
     # (with the deterministic fill ~55 % of the camera trunk's channels are dead ReLUs -- in the fp32 CPU statement too)
     assert float((net.flat_params != before).float().mean()) > 0.4
+
+
+def test_cfg5_fp8_forward_path_model_step():
+    """BASELINE configs[4] in miniature: dtype "fp8" = e4m3 operands in the forward convolutions with Cin >= fp8_min_cin
+    (camera trunk, LiDAR stages, FPN, fusion fc2), bf16 storage and backward.  The fused prediction stays within e4m3
+    noise of the bf16 model and of the CPU statement, the delayed activation scales fill in after the first step, and a
+    train step through the path updates the parameters."""
+    cfg, pts, img, crt = setup("fp8", K=3)
+    cfg["fp8_min_cin"], cfg["fp8_min_blocks"] = 64, 1          # every eligible layer, whatever its size
+    cfg["lidar_module"].update(out_feature1=32, out_feature2=64, out_feature3=128, out_feature4=192, out_feature5=256,
+                               num_res_block1=1, num_res_block2=1, num_res_block3=2, num_res_block4=1, num_res_block5=1)
+    det = pkg("detfill")
+    geo = pkg("data_import_carla").FrameGeometry(cfg, crt)
+    vox, pcs, uvs, cnts = [], [], [], []
+    for p in pts:
+        v, pc, uv, cnt, _ = geo(torch.from_numpy(p))
+        vox.append(v); pcs.append(pc); uvs.append(uv); cnts.append(cnt)
+    args = (torch.stack(vox), img.cuda())
+    kw = dict(points=torch.stack(pcs), uv=torch.stack(uvs), n_valid=torch.cat(cnts))
+    nets = {}
+    for dt in ("fp8", "bf16"):
+        c = copy.deepcopy(cfg)
+        c["dtype"] = dt
+        nets[dt] = pkg("model").ObjectDetection_DCF(c)
+        det.fill_state_dict(nets[dt])
+        nets[dt] = nets[dt].cuda()
+    with torch.no_grad():
+        p16 = nets["bf16"](*args, **kw).cpu()
+        p8_first = nets["fp8"](*args, **kw).cpu()          # step 0: activation scales are 1
+        p8 = nets["fp8"](*args, **kw).cpu()                # step 1: scales from step 0's maxima
+    K = nets["fp8"]._backend
+    f8_layers = [L for L in K.plan.layers if L.w8_off >= 0]
+    assert K.has_fp8 and len(f8_layers) >= 20 and any(L.name.startswith("lidar") for L in f8_layers)
+    used = [float(K._amax(L)[1].item()) for L in f8_layers]
+    # (a conv that shares its input's image with another consumer -- conv1 next to a down-sampling shortcut -- uses
+    # that consumer's slot and leaves its own at 0)
+    assert sum(1 for u in used if u > 0) >= 0.7 * len(used), used
+    x, pc, uv, ns = oracle_inputs(cfg, pts, crt)
+    sd = model_ref.make_state_dict(full_shapes(cfg))
+    g = geometry_ref.grid_constants(cfg)
+    ref = model_ref.forward(sd, cfg, x, img, pc, uv, ns, "eval", fusion={"K": 3, "aff": g["aff"], "rmax": None})
+    e16 = float((p16 - ref).abs().max() / ref.abs().max())
+    for p in (p8_first, p8):
+        assert torch.isfinite(p).all()
+        e8 = float((p - ref).abs().max() / ref.abs().max())
+        d = float((p - p16).norm() / p16.norm())
+        assert e8 < max(0.12, 4 * e16) and d < 0.06, (e8, e16, d)
+    assert not torch.equal(p8, p16)
+    # train step through the fp8 forward
+    net = nets["fp8"]
+    before = net.flat_params.clone()
+    opt = pkg("train").FlatAdam(net, 1e-4, (0.9, 0.999))
+    pred = net(*args, **kw)
+    R = torch.from_numpy(det.uniform(tuple(pred.shape), 779, -1.0, 1.0)).cuda()
+    (pred * R).sum().backward()
+    g8 = net._gradflat.clone()
+    opt.step()
+    assert torch.isfinite(net.flat_params).all() and float((net.flat_params != before).float().mean()) > 0.4
+    # straight-through backward: gradients close to the bf16 model's
+    pred16 = nets["bf16"](*args, **kw)
+    (pred16 * R).sum().backward()
+    g16 = nets["bf16"]._gradflat
+    cos = float((g8 * g16).sum() / (g8.norm() * g16.norm()))
+    assert cos > 0.9, cos
