@@ -329,12 +329,17 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
     }
 
     DCF_STAMP(3);
-    // epilogue: lane (pixel r, half h) holds channels 8q+4h+{0..3} of each 32-channel tile.
+    // epilogue: the MFMA leaves lane (pixel r, half h) with channels 8q+4h+{0..3} of each 32-channel tile.
     //   v = acc + shift + res ; relu ; (dgrad only) v *= (mask > 0), i.e. the ReLU backward of the
     //   layer that PRODUCED this tensor (its dbeta sums come out of the wgrad kernel).
     T *y = reinterpret_cast<T *>(a.y);
     const T *res = reinterpret_cast<const T *>(a.res);
     const T *mask = reinterpret_cast<const T *>(a.mask);
+    // after acc_rows8 lane (pixel r, half h) holds channels 16p+8h+{0..7} of each 32-channel tile in registers 8p..8p+7
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc_rows8(acc[i][j]);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = out_pixel(m0 + (wm * TM + j) * 32 + r);
@@ -342,25 +347,35 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = n0 + (wn * TN + i) * 32 + 8 * q + 4 * h;
-                float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            for (int p = 0; p < 2; ++p) {
+                const int c = n0 + (wn * TN + i) * 32 + 16 * p + 8 * h;
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = acc[i][j][8 * p + k];
                 if (a.shift) {
-                    const float4 s = *reinterpret_cast<const float4 *>(a.shift + c);
-                    v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+                    float s[8];
+                    ld8(a.shift + c, s);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += s[k];
                 }
                 const size_t o = (size_t)m * a.Cn + c;
                 if (res) {
-                    const float4 rr = ld4(res + o);
-                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                    float rr[8];
+                    ld8(res + o, rr);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += rr[k];
                 }
-                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (a.relu) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+                }
                 if (mask) {
-                    const float4 mm = ld4(mask + o);
-                    v.x = mm.x > 0.f ? v.x : 0.f; v.y = mm.y > 0.f ? v.y : 0.f;
-                    v.z = mm.z > 0.f ? v.z : 0.f; v.w = mm.w > 0.f ? v.w : 0.f;
+                    float mm[8];
+                    ld8(mask + o, mm);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = mm[k] > 0.f ? v[k] : 0.f;
                 }
-                st4(y + o, v);
+                st8(y + o, v);
             }
         }
     }
@@ -551,6 +566,11 @@ __global__ void __launch_bounds__(256) k_conv_igemm_dma(ConvArgs a)
     T *y = reinterpret_cast<T *>(a.y);
     const T *res = reinterpret_cast<const T *>(a.res);
     const T *mask = reinterpret_cast<const T *>(a.mask);
+    // after acc_rows8 lane (pixel r, half h) holds channels 16p+8h+{0..7} of each 32-channel tile in registers 8p..8p+7
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc_rows8(acc[i][j]);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = out_pixel(m0 + (wm * TM + j) * 32 + r);
@@ -558,25 +578,35 @@ __global__ void __launch_bounds__(256) k_conv_igemm_dma(ConvArgs a)
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = n0 + (wn * TN + i) * 32 + 8 * q + 4 * h;
-                float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            for (int p = 0; p < 2; ++p) {
+                const int c = n0 + (wn * TN + i) * 32 + 16 * p + 8 * h;
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = acc[i][j][8 * p + k];
                 if (a.shift) {
-                    const float4 s = *reinterpret_cast<const float4 *>(a.shift + c);
-                    v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+                    float s[8];
+                    ld8(a.shift + c, s);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += s[k];
                 }
                 const size_t o = (size_t)m * a.Cn + c;
                 if (res) {
-                    const float4 rr = ld4(res + o);
-                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                    float rr[8];
+                    ld8(res + o, rr);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += rr[k];
                 }
-                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (a.relu) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+                }
                 if (mask) {
-                    const float4 mm = ld4(mask + o);
-                    v.x = mm.x > 0.f ? v.x : 0.f; v.y = mm.y > 0.f ? v.y : 0.f;
-                    v.z = mm.z > 0.f ? v.z : 0.f; v.w = mm.w > 0.f ? v.w : 0.f;
+                    float mm[8];
+                    ld8(mask + o, mm);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = mm[k] > 0.f ? v[k] : 0.f;
                 }
-                st4(y + o, v);
+                st8(y + o, v);
             }
         }
     }

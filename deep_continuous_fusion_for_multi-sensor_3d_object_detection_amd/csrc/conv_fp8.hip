@@ -290,7 +290,12 @@ __global__ void __launch_bounds__(256) k_conv_f8(Conv8Args a)
         __syncthreads();
     }
 
-    // epilogue: lane (pixel r, half h) holds channels 8q+4h+{0..3} of each 32-channel tile
+    // epilogue: the MFMA leaves lane (pixel r, half h) with channels 8q+4h+{0..3} of each 32-channel tile; after acc_rows8
+    // it holds channels 16p+8h+{0..7} in registers 8p..8p+7 (16-byte stores, 8-byte fp8 stores)
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc_rows8(acc[i][j]);
     const float inv_sx = 1.f / f8_act_scale(a.xamax ? *a.xamax : 0.f);
     const float sy = a.y8 ? f8_act_scale(a.y8amax ? *a.y8amax : 0.f) : 0.f;
     float am = 0.f;
@@ -303,27 +308,39 @@ __global__ void __launch_bounds__(256) k_conv_f8(Conv8Args a)
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = n0 + (wn * TN + i) * 32 + 8 * q + 4 * h;
-                const float4 ws = *reinterpret_cast<const float4 *>(a.wscale + c);
-                float4 v = make_float4(acc[i][j][4 * q] * (ws.x * inv_sx), acc[i][j][4 * q + 1] * (ws.y * inv_sx),
-                                       acc[i][j][4 * q + 2] * (ws.z * inv_sx), acc[i][j][4 * q + 3] * (ws.w * inv_sx));
+            for (int p = 0; p < 2; ++p) {
+                const int c = n0 + (wn * TN + i) * 32 + 16 * p + 8 * h;
+                float v[8], ws[8];
+                ld8(a.wscale + c, ws);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = acc[i][j][8 * p + k] * (ws[k] * inv_sx);
                 if (a.shift) {
-                    const float4 s = *reinterpret_cast<const float4 *>(a.shift + c);
-                    v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+                    float s[8];
+                    ld8(a.shift + c, s);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += s[k];
                 }
                 const size_t o = (size_t)m * a.Cn + c;
                 if (res) {
-                    const float4 rr = ld4(res + o);
-                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                    float rr[8];
+                    ld8(res + o, rr);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += rr[k];
                 }
-                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                st4(y + o, v);
+                if (a.relu) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+                }
+                st8(y + o, v);
                 if (a.y8) {
                     // the image is made from the value as stored (rounded to TO): identical to dcf_cast_fp8 of y
-                    const float4 t = make_float4(stored(v.x, y), stored(v.y, y), stored(v.z, y), stored(v.w, y));
-                    am = fmaxf(am, fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w))));
-                    *reinterpret_cast<unsigned *>(a.y8 + o) = pack4_f8(t.x * sy, t.y * sy, t.z * sy, t.w * sy);
+                    float t[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { t[k] = stored(v[k], y); am = fmaxf(am, fabsf(t[k])); }
+                    uint2 q8;
+                    q8.x = pack4_f8(t[0] * sy, t[1] * sy, t[2] * sy, t[3] * sy);
+                    q8.y = pack4_f8(t[4] * sy, t[5] * sy, t[6] * sy, t[7] * sy);
+                    *reinterpret_cast<uint2 *>(a.y8 + o) = q8;
                 }
             }
         }

@@ -131,6 +131,59 @@ __device__ __forceinline__ void st4(f16_t *p, float4 v)
     *reinterpret_cast<h16x4 *>(p) = h;
 }
 
+// load/store 8 consecutive channels (16-byte accesses for the 16-bit types)
+__device__ __forceinline__ void ld8(const float *p, float (&v)[8])
+{
+    const float4 a = ld4(p), b = ld4(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void st8(float *p, const float (&v)[8])
+{
+    st4(p, make_float4(v[0], v[1], v[2], v[3]));
+    st4(p + 4, make_float4(v[4], v[5], v[6], v[7]));
+}
+__device__ __forceinline__ void ld8(const bf16_t *p, float (&v)[8])
+{
+    const uint4 u = *reinterpret_cast<const uint4 *>(p);
+    unpack2<bf16_t>(u.x, v[0], v[1]); unpack2<bf16_t>(u.y, v[2], v[3]); unpack2<bf16_t>(u.z, v[4], v[5]); unpack2<bf16_t>(u.w, v[6], v[7]);
+}
+__device__ __forceinline__ void st8(bf16_t *p, const float (&v)[8])
+{
+    uint4 u;
+    u.x = pack2bf(v[0], v[1]); u.y = pack2bf(v[2], v[3]); u.z = pack2bf(v[4], v[5]); u.w = pack2bf(v[6], v[7]);
+    *reinterpret_cast<uint4 *>(p) = u;
+}
+__device__ __forceinline__ void ld8(const f16_t *p, float (&v)[8])
+{
+    const uint4 u = *reinterpret_cast<const uint4 *>(p);
+    unpack2<f16_t>(u.x, v[0], v[1]); unpack2<f16_t>(u.y, v[2], v[3]); unpack2<f16_t>(u.z, v[4], v[5]); unpack2<f16_t>(u.w, v[6], v[7]);
+}
+__device__ __forceinline__ void st8(f16_t *p, const float (&v)[8])
+{
+    typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+    h16x8 h;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) h[k] = (_Float16)v[k];
+    *reinterpret_cast<h16x8 *>(p) = h;
+}
+
+// MFMA 32x32 accumulator (lane = column, half h; register 4q+k = row 8q+4h+k): the two lane halves trade registers
+// (v_permlane32_swap) so that afterwards registers 8p..8p+7 of a lane are the 8 CONSECUTIVE rows 16p+8h+{0..7}.
+// The epilogues then move 8 channels per access instead of 4: half the memory instructions, half the partial lines.
+typedef float dcf_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void acc_rows8(dcf_f32x16 &c)
+{
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // upper lanes of the first operand (rows 16p+4+k) <-> lower lanes of the second (rows 16p+8+k)
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[8 * p + k]), __float_as_uint(c[8 * p + 4 + k]), false, false);
+            c[8 * p + k] = __uint_as_float(r[0]);
+            c[8 * p + 4 + k] = __uint_as_float(r[1]);
+        }
+}
+
 // wave64 reductions
 __device__ __forceinline__ float wave_sum(float v)
 {
