@@ -73,6 +73,24 @@ class FramePool(object):
         return ids
 
 
+class HostFrames(torch.utils.data.Dataset):
+    """The pool's frames as HOST tensors in the datasets' raw-mode contract (--from-host: the step then includes pinned
+    staging + the PCIe copies of frame_loader.FrameLoader; not the headline number)."""
+    raw = True
+
+    def __init__(self, pool, steps, B):
+        self.pts = [p.cpu() for p in pool.pts]
+        self.img = [i.cpu() for i in pool.img]
+        self.boxes, self.nb, self.n, self.length = pool.boxes, pool.nb, pool.n, steps * B
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        k = i % self.n
+        return {"image": self.img[k], "bboxes": self.boxes[k], "num_bboxes": self.nb[k], "lidar_points": self.pts[k], "crt": None}
+
+
 def train_step(trainer, pool, ids):
     """Whole hot path for one batch.  Geometry + KNN run on the trainer's side stream (overlapping the camera
     stream on the compute stream); everything else is enqueued on torch's current stream."""
@@ -245,6 +263,8 @@ def main():
     ap.add_argument("--bn-mode", default="eval", help="eval = what the reference's train.py really does (F4); train = batch statistics")
     ap.add_argument("--graphs", action="store_true", help="replay captured forward/backward HIP graphs instead of eager launches "
                     "(measured equal on this workload: the step is kernel-bound, not launch-bound)")
+    ap.add_argument("--from-host", action="store_true", help="feed the timed steps from host memory through FrameLoader "
+                    "(pinned staging + H2D on a copy stream): the PCIe-inclusive rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -282,9 +302,17 @@ def main():
         train_step(trainer, pool, pool.batch(s, args.batch))
     barrier()
     log("warm-up done")
+    loader = None
+    if args.from_host:
+        loader = iter(pkg("frame_loader").FrameLoader(HostFrames(pool, args.steps + 2, args.batch), args.batch))
+        trainer.one_step_raw(pool.geometry, next(loader))          # staging buffers allocated outside the timed region
+        barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        train_step(trainer, pool, pool.batch(args.warmup + s, args.batch))
+        if loader is not None:
+            trainer.one_step_raw(pool.geometry, next(loader))
+        else:
+            train_step(trainer, pool, pool.batch(args.warmup + s, args.batch))
     barrier()
     dt = time.perf_counter() - t0
     if ws > 1:
@@ -315,7 +343,8 @@ def main():
                                               (args.points, args.knn, args.image_stream, args.batch, args.dtype, args.image.lower()), "custom"),
                                           args.points, args.image.lower(), {"resnet18": "ResNet-18", "resnet34": "ResNet-34", "resnet50": "ResNet-50"}.get(args.image_stream, args.image_stream),
                                           args.knn, args.bn_mode, " (reference F4)" if args.bn_mode == "eval" else "", args.batch),
-                          "global_batch": args.batch * ws, "parallelism": "dp%d" % ws, "final_loss": round(loss, 4)},
+                          "global_batch": args.batch * ws, "parallelism": "dp%d" % ws, "final_loss": round(loss, 4),
+                          "input": "host memory through FrameLoader (PCIe-inclusive)" if args.from_host else "resident in HBM"},
                "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown}
         print(json.dumps(out))
     if ws > 1:

@@ -10,7 +10,7 @@ the step of batch i.
     loader = FrameLoader(dataset, batch_size, sampler=..., num_workers=4)
     for batch in loader:        # batch["points"]: list of [n_i,3] f32 device tensors, batch["image"]: [B,3,H,W] u8
         batch.wait()            # compute stream waits on the copy stream's event
-        x_lidar, geom = trainer.geometry_async(dataset.geometry, batch["points"], crts=batch["crt"])
+        x_lidar, geom = trainer.geometry_async(dataset.geometry, batch["points"], crts=batch["crt"], wait_event=batch.event)
 
 With device=None (no GPU: unit tests, host-side tooling) the same batches come back as host tensors.
 """
@@ -19,9 +19,10 @@ from torch.utils.data import DataLoader
 
 
 def collate_raw(samples):
-    """Raw samples -> one batch dict; point lists stay ragged (a list), everything else is stacked."""
+    """Raw samples -> one batch dict; point lists and images stay lists (they are packed straight into the pinned
+    staging set), the small label tensors are stacked."""
     out = {"points": [s["lidar_points"] for s in samples],
-           "image": torch.stack([s["image"] for s in samples], 0),
+           "image": [s["image"] for s in samples],
            "bboxes": torch.stack([s["bboxes"] for s in samples], 0),
            "num_bboxes": torch.tensor([int(s["num_bboxes"]) for s in samples]),
            "crt": [s["crt"] for s in samples] if samples and samples[0].get("crt") is not None else None}
@@ -29,23 +30,30 @@ def collate_raw(samples):
 
 
 class Batch(dict):
-    """dict of tensors + the copy-stream event guarding them."""
+    """dict of tensors + the copy-stream event guarding them.  The device tensors are views of the loader's staging set:
+    they stay valid until the loader has handed out the batch after the next one."""
     event = None
 
     def wait(self, stream=None):
+        """Make `stream` (default: the current one) wait for the H2D copies of this batch."""
         if self.event is not None:
             (stream or torch.cuda.current_stream()).wait_event(self.event)
-            for t in list(self["points"]) + [self["image"]]:
-                t.record_stream(stream or torch.cuda.current_stream())
         return self
 
 
 class _Staging(object):
-    """One set of pinned host buffers: points of a whole batch back to back, and the image batch."""
+    """One staging set: pinned host buffers (points of a whole batch back to back, the image batch) and their device
+    twins -- allocated once, so a step allocates nothing and frees nothing on the copy stream."""
 
-    def __init__(self, max_points, batch, image_shape):
+    def __init__(self, max_points, batch, image_shape, device):
         self.points = torch.empty((batch * max_points, 3), dtype=torch.float32).pin_memory()
         self.image = torch.empty((batch,) + tuple(image_shape), dtype=torch.uint8).pin_memory()
+        # numpy views for the packing: a plain single-threaded memcpy.  (torch's CPU copy_ of a megabyte-sized tensor opens
+        # an OpenMP region whose workers then spin on every core and slow the thread that enqueues the step: measured
+        # 35 ms instead of 7 ms per step.)
+        self.points_np, self.image_np = self.points.numpy(), self.image.numpy()
+        self.dev_points = torch.empty((batch * max_points, 3), dtype=torch.float32, device=device)
+        self.dev_image = torch.empty((batch,) + tuple(image_shape), dtype=torch.uint8, device=device)
         self.done = None                       # event: the H2D copies out of this set have finished
 
 
@@ -64,7 +72,7 @@ class FrameLoader(object):
             kw.update(prefetch_factor=prefetch_factor, persistent_workers=True)
         self.loader = DataLoader(dataset, **kw)
         self.max_points = max_points
-        self._sets, self._copy = None, None
+        self._sets, self._copy, self._cap = None, None, 0
 
     def __len__(self):
         return len(self.loader)
@@ -73,11 +81,11 @@ class FrameLoader(object):
         """Pack one host batch into staging set `slot` and enqueue its H2D copies on the copy stream."""
         B = len(host["points"])
         need = max(int(p.shape[0]) for p in host["points"])
-        if self._sets is None or self._sets[0].points.shape[0] < self.batch_size * need or \
-                tuple(self._sets[0].image.shape[1:]) != tuple(host["image"].shape[1:]):
+        ishape = tuple(host["image"][0].shape)
+        if self._sets is None or self._cap < need or tuple(self._sets[0].image.shape[1:]) != ishape:
             cap = max(need, int(self.max_points or 0))
             cap = (cap + 4095) // 4096 * 4096
-            self._sets = [_Staging(cap, self.batch_size, host["image"].shape[1:]) for _ in range(2)]
+            self._sets = [_Staging(cap, self.batch_size, ishape, self.device) for _ in range(2)]
             self._cap = cap
         st = self._sets[slot]
         if st.done is not None:
@@ -87,13 +95,21 @@ class FrameLoader(object):
         pts = []
         for b, p in enumerate(host["points"]):
             n = int(p.shape[0])
-            st.points[b * self._cap:b * self._cap + n].copy_(p)
+            st.points_np[b * self._cap:b * self._cap + n] = p.numpy()
             pts.append((b * self._cap, n))
-        st.image[:B].copy_(host["image"])
+        for b, im in enumerate(host["image"]):
+            st.image_np[b] = im.numpy()
         out = Batch(bboxes=host["bboxes"], num_bboxes=host["num_bboxes"], crt=host["crt"])
+        # the device twins were last read by the step of the batch two back: everything enqueued so far (that step
+        # included; the step of the previous batch is not enqueued yet) must be through before they are overwritten
+        self._copy.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self._copy):
-            out["points"] = [st.points[o:o + n].to(self.device, non_blocking=True) for o, n in pts]
-            out["image"] = st.image[:B].to(self.device, non_blocking=True)
+            out["points"] = []
+            for o, n in pts:
+                st.dev_points[o:o + n].copy_(st.points[o:o + n], non_blocking=True)
+                out["points"].append(st.dev_points[o:o + n])
+            st.dev_image[:B].copy_(st.image[:B], non_blocking=True)
+            out["image"] = st.dev_image[:B]
             ev = torch.cuda.Event()
             ev.record()
         st.done = ev
@@ -103,6 +119,7 @@ class FrameLoader(object):
     def __iter__(self):
         if self.device is None:
             for host in self.loader:
+                host["image"] = torch.stack(host["image"], 0)
                 yield Batch(host)
             return
         # one batch of look-ahead: batch i+1 is staged and in flight while the caller works on batch i

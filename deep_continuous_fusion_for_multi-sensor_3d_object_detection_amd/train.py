@@ -65,14 +65,17 @@ class Train(nn.Module):
             dist.broadcast(self.model._bufflat, 0)
         self._side = None
 
-    def geometry_async(self, frame_geometry, points_list, crts=None):
+    def geometry_async(self, frame_geometry, points_list, crts=None, wait_event=None):
         """Per-frame geometry (voxelise, project, KNN of the fusion sites) on a side HIP stream, so that these
         small latency-bound kernels overlap the camera stream's convolutions on the compute stream.
         Returns (x_lidar [B,Cz,L,W], geom) where geom carries the events the engine waits on.
-        crts: optional per-frame [4,3] projection matrices (KITTI calibrates every frame)."""
+        crts: optional per-frame [4,3] projection matrices (KITTI calibrates every frame).
+        wait_event: event the side stream has to wait for before it reads the points (FrameLoader's H2D copies)."""
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream()
+        if wait_event is not None:
+            self._side.wait_event(wait_event)
         with torch.cuda.stream(self._side):
             pcs, uvs, cnts = [], [], []
             Cz, L, W = frame_geometry.grid.dims
@@ -127,7 +130,7 @@ class Train(nn.Module):
     def one_step_raw(self, frame_geometry, batch):
         """One train step from a FrameLoader batch (raw points + image in HBM): geometry on the side stream, then one_step."""
         batch.wait()
-        x_lidar, geom = self.geometry_async(frame_geometry, batch["points"], crts=batch.get("crt"))
+        x_lidar, geom = self.geometry_async(frame_geometry, batch["points"], crts=batch.get("crt"), wait_event=batch.event)
         self.one_step(x_lidar, batch["image"], batch["bboxes"], batch["num_bboxes"], geom=geom)
 
     # ------------------------------------------------------------------ checkpoint / resume (SURVEY.md 8(f) N4)

@@ -214,7 +214,7 @@ def test_frame_loader_feeds_train_steps(tmp_path):
             assert n == n_ref and n > 0
             assert np.array_equal(pc[:n].cpu().numpy(), pc_ref[:n])
             assert np.allclose(uv[:n].cpu().numpy(), uv_ref[:n], rtol=0, atol=2e-3)
-        x_lidar, geom = trainer.geometry_async(ds.geometry, batch["points"], crts=batch["crt"])
+        x_lidar, geom = trainer.geometry_async(ds.geometry, batch["points"], crts=batch["crt"], wait_event=batch.event)
         torch.cuda.synchronize()
         for b, p in enumerate(batch["points"]):
             assert torch.equal(x_lidar[b], ds.geometry.voxelize(p))
