@@ -62,6 +62,7 @@ class HipBackend(object):
             L.nsplit, L.slab_off = 0, 0
         self.warena = torch.zeros(max(woff, 16), dtype=torch.uint8, device=self.dev)
         self.ssarena = torch.zeros(max(ssoff, 4), dtype=torch.float32, device=self.dev)
+        self._wbase, self._ssbase = self.warena.data_ptr(), self.ssarena.data_ptr()
         self.gsum = None
         # fp8 weight images, per-channel dequantisation factors and the activation maxima of the delayed scaling
         w8off = wsoff = 0
@@ -96,8 +97,8 @@ class HipBackend(object):
         self.max_cout = max(L.cout for L in layers)
 
     def _w(self, L, dgrad=False):
-        off = L.wdgrad_off if dgrad else L.wfwd_off
-        return self.warena[off:]
+        # raw device address (the arenas never move): a tensor slice per launch costs the host ~3 us, x160 per step
+        return self._wbase + (L.wdgrad_off if dgrad else L.wfwd_off)
 
     def set_bn_mode(self, train):
         train = bool(train)
@@ -109,7 +110,7 @@ class HipBackend(object):
     def _shift(self, L):
         if L.bn is None or self.bn_train:
             return None
-        return self.ssarena[L.shift_off + L.cout_pad:]
+        return self._ssbase + 4 * (L.shift_off + L.cout_pad)
 
     # ------------------------------------------------------------------ step phases
     def prepare(self):
@@ -136,6 +137,7 @@ class HipBackend(object):
                 goff += 4 * L.nsplit * L.cout_pad
             self.slabs = torch.empty(max(off, 4), dtype=torch.float32, device=self.dev)
             self.gsum = torch.zeros(max(goff, 4), dtype=torch.float32, device=self.dev)
+            self._gsbase, self._slbase = self.gsum.data_ptr(), self.slabs.data_ptr()
             self._upload_table(layers)
             self._sig = sig
         self.grads.zero_()
@@ -221,7 +223,7 @@ class HipBackend(object):
         return ops.conv2d_dgrad(self.dtype, gy, self._w(L, True), res, in_shape, L.kh, L.kw, L.stride, L.pad, mask)
 
     def _gs(self, L):
-        return self.gsum[L.gsum_off:] if (L.bn is not None and not self.bn_train) else None
+        return self._gsbase + 4 * L.gsum_off if (L.bn is not None and not self.bn_train) else None
 
     def _flush_wgrads(self):
         """Issue the collected weight gradients together (dcf_conv2d_wgrad_group: one launch per <= 32 layers of a kernel class)."""
@@ -231,9 +233,7 @@ class HipBackend(object):
         items = (H.WgradItem * len(q))()
         for i, (L, x, gy) in enumerate(q):
             B, Hh, W, Cin = x.shape
-            gs = self._gs(L)
-            items[i] = H.WgradItem(self.dtype, L.nsplit, x.data_ptr(), gy.data_ptr(), self.slabs[L.slab_off:].data_ptr(),
-                                   gs.data_ptr() if gs is not None else None, B, Hh, W, Cin, L.cout_pad, L.kh, L.kw, L.stride, L.pad, 0)
+            items[i] = H.WgradItem(self.dtype, L.nsplit, x.data_ptr(), gy.data_ptr(), self._slbase + 4 * L.slab_off, self._gs(L), B, Hh, W, Cin, L.cout_pad, L.kh, L.kw, L.stride, L.pad, 0)
         H.call("dcf_conv2d_wgrad_group", ctypes.addressof(items), len(q), H.stream_ptr())
         self._wq = []                      # the launches are enqueued: x / gy may be released (same stream)
 
@@ -246,7 +246,7 @@ class HipBackend(object):
             # independent of everything else in the backward: collected (x, gy kept alive) and issued together at the end
             self._wq = self._wq + [(L, x, gy)]
             return
-        ops.conv2d_wgrad(self.dtype, x, gy, self.slabs[L.slab_off:], L.nsplit, L.kh, L.kw, L.stride, L.pad, self._gs(L))
+        ops.conv2d_wgrad(self.dtype, x, gy, self._slbase + 4 * L.slab_off, L.nsplit, L.kh, L.kw, L.stride, L.pad, self._gs(L))
 
     def stem_fwd(self, L, img4, Hh, W):
         if self.bn_train:
@@ -258,7 +258,7 @@ class HipBackend(object):
         return y
 
     def stem_wgrad(self, L, img4, gy, Hh, W):
-        ops.stem7x7_wgrad(self.dtype, img4, gy, self.slabs[L.slab_off:], L.nsplit, Hh, W, self._gs(L))
+        ops.stem7x7_wgrad(self.dtype, img4, gy, self._slbase + 4 * L.slab_off, L.nsplit, Hh, W, self._gs(L))
 
     def relu_mask(self, g, y):
         """g *= (y > 0) in place (the dbeta sums come out of the wgrad kernel)."""
