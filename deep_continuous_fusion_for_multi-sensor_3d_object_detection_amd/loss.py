@@ -74,10 +74,11 @@ class LossTotal(nn.Module):
         span = c["positive_range"]
         half = int(span / 2)
         positives, regress, owner = [], [], []
-        for box in boxes:
+        centres = boxes[:, :2].tolist() if hasattr(boxes, "tolist") else [(float(b[0]), float(b[1])) for b in boxes]
+        for bx, by in centres:              # python floats of the fp32 values, like float(box[0]) in the reference
             members = []
-            cx = int((float(box[0]) * self._xs + self._xo) / rs)
-            cy = int((float(box[1]) * self._ys + self._yo) / rs)
+            cx = int((bx * self._xs + self._xo) / rs)
+            cy = int((by * self._ys + self._yo) / rs)
             if 0 <= cx <= H - 1 and 0 <= cy <= W - 1:
                 for dx in range(span):
                     for dy in range(span):
@@ -91,12 +92,17 @@ class LossTotal(nn.Module):
             owner.append(members)
         np.random.shuffle(positives)
         positives = positives[:c["pos_sample_threshold"]] if len(positives) > c["pos_sample_threshold"] else positives
+        # same draws and the same rejections as the reference's `[x, y] in list` test (loss.py:117-126), with a set lookup
+        taken = set((p[0], p[1]) for p in positives)
+        # ... and drawn in batches: randint([H, W], size=(m, 2)) consumes the legacy generator exactly like m pairs of
+        # scalar calls (checked in tests/test_host_logic.py); a batch never holds more pairs than are still missing, so
+        # no draw goes unused and the stream stays where the reference's loop leaves it
         negatives = []
-        while len(negatives) <= c["neg_sample_threshold"]:
-            cand = [np.random.randint(H), np.random.randint(W)]
-            if cand in positives:
-                continue
-            negatives.append(cand)
+        want = c["neg_sample_threshold"] + 1
+        while len(negatives) < want:
+            for x, y in np.random.randint([H, W], size=(want - len(negatives), 2)).tolist():
+                if (x, y) not in taken:
+                    negatives.append([x, y])
         return positives, negatives, regress, owner
 
     # ------------------------------------------------------------------ device-side terms

@@ -142,3 +142,26 @@ def test_eval_postprocessing_matches_reference_golden():
     T.initialize_ap()
     T.precision_recall_singleshot([[]], torch.zeros(1, 20, 9))
     assert T.get_num_T() == 0 and T.get_num_P() == 0
+
+
+def test_batched_negative_sampling_consumes_the_generator_like_scalar_calls():
+    """loss.LossTotal.assign draws its negative cells in batches; the legacy numpy generator must be left exactly where
+    the reference's scalar loop (loss.py:117-126: randint(H), randint(W), reject if positive) leaves it."""
+    import numpy as np
+    for H, W, seed in ((176, 200, 0), (96, 64, 5), (16, 8, 11), (4, 4, 3)):
+        taken = {(i % H, (3 * i) % W) for i in range(0, min(H * W // 2, 128))}
+        np.random.seed(seed)
+        ref = []
+        while len(ref) <= 128 and len(ref) < H * W - len(taken):
+            cand = (np.random.randint(H), np.random.randint(W))
+            if cand in taken:
+                continue
+            ref.append(cand)
+        tail_ref = np.random.randint(1 << 30)
+        np.random.seed(seed)
+        got, want = [], len(ref)
+        while len(got) < want:
+            for x, y in np.random.randint([H, W], size=(want - len(got), 2)).tolist():
+                if (x, y) not in taken:
+                    got.append((x, y))
+        assert got == ref and np.random.randint(1 << 30) == tail_ref
