@@ -106,6 +106,7 @@ class HipBackend(object):
             self.bn_train = train
             self._upload_table(self.plan.layers)
             self._sig = None
+            self.__dict__.pop("_bw_cache", None)      # cached tables describe the other BN mode
 
     def _shift(self, L):
         if L.bn is None or self.bn_train:
@@ -124,21 +125,33 @@ class HipBackend(object):
     def begin_backward(self, layers):
         sig = tuple(L.out_shape for L in layers)
         if sig != self._sig:
-            off = goff = 0
-            for L in layers:
-                if L.out_shape is None:
-                    L.nsplit, L.slab_off, L.gsum_off = 0, 0, 0
-                    continue
-                B, Ho, Wo = L.out_shape
-                L.nsplit = ops.conv2d_wgrad_splits(B, Ho, Wo, L.cin, L.cout_pad, L.kh, L.kw, L.stride)
-                L.slab_off = off
-                off += L.nsplit * L.cout_pad * L.taps * L.cin
-                L.gsum_off = goff                       # [4*nsplit][cout_pad] per-wave sums of g (dbeta)
-                goff += 4 * L.nsplit * L.cout_pad
-            self.slabs = torch.empty(max(off, 4), dtype=torch.float32, device=self.dev)
-            self.gsum = torch.zeros(max(goff, 4), dtype=torch.float32, device=self.dev)
+            # one (slab arena, gsum arena, table) per output-shape signature, kept alive: a captured graph has their addresses
+            # baked in, and a step stream that alternates between two signatures (valid-point counts) re-uses them
+            cache = self.__dict__.setdefault("_bw_cache", {})
+            hit = cache.get(sig)
+            if hit is None:
+                off = goff = 0
+                for L in layers:
+                    if L.out_shape is None:
+                        L.nsplit, L.slab_off, L.gsum_off = 0, 0, 0
+                        continue
+                    B, Ho, Wo = L.out_shape
+                    L.nsplit = ops.conv2d_wgrad_splits(B, Ho, Wo, L.cin, L.cout_pad, L.kh, L.kw, L.stride)
+                    L.slab_off = off
+                    off += L.nsplit * L.cout_pad * L.taps * L.cin
+                    L.gsum_off = goff                       # [4*nsplit][cout_pad] per-wave sums of g (dbeta)
+                    goff += 4 * L.nsplit * L.cout_pad
+                self.slabs = torch.empty(max(off, 4), dtype=torch.float32, device=self.dev)
+                self.gsum = torch.zeros(max(goff, 4), dtype=torch.float32, device=self.dev)
+                self._upload_table(layers)
+                if len(cache) >= 8:
+                    cache.pop(next(iter(cache)))
+                cache[sig] = (self.slabs, self.gsum, self.table, [(L.nsplit, L.slab_off, L.gsum_off) for L in layers])
+            else:
+                self.slabs, self.gsum, self.table, per = hit
+                for L, (ns, so, go) in zip(layers, per):
+                    L.nsplit, L.slab_off, L.gsum_off = ns, so, go
             self._gsbase, self._slbase = self.gsum.data_ptr(), self.slabs.data_ptr()
-            self._upload_table(layers)
             self._sig = sig
         self.grads.zero_()
         self._wq = []                      # weight gradients collected by a backward that did not finish are dropped

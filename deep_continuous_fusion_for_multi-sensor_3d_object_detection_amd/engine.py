@@ -304,15 +304,26 @@ class Plan(object):
             self.fusion.append(f)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, K, x_lidar, x_image=None, geom=None, save=True):
+    def forward_image(self, K, x_image, save=True):
+        """Camera stream alone (it does not depend on the frame's geometry): returns the feature map to hand to forward()
+        as `fmap`.  The captured-graph path replays this part while the geometry still runs on its side stream."""
+        self.ctx = {"save": save}
+        fmap = self._image_forward(K, x_image, save)
+        self._img_saved = self.ctx.get("img")
+        return fmap
+
+    def forward(self, K, x_lidar, x_image=None, geom=None, save=True, fmap=None):
         """x_lidar [B,Cz,L,W] fp32 NCHW (model.py:194); returns pred [B,32,L/4,W/4] fp32 NCHW.
 
         geom (fusion only): dict(xyz [B,n_max,3], uv [B,n_max,2], cnt [B] int32 device, idx = list over
         sites of [B,K,h,w] int32, aff) -- produced once per frame by the geometry kernels.
+        fmap: the camera feature map when forward_image() already ran for this step.
         """
         self.ctx = {"save": save}
-        fmap = None
-        if self.with_image and geom is not None:
+        if fmap is not None:
+            if save:
+                self.ctx["img"] = self._img_saved
+        elif self.with_image and geom is not None:
             fmap = self._image_forward(K, x_image, save)
         if geom is not None and geom.get("voxel_event") is not None:
             K.wait_event(geom["voxel_event"])          # voxel grid produced on the geometry side stream

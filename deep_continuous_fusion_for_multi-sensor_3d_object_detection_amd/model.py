@@ -89,64 +89,105 @@ class _RunGraphs(torch.autograd.Function):
         return None, None, None, None, None
 
 
-class _StepGraphs(object):
-    """Captured forward / backward HIP graphs of one model for one input signature."""
+class _GraphSet(object):
+    """Static buffers and the captured graphs of one input signature (tensor shapes + rows of the per-point fusion
+    tensors): g_img = weight preparation + camera stream, g_lid = LiDAR stream with the fusion sites and the heads,
+    g_bwd = the whole backward.  The three share one memory pool (activations saved by the forward graphs are read by
+    the backward graph)."""
 
-    def __init__(self, model):
-        self.model = model
-        self.sig = None
-
-    @staticmethod
-    def _signature(x_lidar, x_image, geom):
-        g = None if geom is None else (tuple(geom["xyz"].shape), tuple(geom["idx"][0].shape))
-        return (tuple(x_lidar.shape), None if x_image is None else tuple(x_image.shape), g)
-
-    def _capture(self, x_lidar, x_image, geom):
-        m = self.model
-        K = m._backend
+    def __init__(self, model, x_lidar, x_image, geom, n_rows):
+        m, K = model, model._backend
         self.sx = x_lidar.clone()
         self.simg = None if x_image is None else x_image.clone()
         self.sgeom = None
         if geom is not None:
             self.sgeom = dict(xyz=geom["xyz"].clone(), uv=geom["uv"].clone(), cnt=geom["cnt"].clone(),
-                              idx=[t.clone() for t in geom["idx"]], aff=geom["aff"])
+                              idx=[t.clone() for t in geom["idx"]], aff=geom["aff"], n_rows=n_rows)
+            if geom.get("inv") is not None:
+                self.sgeom["inv"] = tuple(t.clone() for t in geom["inv"])
+                self.sgeom["inv_nmax"] = geom["inv_nmax"]
+        split = m._plan.with_image and self.sgeom is not None
         # eager warm-up step on the static buffers: lazy allocations (slabs, anchors, workspaces) happen here
         K.prepare()
         pred = m._plan.forward(K, self.sx, self.simg, self.sgeom, save=True)
         m._plan.backward(K, torch.zeros_like(pred))
         torch.cuda.synchronize()
-        self.g_fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fwd):
+        self.g_img = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_img):
             K.prepare()
-            self.spred = m._plan.forward(K, self.sx, self.simg, self.sgeom, save=True)
+            self.sfmap = m._plan.forward_image(K, self.simg, save=True) if split else None
+        self.g_lid = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_lid, pool=self.g_img.pool()):
+            self.spred = m._plan.forward(K, self.sx, self.simg, self.sgeom, save=True, fmap=self.sfmap)
         self.sgpred = torch.zeros_like(self.spred)
         self.g_bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()):
+        with torch.cuda.graph(self.g_bwd, pool=self.g_img.pool()):
             m._plan.backward(K, self.sgpred)
+
+
+class _StepGraphs(object):
+    """Captured-graph execution of the train step (config['hip_graphs']).  The geometry stays outside the graphs, on the
+    caller's side stream (train.Train.geometry_async): the camera-stream graph is replayed first and overlaps it, the
+    LiDAR-stream graph follows once the voxel grid and the KNN maps are there.  One set of graphs per input signature;
+    the signature includes the row count of the per-point fusion tensors (the valid-point count rounded up to 1024),
+    so the graphs keep the valid-count sizing of the eager path."""
+    MAX_SETS = 6
+
+    def __init__(self, model):
+        self.model = model
+        self.sets = {}
+        self.cur = None
+
+    @staticmethod
+    def _rows(geom):
+        if geom is None:
+            return 0
+        n = geom["xyz"].shape[1]
+        ch = geom.get("cnt_host")
+        if ch is not None:
+            geom["cnt_event"].synchronize()
+            n = min(n, max(1024, (int(ch.max()) + 1023) // 1024 * 1024))
+        return n
 
     def run_forward(self, x_lidar, x_image, geom):
         cur = torch.cuda.current_stream()
-        if geom is not None:
-            for k in ("voxel_event", "event"):
-                if geom.get(k) is not None:
-                    cur.wait_event(geom[k])
-        sig = self._signature(x_lidar, x_image, geom)
-        if sig != self.sig:
-            self._capture(x_lidar, x_image, geom)
-            self.sig = sig
-        self.sx.copy_(x_lidar)
-        if self.simg is not None:
-            self.simg.copy_(x_image)
-        if self.sgeom is not None:
-            self.sgeom["xyz"].copy_(geom["xyz"]); self.sgeom["uv"].copy_(geom["uv"]); self.sgeom["cnt"].copy_(geom["cnt"])
-            for d, s_ in zip(self.sgeom["idx"], geom["idx"]):
+        n_rows = self._rows(geom)
+        sig = (tuple(x_lidar.shape), None if x_image is None else tuple(x_image.shape),
+               None if geom is None else (tuple(geom["xyz"].shape), tuple(geom["idx"][0].shape), geom.get("inv") is not None), n_rows)
+        st = self.sets.get(sig)
+        if st is None:
+            if geom is not None:
+                for k in ("voxel_event", "event", "inv_event"):
+                    if geom.get(k) is not None:
+                        cur.wait_event(geom[k])
+            if len(self.sets) >= self.MAX_SETS:
+                self.sets.pop(next(iter(self.sets)))
+            st = self.sets[sig] = _GraphSet(self.model, x_lidar, x_image, geom, n_rows)
+        self.cur = (st, geom)
+        if st.simg is not None:
+            st.simg.copy_(x_image)
+        st.g_img.replay()                              # weight images + camera stream: overlaps the geometry side stream
+        if geom is not None and geom.get("voxel_event") is not None:
+            cur.wait_event(geom["voxel_event"])
+        st.sx.copy_(x_lidar)
+        if st.sgeom is not None:
+            if geom.get("event") is not None:
+                cur.wait_event(geom["event"])
+            st.sgeom["xyz"].copy_(geom["xyz"]); st.sgeom["uv"].copy_(geom["uv"]); st.sgeom["cnt"].copy_(geom["cnt"])
+            for d, s_ in zip(st.sgeom["idx"], geom["idx"]):
                 d.copy_(s_)
-        self.g_fwd.replay()
-        return self.spred
+        st.g_lid.replay()
+        return st.spred
 
     def run_backward(self, gpred):
-        self.sgpred.copy_(gpred)
-        self.g_bwd.replay()
+        st, geom = self.cur
+        if st.sgeom is not None and st.sgeom.get("inv") is not None:
+            if geom.get("inv_event") is not None:
+                torch.cuda.current_stream().wait_event(geom["inv_event"])
+            for d, s_ in zip(st.sgeom["inv"], geom["inv"]):
+                d.copy_(s_)
+        st.sgpred.copy_(gpred)
+        st.g_bwd.replay()
 
 
 class ObjectDetection_DCF(nn.Module):

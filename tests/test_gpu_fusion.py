@@ -322,3 +322,37 @@ def test_cfg5_fp8_forward_path_model_step():
     g16 = nets["bf16"]._gradflat
     cos = float((g8 * g16).sum() / (g8.norm() * g16.norm()))
     assert cos > 0.9, cos
+
+
+def test_graph_replay_with_side_stream_geometry_matches_eager():
+    """config hip_graphs with the fusion path: camera-stream graph, then (after the side-stream geometry) the
+    LiDAR-stream graph, then the backward graph -- same predictions and gradients as the eager launches, over several
+    steps with different frames (replays, and a second graph set when the valid-point count changes bucket)."""
+    cfg, pts, img, crt = setup("f32")
+    T = pkg("train")
+    det = pkg("detfill")
+    geo = pkg("data_import_carla").FrameGeometry(cfg, crt)
+    lim6 = (cfg["lidar_x_min"], cfg["lidar_x_max"], cfg["lidar_y_min"], cfg["lidar_y_max"], cfg["lidar_z_min"], cfg["lidar_z_max"])
+    frames = [[torch.from_numpy(p).cuda() for p in pts],
+              [torch.from_numpy(det.synthetic_points(1500, lim6, 70 + b)).cuda() for b in range(2)],
+              [torch.from_numpy(det.synthetic_points(400, lim6, 90 + b)).cuda() for b in range(2)]]     # fewer valid points
+    order = [0, 1, 0, 2, 1, 2]
+    res = {}
+    for graphs in (False, True):
+        c = copy.deepcopy(cfg)
+        c["hip_graphs"] = graphs
+        trainer = T.Train(c)
+        det.fill_state_dict(trainer.model)
+        out = []
+        for step, k in enumerate(order):
+            x_lidar, geom = trainer.geometry_async(geo, frames[k])
+            pred = trainer.model(x_lidar, img.cuda(), geom=geom)
+            R = torch.from_numpy(det.uniform(tuple(pred.shape), 700 + step, -1.0, 1.0)).cuda()
+            (pred * R).sum().backward()
+            out.append((pred.detach().clone(), trainer.model._gradflat.clone()))
+        res[graphs] = out
+        if graphs:
+            assert trainer.model._graphs is not None and 1 <= len(trainer.model._graphs.sets) <= 3
+    for (p0, g0), (p1, g1) in zip(res[False], res[True]):
+        assert torch.allclose(p0, p1, rtol=1e-5, atol=1e-6)
+        assert float((g0 - g1).abs().max()) < 2e-5 * float(g0.abs().max())
