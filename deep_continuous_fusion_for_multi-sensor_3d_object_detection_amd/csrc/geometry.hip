@@ -426,28 +426,41 @@ __global__ void __launch_bounds__(256) k_knn_search(const int *count, int n_max,
             if (!done) top.clear();
             const int Rmax = max(g.h8, g.w8);
             for (int R = 0; R <= Rmax; ++R) {
-                for (int a = -R; a <= R; ++a) {
-                    const int bi = TI + a;
-                    if (bi < 0 || bi >= g.h8) continue;
-                    const bool edge = (a == -R || a == R);
-                    for (int b = -R; b <= R; b += (edge ? 1 : 2 * R)) {
-                        const int bj = TJ + b;
-                        if (bj >= 0 && bj < g.w8) {
-                            const int k0 = (bi * g.w8 + bj) << 6;
-                            const int ps = cellstart[k0], pe = cellstart[k0 + 64];
-                            if (pe > ps) {
-                                bool visit = !done;
-                                if (visit && top.full()) {  // prune by the block's metric bounding box
-                                    const float lox = ((float)(bi * 8) * s - g.xo) / g.xs, hix = ((float)(bi * 8 + 8) * s - g.xo) / g.xs;
-                                    const float loy = ((float)(bj * 8) * s - g.yo) / g.ys, hiy = ((float)(bj * 8 + 8) * s - g.yo) / g.ys;
-                                    const float ddx = fmaxf(0.f, fmaxf(lox - X, X - hix) - 1e-3f);
-                                    const float ddy = fmaxf(0.f, fmaxf(loy - Y, Y - hiy) - 1e-3f);
-                                    visit = (ddx * ddx + ddy * ddy) <= top.kth();
-                                }
-                                if (__any(visit)) scan_range(ps, pe, visit);
-                            }
+                // the 8R blocks of ring R are probed 64 at a time, one per lane (tiles far from every point walk many
+                // empty rings: a vector load per 64 blocks instead of two dependent scalar loads per block); the
+                // non-empty ones are then scanned by the whole wave, in any order
+                const int nblk = R == 0 ? 1 : 8 * R;
+                for (int t0 = 0; t0 < nblk; t0 += 64) {
+                    const int t = t0 + lane;
+                    int a = 0, b = 0;
+                    if (R > 0) {
+                        if (t < 2 * R + 1) { a = -R; b = -R + t; }
+                        else if (t < 4 * R + 2) { a = R; b = -R + (t - (2 * R + 1)); }
+                        else if (t < 6 * R + 1) { b = -R; a = -R + 1 + (t - (4 * R + 2)); }
+                        else { b = R; a = -R + 1 + (t - (6 * R + 1)); }
+                    }
+                    const int bi = TI + a, bj = TJ + b;
+                    int ps = 0, pe = 0;
+                    if (t < nblk && bi >= 0 && bi < g.h8 && bj >= 0 && bj < g.w8) {
+                        const int k0 = (bi * g.w8 + bj) << 6;
+                        ps = cellstart[k0];
+                        pe = cellstart[k0 + 64];
+                    }
+                    unsigned long long live = __ballot(pe > ps);
+                    while (live) {
+                        const int l = __ffsll((long long)live) - 1;
+                        live &= live - 1;
+                        const int cbi = __builtin_amdgcn_readlane(bi, l), cbj = __builtin_amdgcn_readlane(bj, l);
+                        const int cps = __builtin_amdgcn_readlane(ps, l), cpe = __builtin_amdgcn_readlane(pe, l);
+                        bool visit = !done;
+                        if (visit && top.full()) {  // prune by the block's metric bounding box
+                            const float lox = ((float)(cbi * 8) * s - g.xo) / g.xs, hix = ((float)(cbi * 8 + 8) * s - g.xo) / g.xs;
+                            const float loy = ((float)(cbj * 8) * s - g.yo) / g.ys, hiy = ((float)(cbj * 8 + 8) * s - g.yo) / g.ys;
+                            const float ddx = fmaxf(0.f, fmaxf(lox - X, X - hix) - 1e-3f);
+                            const float ddy = fmaxf(0.f, fmaxf(loy - Y, Y - hiy) - 1e-3f);
+                            visit = (ddx * ddx + ddy * ddy) <= top.kth();
                         }
-                        if (R == 0) break;
+                        if (__any(visit)) scan_range(cps, cpe, visit);
                     }
                 }
                 const float bound = (8.0f * (float)R + 0.5f) * cwmin - 1e-3f;
@@ -551,28 +564,39 @@ __global__ void __launch_bounds__(256) k_knn_search_wave(const int *count, int n
         const int I = i >> 3, J = j >> 3;
         const int Rmax = max(g.h8, g.w8);
         for (int R = 0; R <= Rmax && !done; ++R) {
-            for (int a = -R; a <= R; ++a) {
-                const int bi = I + a;
-                if (bi < 0 || bi >= g.h8) continue;
-                const bool edge = (a == -R || a == R);
-                for (int b = -R; b <= R; b += (edge ? 1 : 2 * R)) {
-                    const int bj = J + b;
-                    if (bj >= 0 && bj < g.w8) {
-                        const int k0 = (bi * g.w8 + bj) << 6;
-                        const int ps = cellstart[k0], pe = cellstart[k0 + 64];
-                        if (pe > ps) {
-                            bool visit = true;
-                            if (gcnt >= K) {   // prune with the (possibly stale, hence conservative) wave-wide K-th
-                                const float lox = ((float)(bi * 8) * s - g.xo) / g.xs, hix = ((float)(bi * 8 + 8) * s - g.xo) / g.xs;
-                                const float loy = ((float)(bj * 8) * s - g.yo) / g.ys, hiy = ((float)(bj * 8 + 8) * s - g.yo) / g.ys;
-                                const float ddx = fmaxf(0.f, fmaxf(lox - X, X - hix) - 1e-3f);
-                                const float ddy = fmaxf(0.f, fmaxf(loy - Y, Y - hiy) - 1e-3f);
-                                visit = (ddx * ddx + ddy * ddy) <= gd[K - 1];
-                            }
-                            if (visit) scan_range(ps, pe);
-                        }
+            // ring R's blocks probed one per lane, the non-empty ones scanned by the wave (as in k_knn_search)
+            const int nblk = R == 0 ? 1 : 8 * R;
+            for (int t0 = 0; t0 < nblk; t0 += 64) {
+                const int t = t0 + lane;
+                int a = 0, b = 0;
+                if (R > 0) {
+                    if (t < 2 * R + 1) { a = -R; b = -R + t; }
+                    else if (t < 4 * R + 2) { a = R; b = -R + (t - (2 * R + 1)); }
+                    else if (t < 6 * R + 1) { b = -R; a = -R + 1 + (t - (4 * R + 2)); }
+                    else { b = R; a = -R + 1 + (t - (6 * R + 1)); }
+                }
+                const int bi = I + a, bj = J + b;
+                int ps = 0, pe = 0;
+                if (t < nblk && bi >= 0 && bi < g.h8 && bj >= 0 && bj < g.w8) {
+                    const int k0 = (bi * g.w8 + bj) << 6;
+                    ps = cellstart[k0];
+                    pe = cellstart[k0 + 64];
+                }
+                unsigned long long live = __ballot(pe > ps);
+                while (live) {
+                    const int l = __ffsll((long long)live) - 1;
+                    live &= live - 1;
+                    const int cbi = __builtin_amdgcn_readlane(bi, l), cbj = __builtin_amdgcn_readlane(bj, l);
+                    const int cps = __builtin_amdgcn_readlane(ps, l), cpe = __builtin_amdgcn_readlane(pe, l);
+                    bool visit = true;
+                    if (gcnt >= K) {   // prune with the (possibly stale, hence conservative) wave-wide K-th
+                        const float lox = ((float)(cbi * 8) * s - g.xo) / g.xs, hix = ((float)(cbi * 8 + 8) * s - g.xo) / g.xs;
+                        const float loy = ((float)(cbj * 8) * s - g.yo) / g.ys, hiy = ((float)(cbj * 8 + 8) * s - g.yo) / g.ys;
+                        const float ddx = fmaxf(0.f, fmaxf(lox - X, X - hix) - 1e-3f);
+                        const float ddy = fmaxf(0.f, fmaxf(loy - Y, Y - hiy) - 1e-3f);
+                        visit = (ddx * ddx + ddy * ddy) <= gd[K - 1];
                     }
-                    if (R == 0) break;
+                    if (visit) scan_range(cps, cpe);
                 }
             }
             wave_merge<K>(top, gd, gi, gcnt);
