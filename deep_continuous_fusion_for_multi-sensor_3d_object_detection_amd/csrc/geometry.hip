@@ -407,13 +407,23 @@ __global__ void __launch_bounds__(256) k_knn_search(const int *count, int n_max,
     if (n > 0) {
         // ---- phase A: rows 8TI-2 .. 8TI+9, three column segments (one per coarse block column)
         const int H8 = g.h8 * 8, W8 = g.w8 * 8;
-        for (int ci = max(TI * 8 - 2, 0); ci <= min(TI * 8 + 9, H8 - 1); ++ci) {
-            for (int seg = 0; seg < 3; ++seg) {
-                int c0 = TJ * 8 + (seg == 0 ? -2 : (seg == 1 ? 0 : 8));
-                int c1 = TJ * 8 + (seg == 0 ? -1 : (seg == 1 ? 7 : 9));
-                c0 = max(c0, 0); c1 = min(c1, W8 - 1);
-                if (c0 > c1) continue;
-                scan_range(cellstart[cell_key(ci, c0, g)], cellstart[cell_key(ci, c1, g) + 1], !done);
+        {
+            // the 12 rows x 3 segments are looked up one per lane; the wave then scans the non-empty ranges
+            const int row = lane / 3, seg = lane - row * 3;
+            const int ci = TI * 8 - 2 + row;
+            int c0 = TJ * 8 + (seg == 0 ? -2 : (seg == 1 ? 0 : 8));
+            int c1 = TJ * 8 + (seg == 0 ? -1 : (seg == 1 ? 7 : 9));
+            c0 = max(c0, 0); c1 = min(c1, W8 - 1);
+            int ps = 0, pe = 0;
+            if (lane < 36 && ci >= 0 && ci <= H8 - 1 && c0 <= c1) {
+                ps = cellstart[cell_key(ci, c0, g)];
+                pe = cellstart[cell_key(ci, c1, g) + 1];
+            }
+            unsigned long long live = __ballot(pe > ps);
+            while (live) {
+                const int l = __ffsll((long long)live) - 1;
+                live &= live - 1;
+                scan_range(__builtin_amdgcn_readlane(ps, l), __builtin_amdgcn_readlane(pe, l), !done);
             }
         }
         {
