@@ -551,14 +551,25 @@ __global__ void __launch_bounds__(256) k_knn_search_wave(const int *count, int n
     bool done = (n == 0);
     if (!done) {
         const int H8 = g.h8 * 8, W8 = g.w8 * 8;
-        for (int ci = max(i - 2, 0); ci <= min(i + 2, H8 - 1); ++ci) {
-            // columns j-2..j+2 split at coarse-block boundaries (cells of one block row are contiguous keys)
-            int c0 = max(j - 2, 0);
-            const int cend = min(j + 2, W8 - 1);
-            while (c0 <= cend) {
-                const int c1 = min(cend, (c0 | 7));
-                scan_range(cellstart[cell_key(ci, c0, g)], cellstart[cell_key(ci, c1, g) + 1]);
-                c0 = c1 + 1;
+        {
+            // 5 rows x (columns j-2..j+2 split at a coarse-block boundary: cells of one block row are contiguous keys):
+            // at most 10 ranges, looked up one per lane, the non-empty ones scanned by the wave
+            const int row = lane >> 1, part = lane & 1;
+            const int ci = i - 2 + row;
+            const int cbeg = max(j - 2, 0), cend = min(j + 2, W8 - 1);
+            const int split = min(cend, (cbeg | 7));                  // last column of the first block
+            const int c0 = part == 0 ? cbeg : split + 1;
+            const int c1 = part == 0 ? split : cend;
+            int ps = 0, pe = 0;
+            if (lane < 10 && ci >= 0 && ci <= H8 - 1 && c0 <= c1) {
+                ps = cellstart[cell_key(ci, c0, g)];
+                pe = cellstart[cell_key(ci, c1, g) + 1];
+            }
+            unsigned long long live = __ballot(pe > ps);
+            while (live) {
+                const int l = __ffsll((long long)live) - 1;
+                live &= live - 1;
+                scan_range(__builtin_amdgcn_readlane(ps, l), __builtin_amdgcn_readlane(pe, l));
             }
         }
         wave_merge<K>(top, gd, gi, gcnt);
