@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libdcf_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16, F16 = 0, 1, 2
-VOXEL_COMPAT, VOXEL_ACCUM = 0, 1
+VOXEL_COMPAT, VOXEL_ACCUM, VOXEL_COMPAT_ROUNDS = 0, 1, 2
 PROJ_COMPAT, PROJ_CORRECT = 0, 1
 
 c_int, c_float, c_i64, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p

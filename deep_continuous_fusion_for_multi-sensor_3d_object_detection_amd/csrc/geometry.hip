@@ -208,37 +208,98 @@ __global__ void __launch_bounds__(256) k_voxel_compat_round(const float *pts, in
     }
 }
 
-// The frames of a batch are independent and each round is latency bound (a scattered read, an atomic): blockIdx.y = frame
-// runs them side by side in one launch per round.
+// frames of a batch: blockIdx.y = frame
 struct VoxBatch {
     const float *pts[DCF_MAX_VOXEL_BATCH];
     int n[DCF_MAX_VOXEL_BATCH];
 };
-__global__ void __launch_bounds__(256) k_voxel_compat_round_batch(VoxBatch vb, Lim6 lim, Aff6 aff, int L, int W, int nvox, int round, float *grids,
-                                                                  int *owners)
+// ---- compat voxeliser in three launches instead of nine rounds.
+// Pass c of the reference writes voxel cell(i)+delta_c for every point i, last writer (highest index) wins: the points that
+// compete for one voxel in one pass are exactly the points of one CELL, so a single "last point of the cell" map decides
+// every pass.  A voxel v then holds  sum over c = 0..7, in pass order, of  w_c(last(v - delta_c))  (cells without a point
+// contribute nothing).  Step 1 claims the cells (atomicMax of index+1), step 2 lets every cell winner evaluate that ordered
+// sum for its 8 corners (neighbouring winners compute the same value for a shared voxel: identical stores), step 3 clears
+// the claims so the workspace is all-zero again.
+__device__ __forceinline__ float corner_weight(float x, float y, float z, const Aff6 &a, int c)
+{
+    const float fx = __fadd_rn(__fmul_rn(x, a.v[0]), a.v[1]);
+    const float fy = __fadd_rn(__fmul_rn(y, a.v[2]), a.v[3]);
+    const float fz = __fadd_rn(__fmul_rn(z, a.v[4]), a.v[5]);
+    const float dx = __fsub_rn(fx, (float)(int)fx), dy = __fsub_rn(fy, (float)(int)fy), dz = __fsub_rn(fz, (float)(int)fz);
+    const float wx = ((c >> 1) & 1) ? dx : __fsub_rn(1.0f, dx);
+    const float wy = ((c >> 2) & 1) ? dy : __fsub_rn(1.0f, dy);
+    const float wz = (c & 1) ? dz : __fsub_rn(1.0f, dz);
+    return __fmul_rn(__fmul_rn(wx, wy), wz);
+}
+
+__global__ void __launch_bounds__(256) k_voxel_cell_claim(VoxBatch vb, Lim6 lim, Aff6 aff, int L, int W, int nvox, int *owners, int release)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= vb.n[b]) return;
     const float *pts = vb.pts[b];
-    float *grid = grids + (size_t)b * nvox;
-    int *owner = owners + (size_t)b * 2 * nvox;
     const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
     if (!in_range(x, y, z, lim)) return;
-    Corner8 c8;
-    corners(x, y, z, aff, L, W, c8);
-    if (round >= 1) {
-        const int c = round - 1;
-        int *ow = owner + (size_t)(c & 1) * nvox;
-        const int v = c8.vox[c];
-        if (ow[v] == i + 1) {
-            grid[v] = __fadd_rn(grid[v], c8.w[c]);
-            ow[v] = 0;
-        }
-    }
-    if (round <= 7) {
-        int *ow = owner + (size_t)(round & 1) * nvox;
-        atomicMax(&ow[c8.vox[round]], i + 1);
+    const int xl = (int)__fadd_rn(__fmul_rn(x, aff.v[0]), aff.v[1]), yl = (int)__fadd_rn(__fmul_rn(y, aff.v[2]), aff.v[3]),
+              zl = (int)__fadd_rn(__fmul_rn(z, aff.v[4]), aff.v[5]);
+    int *last = owners + (size_t)b * 2 * nvox;
+    const int cell = (zl * L + xl) * W + yl;
+    if (release) last[cell] = 0;
+    else atomicMax(&last[cell], i + 1);
+}
+
+__global__ void __launch_bounds__(256) k_voxel_cell_gather(VoxBatch vb, Lim6 lim, Aff6 aff, int Cz, int L, int W, int nvox, float *grids,
+                                                           const int *owners)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= vb.n[b]) return;
+    const float *pts = vb.pts[b];
+    const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    if (!in_range(x, y, z, lim)) return;
+    const int xl = (int)__fadd_rn(__fmul_rn(x, aff.v[0]), aff.v[1]), yl = (int)__fadd_rn(__fmul_rn(y, aff.v[2]), aff.v[3]),
+              zl = (int)__fadd_rn(__fmul_rn(z, aff.v[4]), aff.v[5]);
+    const int *last = owners + (size_t)b * 2 * nvox;
+    if (last[(zl * L + xl) * W + yl] != i + 1) return;              // not the last point of its cell
+    float *grid = grids + (size_t)b * nvox;
+    // contrib[k][c]: what pass c adds to this cell's corner k.  The contributor of (k, c) is the last point of the cell at
+    // offset e_k - e_c (e = the corner's (z, x, y) bits), so the 27 neighbouring cells are visited once each -- one claim
+    // read, one point read, the fractional parts computed once -- and hand their weights to the corners they share.
+    // Absent contributors leave +0.0f, which an ordered sum of non-negative terms absorbs exactly.
+    float contrib[8][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) contrib[k][c] = 0.f;
+#pragma unroll
+    for (int oz = -1; oz <= 1; ++oz)
+#pragma unroll
+        for (int ox = -1; ox <= 1; ++ox)
+#pragma unroll
+            for (int oy = -1; oy <= 1; ++oy) {
+                const int cz = zl + oz, cx = xl + ox, cy = yl + oy;
+                if (cz < 0 || cx < 0 || cy < 0 || cz >= Cz || cx >= L || cy >= W) continue;
+                const int j1 = last[(cz * L + cx) * W + cy];
+                if (j1 <= 0) continue;
+                const float *q = pts + 3 * (size_t)(j1 - 1);
+                const float fx = __fadd_rn(__fmul_rn(q[0], aff.v[0]), aff.v[1]);
+                const float fy = __fadd_rn(__fmul_rn(q[1], aff.v[2]), aff.v[3]);
+                const float fz = __fadd_rn(__fmul_rn(q[2], aff.v[4]), aff.v[5]);
+                const float dx = __fsub_rn(fx, (float)(int)fx), dy = __fsub_rn(fy, (float)(int)fy), dz = __fsub_rn(fz, (float)(int)fz);
+                const float wxs[2] = {__fsub_rn(1.0f, dx), dx}, wys[2] = {__fsub_rn(1.0f, dy), dy}, wzs[2] = {__fsub_rn(1.0f, dz), dz};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int ez = (k & 1) - oz, ex = ((k >> 1) & 1) - ox, ey = ((k >> 2) & 1) - oy;     // e_c = e_k - offset
+                    if (ez < 0 || ez > 1 || ex < 0 || ex > 1 || ey < 0 || ey > 1) continue;
+                    contrib[k][ez | (ex << 1) | (ey << 2)] = __fmul_rn(__fmul_rn(wxs[ex], wys[ey]), wzs[ez]);
+                }
+            }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) sum = __fadd_rn(sum, contrib[k][c]);                       // pass order
+        grid[((zl + (k & 1)) * L + xl + ((k >> 1) & 1)) * W + yl + ((k >> 2) & 1)] = sum;
     }
 }
 
@@ -761,6 +822,14 @@ extern "C" int dcf_voxelize(const float *pts, int n, const float *lim, const flo
     const int nb = cdiv(n, 256);
     if (mode == DCF_VOXEL_COMPAT) {
         DCF_REQUIRE(owner_ws != nullptr, "dcf_voxelize: compat mode needs the zeroed owner workspace");
+        VoxBatch vb;
+        for (int b = 0; b < DCF_MAX_VOXEL_BATCH; ++b) { vb.pts[b] = b == 0 ? pts : nullptr; vb.n[b] = b == 0 ? n : 0; }
+        const dim3 g1(nb, 1);
+        DCF_LAUNCH("voxel_cell_claim", s, hipLaunchKernelGGL(k_voxel_cell_claim, g1, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, 0));
+        DCF_LAUNCH("voxel_cell_gather", s, hipLaunchKernelGGL(k_voxel_cell_gather, g1, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, grid, (const int *)owner_ws));
+        DCF_LAUNCH("voxel_cell_claim", s, hipLaunchKernelGGL(k_voxel_cell_claim, g1, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, 1));
+    } else if (mode == DCF_VOXEL_COMPAT_ROUNDS) {
+        DCF_REQUIRE(owner_ws != nullptr, "dcf_voxelize: compat mode needs the zeroed owner workspace");
         for (int r = 0; r <= 8; ++r)
             DCF_LAUNCH("voxel_compat_round", s, hipLaunchKernelGGL(k_voxel_compat_round, dim3(nb), dim3(256), 0, s, pts, n, l, a, L, W, nvox, r,
                                                                    grid, (int *)owner_ws));
@@ -794,9 +863,10 @@ extern "C" int dcf_voxelize_batch(const float *const *pts, const int *n, int B, 
     Lim6 l; Aff6 a;
     memcpy(l.v, lim, sizeof(l.v));
     memcpy(a.v, aff, sizeof(a.v));
-    for (int r = 0; r <= 8; ++r)
-        DCF_LAUNCH("voxel_compat_round", s, hipLaunchKernelGGL(k_voxel_compat_round_batch, dim3(cdiv(nmax, 256), B), dim3(256), 0, s, vb, l, a, L, W, nvox,
-                                                               r, grids, (int *)owner_ws));
+    const dim3 grid(cdiv(nmax, 256), B);
+    DCF_LAUNCH("voxel_cell_claim", s, hipLaunchKernelGGL(k_voxel_cell_claim, grid, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, 0));
+    DCF_LAUNCH("voxel_cell_gather", s, hipLaunchKernelGGL(k_voxel_cell_gather, grid, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, grids, (const int *)owner_ws));
+    DCF_LAUNCH("voxel_cell_claim", s, hipLaunchKernelGGL(k_voxel_cell_claim, grid, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, 1));
     return DCF_OK;
 }
 

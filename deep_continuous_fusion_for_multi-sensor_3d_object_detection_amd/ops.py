@@ -251,7 +251,7 @@ def voxelize(pts, lim, aff, dims, mode=H.VOXEL_COMPAT, owner_ws=None, out=None):
     Cz, L, W = dims
     dev = pts.device
     grid = torch.empty((Cz, L, W), dtype=torch.float32, device=dev) if out is None else _chk(out, "out")
-    if mode == H.VOXEL_COMPAT and owner_ws is None:
+    if mode in (H.VOXEL_COMPAT, H.VOXEL_COMPAT_ROUNDS) and owner_ws is None:
         owner_ws = torch.zeros((2, Cz * L * W), dtype=torch.int32, device=dev)
     H.call("dcf_voxelize", _chk(pts, "pts"), pts.shape[0], H.host_f32(lim), H.host_f32(aff), Cz, L, W, mode, grid, owner_ws,
            H.stream_ptr())
@@ -259,7 +259,8 @@ def voxelize(pts, lim, aff, dims, mode=H.VOXEL_COMPAT, owner_ws=None, out=None):
 
 
 def voxelize_batch(pts_list, lim, aff, dims, owner_ws, out):
-    """Compat-mode grids of B frames in one launch per round: out [B,Cz,L,W] fp32, owner_ws int32 [B,2,Cz*L*W] (zero)."""
+    """Compat-mode grids of B frames (claim / gather / release, one launch each for all frames): out [B,Cz,L,W] fp32,
+    owner_ws int32 [B,2,Cz*L*W] (zero on entry and on exit)."""
     Cz, L, W = dims
     B = len(pts_list)
     ptrs = (ctypes.c_void_p * B)(*[_chk(p, "pts").data_ptr() for p in pts_list])

@@ -32,7 +32,9 @@ typedef void *dcf_stream_t; /* hipStream_t */
 
 enum { DCF_OK = 0, DCF_EINVAL = -1, DCF_ELAUNCH = -2, DCF_EUNSUPPORTED = -3 };
 enum { DCF_F32 = 0, DCF_BF16 = 1, DCF_F16 = 2 };   /* compute / storage type of activations and weight images */
-enum { DCF_VOXEL_COMPAT = 0, DCF_VOXEL_ACCUM = 1 };
+/* COMPAT: the reference's last-writer-wins scatter (data_import_carla.py:236-258), three launches; COMPAT_ROUNDS: the same
+ * result by the literal nine rounds (claim pass c, resolve pass c-1), kept as a cross-check; ACCUM: atomic accumulation. */
+enum { DCF_VOXEL_COMPAT = 0, DCF_VOXEL_ACCUM = 1, DCF_VOXEL_COMPAT_ROUNDS = 2 };
 enum { DCF_PROJ_COMPAT = 0, DCF_PROJ_CORRECT = 1 };
 
 const char *dcf_last_error(void);

@@ -200,3 +200,32 @@ def test_voxelize_batch_equals_per_frame():
     for b, p in enumerate(frames):
         ref = ops.voxelize(p, g.lim, g.aff, g.dims, H.VOXEL_COMPAT)
         assert torch.equal(out[b].view(torch.int32), ref.view(torch.int32))
+        lit = ops.voxelize(p, g.lim, g.aff, g.dims, H.VOXEL_COMPAT_ROUNDS)          # the literal nine-round formulation
+        assert torch.equal(out[b].view(torch.int32), lit.view(torch.int32))
+
+
+@pytest.mark.parametrize("case", ["dense", "clustered", "one_cell", "edges"])
+def test_voxel_cell_formulation_equals_nine_rounds(case):
+    """The three-launch compat voxeliser (last point of every CELL decides all eight passes; each cell winner evaluates the
+    ordered sums of its corners) against the literal nine rounds (claim pass c / resolve pass c-1), bit for bit, on clouds
+    with many points per cell, shared voxels between neighbouring cells and points on the range limits."""
+    ops, H, det = pkg("ops"), pkg("_hip"), pkg("detfill")
+    cfg = golden_cfg(load_golden("geometry_carla.npz"))
+    g = _spec(cfg)
+    lim6 = (cfg["lidar_x_min"], cfg["lidar_x_max"], cfg["lidar_y_min"], cfg["lidar_y_max"], cfg["lidar_z_min"], cfg["lidar_z_max"])
+    if case == "dense":
+        p = det.synthetic_points(60000, lim6, 5)
+    elif case == "clustered":                       # 40 k points inside a 2 m cube: dozens of points per cell
+        p = det.synthetic_points(40000, lim6, 6)
+        p = (p - p.mean(0)) * 0.02 + np.array([20.0, 3.0, -1.0], dtype=np.float32)
+    elif case == "one_cell":
+        p = np.tile(np.array([[10.03, 1.01, -0.52]], dtype=np.float32), (500, 1)) + det.uniform((500, 3), 9, 0.0, 0.02)
+    else:                                           # points at / next to the limits (some filtered, some in the last cells)
+        u = det.uniform((4000, 3), 12, 0.0, 1.0)
+        lo = np.array([lim6[0], lim6[2], lim6[4]], dtype=np.float32)
+        hi = np.array([lim6[1], lim6[3], lim6[5]], dtype=np.float32)
+        p = np.where(u < 0.5, lo + u * 0.6, hi - (1.0 - u) * 0.6).astype(np.float32)
+    pts = torch.from_numpy(np.ascontiguousarray(p, dtype=np.float32)).cuda()
+    a = ops.voxelize(pts, g.lim, g.aff, g.dims, H.VOXEL_COMPAT)
+    b = ops.voxelize(pts, g.lim, g.aff, g.dims, H.VOXEL_COMPAT_ROUNDS)
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and float(a.sum()) > 0
