@@ -248,7 +248,10 @@ __global__ void __launch_bounds__(256) k_voxel_cell_claim(VoxBatch vb, Lim6 lim,
     else atomicMax(&last[cell], i + 1);
 }
 
-__global__ void __launch_bounds__(256) k_voxel_cell_gather(VoxBatch vb, Lim6 lim, Aff6 aff, int Cz, int L, int W, int nvox, float *grids,
+// TO / NHWC: fp32 [Cz][L][W] grids (the reference's layout) or the engine's input image [L][W][Cz] in the compute type --
+// the value of a voxel is produced in one piece here, so rounding it on the way out equals casting the fp32 grid later.
+template <typename TO, bool NHWC>
+__global__ void __launch_bounds__(256) k_voxel_cell_gather(VoxBatch vb, Lim6 lim, Aff6 aff, int Cz, int L, int W, int nvox, TO *grids,
                                                            const int *owners)
 {
     const int b = blockIdx.y;
@@ -261,7 +264,7 @@ __global__ void __launch_bounds__(256) k_voxel_cell_gather(VoxBatch vb, Lim6 lim
               zl = (int)__fadd_rn(__fmul_rn(z, aff.v[4]), aff.v[5]);
     const int *last = owners + (size_t)b * 2 * nvox;
     if (last[(zl * L + xl) * W + yl] != i + 1) return;              // not the last point of its cell
-    float *grid = grids + (size_t)b * nvox;
+    TO *grid = grids + (size_t)b * nvox;
     // contrib[k][c]: what pass c adds to this cell's corner k.  The contributor of (k, c) is the last point of the cell at
     // offset e_k - e_c (e = the corner's (z, x, y) bits), so the 27 neighbouring cells are visited once each -- one claim
     // read, one point read, the fractional parts computed once -- and hand their weights to the corners they share.
@@ -271,15 +274,19 @@ __global__ void __launch_bounds__(256) k_voxel_cell_gather(VoxBatch vb, Lim6 lim
     for (int k = 0; k < 8; ++k)
 #pragma unroll
         for (int c = 0; c < 8; ++c) contrib[k][c] = 0.f;
+    // (everything in FLAT voxel indices, like the reference's index arithmetic on the flattened grid: a corner index one
+    // past the end of a row is the first voxel of the next row -- only reachable with limits that leave less than one
+    // cell of margin, but the nine-round formulation and the CPU restatement behave that way)
+    const int cell = (zl * L + xl) * W + yl;
 #pragma unroll
     for (int oz = -1; oz <= 1; ++oz)
 #pragma unroll
         for (int ox = -1; ox <= 1; ++ox)
 #pragma unroll
             for (int oy = -1; oy <= 1; ++oy) {
-                const int cz = zl + oz, cx = xl + ox, cy = yl + oy;
-                if (cz < 0 || cx < 0 || cy < 0 || cz >= Cz || cx >= L || cy >= W) continue;
-                const int j1 = last[(cz * L + cx) * W + cy];
+                const int nc = cell + (oz * L + ox) * W + oy;
+                if (nc < 0 || nc >= nvox) continue;
+                const int j1 = last[nc];
                 if (j1 <= 0) continue;
                 const float *q = pts + 3 * (size_t)(j1 - 1);
                 const float fx = __fadd_rn(__fmul_rn(q[0], aff.v[0]), aff.v[1]);
@@ -299,7 +306,14 @@ __global__ void __launch_bounds__(256) k_voxel_cell_gather(VoxBatch vb, Lim6 lim
         float sum = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) sum = __fadd_rn(sum, contrib[k][c]);                       // pass order
-        grid[((zl + (k & 1)) * L + xl + ((k >> 1) & 1)) * W + yl + ((k >> 2) & 1)] = sum;
+        const int v = cell + ((k & 1) * L + ((k >> 1) & 1)) * W + ((k >> 2) & 1);
+        if (v >= nvox) continue;
+        if (NHWC) {
+            const int vz = v / (L * W), r = v - vz * (L * W);
+            DT<TO>::st(grid + (size_t)r * Cz + vz, sum);                                       // r = vx*W + vy
+        } else {
+            DT<TO>::st(grid + v, sum);
+        }
     }
 }
 
@@ -826,7 +840,7 @@ extern "C" int dcf_voxelize(const float *pts, int n, const float *lim, const flo
         for (int b = 0; b < DCF_MAX_VOXEL_BATCH; ++b) { vb.pts[b] = b == 0 ? pts : nullptr; vb.n[b] = b == 0 ? n : 0; }
         const dim3 g1(nb, 1);
         DCF_LAUNCH("voxel_cell_claim", s, hipLaunchKernelGGL(k_voxel_cell_claim, g1, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, 0));
-        DCF_LAUNCH("voxel_cell_gather", s, hipLaunchKernelGGL(k_voxel_cell_gather, g1, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, grid, (const int *)owner_ws));
+        DCF_LAUNCH("voxel_cell_gather", s, hipLaunchKernelGGL((k_voxel_cell_gather<float, false>), g1, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, grid, (const int *)owner_ws));
         DCF_LAUNCH("voxel_cell_claim", s, hipLaunchKernelGGL(k_voxel_cell_claim, g1, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, 1));
     } else if (mode == DCF_VOXEL_COMPAT_ROUNDS) {
         DCF_REQUIRE(owner_ws != nullptr, "dcf_voxelize: compat mode needs the zeroed owner workspace");
@@ -842,21 +856,21 @@ extern "C" int dcf_voxelize(const float *pts, int n, const float *lim, const flo
     return DCF_OK;
 }
 
-extern "C" int dcf_voxelize_batch(const float *const *pts, const int *n, int B, const float *lim, const float *aff, int Cz, int L, int W,
-                                  float *grids, void *owner_ws, dcf_stream_t stream)
+static int voxelize_batch_impl(const char *who, int dtype, bool nhwc, const float *const *pts, const int *n, int B, const float *lim, const float *aff,
+                               int Cz, int L, int W, void *grids, void *owner_ws, hipStream_t s)
 {
-    DCF_REQUIRE(pts && n && lim && aff && grids && owner_ws && Cz > 0 && L > 0 && W > 0, "dcf_voxelize_batch: bad arguments");
-    DCF_REQUIRE(B >= 1 && B <= DCF_MAX_VOXEL_BATCH, "dcf_voxelize_batch: 1..%d frames per call", DCF_MAX_VOXEL_BATCH);
-    DCF_REQUIRE((int64_t)Cz * L * W < (1ll << 31), "dcf_voxelize_batch: grid too large for int32 voxel ids");
-    hipStream_t s = S(stream);
+    DCF_REQUIRE(pts && n && lim && aff && grids && owner_ws && Cz > 0 && L > 0 && W > 0, "%s: bad arguments", who);
+    DCF_REQUIRE(B >= 1 && B <= DCF_MAX_VOXEL_BATCH, "%s: 1..%d frames per call", who, DCF_MAX_VOXEL_BATCH);
+    DCF_REQUIRE((int64_t)Cz * L * W < (1ll << 31), "%s: grid too large for int32 voxel ids", who);
     const int nvox = Cz * L * W;
-    DCF_HIP(hipMemsetAsync(grids, 0, sizeof(float) * (size_t)nvox * B, s));
+    const size_t es = dtype == DCF_F32 ? 4 : 2;
+    DCF_HIP(hipMemsetAsync(grids, 0, es * (size_t)nvox * B, s));
     VoxBatch vb;
     int nmax = 0;
     for (int b = 0; b < DCF_MAX_VOXEL_BATCH; ++b) {
         vb.pts[b] = b < B ? pts[b] : nullptr;
         vb.n[b] = b < B ? n[b] : 0;
-        DCF_REQUIRE(b >= B || (n[b] >= 0 && (n[b] == 0 || pts[b])), "dcf_voxelize_batch: frame %d: null points", b);
+        DCF_REQUIRE(b >= B || (n[b] >= 0 && (n[b] == 0 || pts[b])), "%s: frame %d: null points", who, b);
         if (b < B && n[b] > nmax) nmax = n[b];
     }
     if (nmax == 0) return DCF_OK;
@@ -865,9 +879,26 @@ extern "C" int dcf_voxelize_batch(const float *const *pts, const int *n, int B, 
     memcpy(a.v, aff, sizeof(a.v));
     const dim3 grid(cdiv(nmax, 256), B);
     DCF_LAUNCH("voxel_cell_claim", s, hipLaunchKernelGGL(k_voxel_cell_claim, grid, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, 0));
-    DCF_LAUNCH("voxel_cell_gather", s, hipLaunchKernelGGL(k_voxel_cell_gather, grid, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, grids, (const int *)owner_ws));
+    if (!nhwc) {
+        DCF_LAUNCH("voxel_cell_gather", s, hipLaunchKernelGGL((k_voxel_cell_gather<float, false>), grid, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, (float *)grids, (const int *)owner_ws));
+    } else {
+        DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("voxel_cell_gather", s, hipLaunchKernelGGL((k_voxel_cell_gather<T, true>), grid, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, (T *)grids, (const int *)owner_ws)); })
+    }
     DCF_LAUNCH("voxel_cell_claim", s, hipLaunchKernelGGL(k_voxel_cell_claim, grid, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, 1));
     return DCF_OK;
+}
+
+extern "C" int dcf_voxelize_batch(const float *const *pts, const int *n, int B, const float *lim, const float *aff, int Cz, int L, int W,
+                                  float *grids, void *owner_ws, dcf_stream_t stream)
+{
+    return voxelize_batch_impl("dcf_voxelize_batch", DCF_F32, false, pts, n, B, lim, aff, Cz, L, W, grids, owner_ws, S(stream));
+}
+
+extern "C" int dcf_voxelize_batch_nhwc(int dtype, const float *const *pts, const int *n, int B, const float *lim, const float *aff, int Cz, int L,
+                                       int W, void *x_nhwc, void *owner_ws, dcf_stream_t stream)
+{
+    DCF_REQUIRE(dtype == DCF_F32 || dtype == DCF_BF16 || dtype == DCF_F16, "dcf_voxelize_batch_nhwc: unsupported dtype %d", dtype);
+    return voxelize_batch_impl("dcf_voxelize_batch_nhwc", dtype, true, pts, n, B, lim, aff, Cz, L, W, x_nhwc, owner_ws, S(stream));
 }
 
 static inline void knn_dims(int h, int w, int &h8, int &w8, int &ncell) { h8 = (h + 7) / 8; w8 = (w + 7) / 8; ncell = h8 * w8 * 64; }

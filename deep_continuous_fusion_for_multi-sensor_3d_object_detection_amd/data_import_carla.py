@@ -57,10 +57,14 @@ class FrameGeometry(object):
                 owner = self._owner[key] = torch.zeros((2, g.dims[0] * g.dims[1] * g.dims[2]), dtype=torch.int32, device=pts.device)
         return ops.voxelize(pts, g.lim, g.aff, g.dims, self.voxel_mode, owner, voxel_out)
 
-    def voxelize_batch(self, points_list, out):
-        """Voxel grids of the frames of a batch written into out [B,Cz,L,W]; compat mode runs all frames in one launch
-        per owner round, other modes frame by frame."""
-        if self.voxel_mode != H.VOXEL_COMPAT or len(points_list) > 8:
+    def voxelize_batch(self, points_list, out, nhwc_dtype=None):
+        """Voxel grids of the frames of a batch written into out [B,Cz,L,W] fp32 -- or, with nhwc_dtype (a dtype code), into
+        out [B,L,W,Cz] of that type: the engine's input image, without the fp32 grid and its transpose (compat mode, <= 8
+        frames).  Compat mode runs all frames in one launch per phase, other modes frame by frame."""
+        if nhwc_dtype is not None:
+            if self.voxel_mode != H.VOXEL_COMPAT or len(points_list) > 8:
+                raise H.DcfError("the NHWC voxel image needs compat mode and at most 8 frames per call")
+        elif self.voxel_mode != H.VOXEL_COMPAT or len(points_list) > 8:
             for b, p in enumerate(points_list):
                 self.voxelize(p, out[b])
             return out
@@ -72,6 +76,8 @@ class FrameGeometry(object):
         owner = self._owner.get(key)
         if owner is None:
             owner = self._owner[key] = torch.zeros((len(pts), 2, g.dims[0] * g.dims[1] * g.dims[2]), dtype=torch.int32, device=pts[0].device)
+        if nhwc_dtype is not None:
+            return ops.voxelize_batch_nhwc(nhwc_dtype, pts, g.lim, g.aff, g.dims, owner, out)
         return ops.voxelize_batch(pts, g.lim, g.aff, g.dims, owner, out)
 
     def project(self, lidar_points, crt=None):

@@ -327,7 +327,8 @@ class Plan(object):
             fmap = self._image_forward(K, x_image, save)
         if geom is not None and geom.get("voxel_event") is not None:
             K.wait_event(geom["voxel_event"])          # voxel grid produced on the geometry side stream
-        x = K.nchw_to_nhwc(x_lidar)
+        # a 16-bit x_lidar is already the input image [B,L,W,Cz] (train.geometry_async: written by the voxeliser)
+        x = x_lidar if x_lidar.dtype != torch.float32 else K.nchw_to_nhwc(x_lidar)
         outs = []
         for si, blocks in enumerate(self.stages):
             for b in blocks:

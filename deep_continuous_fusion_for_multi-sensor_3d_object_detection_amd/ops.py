@@ -270,6 +270,17 @@ def voxelize_batch(pts_list, lim, aff, dims, owner_ws, out):
     return out
 
 
+def voxelize_batch_nhwc(dtype, pts_list, lim, aff, dims, owner_ws, out):
+    """The same grids as the engine's input image: out [B,L,W,Cz] in the compute dtype (= nchw_to_nhwc of voxelize_batch)."""
+    Cz, L, W = dims
+    B = len(pts_list)
+    ptrs = (ctypes.c_void_p * B)(*[_chk(p, "pts").data_ptr() for p in pts_list])
+    ns = (ctypes.c_int * B)(*[p.shape[0] for p in pts_list])
+    H.call("dcf_voxelize_batch_nhwc", dtype, ctypes.addressof(ptrs), ctypes.addressof(ns), B, H.host_f32(lim), H.host_f32(aff), Cz, L, W,
+           _chk(out, "out"), owner_ws, H.stream_ptr())
+    return out
+
+
 def project_filter(pts, lim, crt, ulim, vlim, mode=H.PROJ_COMPAT, n_out=None, want_src=False):
     """Returns (uv [n_out,2], xyz [n_out,3], count int32[1] (device), src or None); rows past count are zero."""
     n = pts.shape[0]

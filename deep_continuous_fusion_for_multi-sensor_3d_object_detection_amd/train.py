@@ -79,7 +79,14 @@ class Train(nn.Module):
         with torch.cuda.stream(self._side):
             pcs, uvs, cnts = [], [], []
             Cz, L, W = frame_geometry.grid.dims
-            x_lidar = torch.empty((len(points_list), Cz, L, W), dtype=torch.float32, device="cuda")
+            # 16-bit compute types: the voxeliser writes the engine's input image ([B,L,W,Cz] in that type) directly -- no fp32
+            # grid, no transpose (the model recognises it by its dtype); f32 keeps the reference's [B,Cz,L,W] grid
+            fast = self.model.dtype != 0 and frame_geometry.voxel_mode == 0 and len(points_list) <= 8
+            if fast:
+                from ._hip import torch_dtype
+                x_lidar = torch.empty((len(points_list), L, W, Cz), dtype=torch_dtype(self.model.dtype), device="cuda")
+            else:
+                x_lidar = torch.empty((len(points_list), Cz, L, W), dtype=torch.float32, device="cuda")
             # projection first: its valid-point counts go to the host (pinned, asynchronous) while the voxeliser and the KNN
             # still run; the engine sizes the per-point fusion tensors by them instead of max_num_pc (Plan._fusion_rows)
             for b, pts in enumerate(points_list):
@@ -89,7 +96,7 @@ class Train(nn.Module):
             cnt_host.copy_(torch.cat(cnts, 0), non_blocking=True)
             ev_cnt = torch.cuda.Event()
             ev_cnt.record()
-            frame_geometry.voxelize_batch(points_list, x_lidar)                  # grids written in place, frames side by side
+            frame_geometry.voxelize_batch(points_list, x_lidar, self.model.dtype if fast else None)   # written in place, frames side by side
             ev_vox = torch.cuda.Event()
             ev_vox.record()
             geom = None

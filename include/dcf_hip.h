@@ -69,12 +69,15 @@ int dcf_range_filter(const float *pts, int n, const float *lim, float *out_pts, 
 size_t dcf_voxelize_workspace_bytes(int Cz, int L, int W);
 int dcf_voxelize(const float *pts, int n, const float *lim, const float *aff, int Cz, int L, int W,
                  int mode, float *grid, void *owner_ws, dcf_stream_t stream);
-/* Compat-mode voxeliser for the B frames of a batch in one launch per round (the frames are independent; every round is
- * latency bound).  pts / n: HOST arrays of B device pointers / point counts; grids [B][Cz][L][W];
+/* Compat-mode voxeliser for the B frames of a batch (claim / gather / release, one launch each for all frames).  pts / n: HOST arrays of B device pointers / point counts; grids [B][Cz][L][W];
  * owner_ws: B * dcf_voxelize_workspace_bytes(Cz,L,W), zero on entry, returned zero.  Same results as B dcf_voxelize calls. */
 #define DCF_MAX_VOXEL_BATCH 8
 int dcf_voxelize_batch(const float *const *pts, const int *n, int B, const float *lim, const float *aff, int Cz, int L, int W,
                        float *grids, void *owner_ws, dcf_stream_t stream);
+/* Same grids written as the engine's input image: x_nhwc [B][L][W][Cz] in `dtype` (what dcf_nchw_to_nhwc makes of the fp32
+ * grids, bit for bit: a voxel's value is produced in one piece and rounded once).  Saves the fp32 grid and its transpose. */
+int dcf_voxelize_batch_nhwc(int dtype, const float *const *pts, const int *n, int B, const float *lim, const float *aff, int Cz, int L,
+                            int W, void *x_nhwc, void *owner_ws, dcf_stream_t stream);
 
 /* Pinhole projection + in-image filter + compaction (data_import_carla.py:196-210,:261-266).
  * Raw points in; keeps points passing the range filter AND the image test, in order.

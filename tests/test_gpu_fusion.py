@@ -356,3 +356,22 @@ def test_graph_replay_with_side_stream_geometry_matches_eager():
     for (p0, g0), (p1, g1) in zip(res[False], res[True]):
         assert torch.allclose(p0, p1, rtol=1e-5, atol=1e-6)
         assert float((g0 - g1).abs().max()) < 2e-5 * float(g0.abs().max())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_voxel_image_fast_path_matches_fp32_grid_path(dtype):
+    """16-bit compute types: train.geometry_async hands the model the voxeliser's [B,L,W,Cz] image instead of the fp32
+    [B,Cz,L,W] grid; the prediction must be the same bit for bit."""
+    cfg, pts, img, crt = setup(dtype)
+    trainer = pkg("train").Train(cfg)
+    pkg("detfill").fill_state_dict(trainer.model)
+    geo = pkg("data_import_carla").FrameGeometry(cfg, crt)
+    dev_pts = [torch.from_numpy(p).cuda() for p in pts]
+    with torch.no_grad():
+        x_lidar, geom = trainer.geometry_async(geo, dev_pts)
+        assert x_lidar.dtype != torch.float32 and x_lidar.shape[-1] == cfg["voxel_channel"]
+        a = trainer.model(x_lidar, img.cuda(), geom=geom)
+        grids = torch.stack([geo.voxelize(p) for p in dev_pts])
+        x2, geom2 = trainer.geometry_async(geo, dev_pts)
+        b = trainer.model(grids, img.cuda(), geom=geom2)
+    assert torch.equal(a, b)

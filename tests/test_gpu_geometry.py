@@ -204,16 +204,18 @@ def test_voxelize_batch_equals_per_frame():
         assert torch.equal(out[b].view(torch.int32), lit.view(torch.int32))
 
 
-@pytest.mark.parametrize("case", ["dense", "clustered", "one_cell", "edges"])
+@pytest.mark.parametrize("case", ["dense", "clustered", "one_cell", "edges", "tight_limits"])
 def test_voxel_cell_formulation_equals_nine_rounds(case):
     """The three-launch compat voxeliser (last point of every CELL decides all eight passes; each cell winner evaluates the
     ordered sums of its corners) against the literal nine rounds (claim pass c / resolve pass c-1), bit for bit, on clouds
     with many points per cell, shared voxels between neighbouring cells and points on the range limits."""
     ops, H, det = pkg("ops"), pkg("_hip"), pkg("detfill")
-    cfg = golden_cfg(load_golden("geometry_carla.npz"))
+    # tight_limits: the tiny model grid leaves less than one cell of margin in y, so a corner index runs one past the end of
+    # a row -- on the flattened grid that is the first voxel of the next row, in both formulations and in the CPU restatement
+    cfg = golden_cfg(load_golden("model_tiny.npz" if case == "tight_limits" else "geometry_carla.npz"))
     g = _spec(cfg)
     lim6 = (cfg["lidar_x_min"], cfg["lidar_x_max"], cfg["lidar_y_min"], cfg["lidar_y_max"], cfg["lidar_z_min"], cfg["lidar_z_max"])
-    if case == "dense":
+    if case in ("dense", "tight_limits"):
         p = det.synthetic_points(60000, lim6, 5)
     elif case == "clustered":                       # 40 k points inside a 2 m cube: dozens of points per cell
         p = det.synthetic_points(40000, lim6, 6)
@@ -229,3 +231,23 @@ def test_voxel_cell_formulation_equals_nine_rounds(case):
     a = ops.voxelize(pts, g.lim, g.aff, g.dims, H.VOXEL_COMPAT)
     b = ops.voxelize(pts, g.lim, g.aff, g.dims, H.VOXEL_COMPAT_ROUNDS)
     assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and float(a.sum()) > 0
+
+
+@pytest.mark.parametrize("dtype", [1, 2, 0])
+def test_voxelize_batch_nhwc_equals_transposed_grid(dtype):
+    """dcf_voxelize_batch_nhwc writes the engine's input image directly; it must equal dcf_nchw_to_nhwc of the fp32 grids."""
+    ops, det = pkg("ops"), pkg("detfill")
+    cfg = golden_cfg(load_golden("geometry_carla.npz"))
+    g = _spec(cfg)
+    lim6 = (cfg["lidar_x_min"], cfg["lidar_x_max"], cfg["lidar_y_min"], cfg["lidar_y_max"], cfg["lidar_z_min"], cfg["lidar_z_max"])
+    frames = [torch.from_numpy(det.synthetic_points(n, lim6, 80 + i)).cuda() for i, n in enumerate((9000, 30000))]
+    Cz, L, W = g.dims
+    owner = torch.zeros((2, 2, Cz * L * W), dtype=torch.int32, device="cuda")
+    grids = torch.empty((2, Cz, L, W), device="cuda")
+    ops.voxelize_batch(frames, g.lim, g.aff, g.dims, owner, grids)
+    want = ops.nchw_to_nhwc(grids, dtype)
+    tdt = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[dtype]
+    got = torch.full((2, L, W, Cz), 7.0, dtype=tdt, device="cuda")
+    ops.voxelize_batch_nhwc(dtype, frames, g.lim, g.aff, g.dims, owner, got)
+    assert int(owner.abs().max()) == 0
+    assert torch.equal(got.view(torch.int32 if dtype == 0 else torch.int16), want.view(torch.int32 if dtype == 0 else torch.int16))
