@@ -470,12 +470,23 @@ __global__ void __launch_bounds__(256) k_knn_search(const int *count, int n_max,
     top.clear();
     bool done = !inside;
 
-    auto scan_range = [&](int b, int e, bool take) {
-        for (int p = b; p < e; ++p) {
-            const float4 q = sorted[p];                       // wave-uniform address
-            const float dx = __fsub_rn(q.x, X), dy = __fsub_rn(q.y, Y);
+    // candidates reach the lanes as register broadcasts: the wave loads up to 64 points with ONE vector load and then
+    // hands them round with v_readlane (a dependent scalar load per point leaves the wave waiting on memory per point)
+    auto offer = [&](const float4 &mine, int n, bool take) {
+        for (int u = 0; u < n; ++u) {
+            const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), u));
+            const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), u));
+            const int qi = __builtin_amdgcn_readlane(__float_as_int(mine.z), u);
+            const float dx = __fsub_rn(qx, X), dy = __fsub_rn(qy, Y);
             const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
-            if (take && !(rmax2 >= 0.0f && d2 > rmax2)) top.insert(d2, __float_as_int(q.z));
+            if (take && !(rmax2 >= 0.0f && d2 > rmax2)) top.insert(d2, qi);
+        }
+    };
+    auto scan_range = [&](int b, int e, bool take) {
+        for (int p0 = b; p0 < e; p0 += 64) {
+            const int n = min(64, e - p0);
+            const float4 mine = lane < n ? sorted[p0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+            offer(mine, n, take);
         }
     };
 
@@ -494,11 +505,29 @@ __global__ void __launch_bounds__(256) k_knn_search(const int *count, int n_max,
                 ps = cellstart[cell_key(ci, c0, g)];
                 pe = cellstart[cell_key(ci, c1, g) + 1];
             }
-            unsigned long long live = __ballot(pe > ps);
-            while (live) {
-                const int l = __ffsll((long long)live) - 1;
-                live &= live - 1;
-                scan_range(__builtin_amdgcn_readlane(ps, l), __builtin_amdgcn_readlane(pe, l), !done);
+            // segmented gather: the (short) ranges are concatenated -- slot t of the concatenation belongs to the range r with
+            // start_r <= t < start_r + len_r -- so the whole window arrives with one vector load per 64 points
+            const int len = pe - ps;
+            int inc = len;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += v;
+            }
+            const int total = __builtin_amdgcn_readlane(inc, 63);
+            const int exc = inc - len;
+            for (int base = 0; base < total; base += 64) {
+                const int t = base + lane;
+                int src = 0;
+                for (int rr = 0; rr < 36; ++rr) {
+                    const int l_r = __builtin_amdgcn_readlane(len, rr);
+                    if (l_r == 0) continue;
+                    const int s_r = __builtin_amdgcn_readlane(exc, rr), p_r = __builtin_amdgcn_readlane(ps, rr);
+                    if (t >= s_r && t < s_r + l_r) src = p_r + (t - s_r);
+                }
+                const int n = min(64, total - base);
+                const float4 mine = lane < n ? sorted[src] : make_float4(0.f, 0.f, 0.f, 0.f);
+                offer(mine, n, !done);
             }
         }
         {
