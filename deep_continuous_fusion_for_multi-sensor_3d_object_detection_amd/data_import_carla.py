@@ -80,13 +80,19 @@ class FrameGeometry(object):
             return ops.voxelize_batch_nhwc(nhwc_dtype, pts, g.lim, g.aff, g.dims, owner, out)
         return ops.voxelize_batch(pts, g.lim, g.aff, g.dims, owner, out)
 
-    def project(self, lidar_points, crt=None):
+    def project(self, lidar_points, crt=None, out=None):
         """(pointcloud_raw [max_num_pc,3], uv [max_num_pc,2], n_valid int32[1] on device) of one frame
-        (data_import_carla.py:196-210, :262-266).  crt: this frame's own [4,3] matrix (KITTI calibrates per frame)."""
+        (data_import_carla.py:196-210, :262-266).  crt: this frame's own [4,3] matrix (KITTI calibrates per frame).
+        out: (xyz [max_num_pc,3], uv [max_num_pc,2], count [1]) zero-filled slices of a batch tensor to write into (used
+        when the frame has at most max_num_pc points)."""
         pts = self._pts(lidar_points)
         ulim, vlim = self.limits()
-        n_out = max(int(self.config["max_num_pc"]), pts.shape[0])
+        mp_ = int(self.config["max_num_pc"])
         crt = self.crt if crt is None else np.ascontiguousarray(crt, dtype=np.float32)
+        if out is not None and pts.shape[0] <= mp_:
+            ops.project_filter(pts, self.grid.lim, crt, ulim, vlim, self.proj_mode, n_out=mp_, out=(out[1], out[0], out[2]))
+            return out
+        n_out = max(mp_, pts.shape[0])
         uv, xyz, cnt, _ = ops.project_filter(pts, self.grid.lim, crt, ulim, vlim, self.proj_mode, n_out=n_out)
         mp = int(self.config["max_num_pc"])
         return xyz[:mp], uv[:mp], cnt

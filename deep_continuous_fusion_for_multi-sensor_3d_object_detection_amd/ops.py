@@ -281,17 +281,24 @@ def voxelize_batch_nhwc(dtype, pts_list, lim, aff, dims, owner_ws, out):
     return out
 
 
-def project_filter(pts, lim, crt, ulim, vlim, mode=H.PROJ_COMPAT, n_out=None, want_src=False):
-    """Returns (uv [n_out,2], xyz [n_out,3], count int32[1] (device), src or None); rows past count are zero."""
+def project_filter(pts, lim, crt, ulim, vlim, mode=H.PROJ_COMPAT, n_out=None, want_src=False, out=None):
+    """Returns (uv [n_out,2], xyz [n_out,3], count int32[1] (device), src or None); rows past count are zero.
+    out: optional (uv, xyz, count) to write into -- zero-filled, contiguous, at least as many rows as input points (a
+    batch's frames then land side by side in one tensor without a stack copy)."""
     n = pts.shape[0]
     dev = pts.device
     n_out = n if n_out is None else n_out
     if n_out < n:
         raise H.DcfError("project_filter: output rows (%d) < input points (%d)" % (n_out, n))
-    uv = torch.zeros((max(n_out, 1), 2), dtype=torch.float32, device=dev)
-    xyz = torch.zeros((max(n_out, 1), 3), dtype=torch.float32, device=dev)
+    if out is not None:
+        uv, xyz, cnt = out
+        if uv.shape[0] < n or xyz.shape[0] < n or not (uv.is_contiguous() and xyz.is_contiguous()):
+            raise H.DcfError("project_filter: out tensors must be contiguous with at least %d rows" % n)
+    else:
+        uv = torch.zeros((max(n_out, 1), 2), dtype=torch.float32, device=dev)
+        xyz = torch.zeros((max(n_out, 1), 3), dtype=torch.float32, device=dev)
+        cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
     src = torch.empty((max(n, 1),), dtype=torch.int32, device=dev) if want_src else None
-    cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
     ws = torch.empty((H.lib().dcf_compact_workspace_bytes(n),), dtype=torch.uint8, device=dev)
     H.call("dcf_project_filter", _chk(pts, "pts"), n, H.host_f32(lim), H.host_f32(crt).reshape(-1), float(ulim), float(vlim), mode,
            uv, xyz, src, cnt, ws, H.stream_ptr())

@@ -89,11 +89,20 @@ class Train(nn.Module):
                 x_lidar = torch.empty((len(points_list), Cz, L, W), dtype=torch.float32, device="cuda")
             # projection first: its valid-point counts go to the host (pinned, asynchronous) while the voxeliser and the KNN
             # still run; the engine sizes the per-point fusion tensors by them instead of max_num_pc (Plan._fusion_rows)
+            # the frames' projections land side by side in batch tensors (no per-frame allocations, no stack copies)
+            Bn, mp = len(points_list), int(frame_geometry.config["max_num_pc"])
+            xyz_all = torch.zeros((Bn, mp, 3), dtype=torch.float32, device="cuda")
+            uv_all = torch.zeros((Bn, mp, 2), dtype=torch.float32, device="cuda")
+            cnt_all = torch.zeros((Bn,), dtype=torch.int32, device="cuda")
+            direct = True
             for b, pts in enumerate(points_list):
-                pc, uv, cnt = frame_geometry.project(pts, crt=None if crts is None else crts[b])
+                pc, uv, cnt = frame_geometry.project(pts, crt=None if crts is None else crts[b],
+                                                     out=(xyz_all[b], uv_all[b], cnt_all[b:b + 1]))
+                direct = direct and pc.data_ptr() == xyz_all[b].data_ptr()
                 pcs.append(pc); uvs.append(uv); cnts.append(cnt)
+            cnt_dev = cnt_all if direct else torch.cat(cnts, 0)
             cnt_host = torch.empty(len(points_list), dtype=torch.int32).pin_memory()
-            cnt_host.copy_(torch.cat(cnts, 0), non_blocking=True)
+            cnt_host.copy_(cnt_dev, non_blocking=True)
             ev_cnt = torch.cuda.Event()
             ev_cnt.record()
             frame_geometry.voxelize_batch(points_list, x_lidar, self.model.dtype if fast else None)   # written in place, frames side by side
@@ -101,7 +110,10 @@ class Train(nn.Module):
             ev_vox.record()
             geom = None
             if self.model.fusion_enabled:
-                geom = self.model.fusion_geometry(torch.stack(pcs, 0), torch.stack(uvs, 0), torch.cat(cnts, 0))
+                if direct:
+                    geom = self.model.fusion_geometry(xyz_all, uv_all, cnt_all)
+                else:                                   # a frame with more than max_num_pc points: the copying path
+                    geom = self.model.fusion_geometry(torch.stack(pcs, 0), torch.stack(uvs, 0), cnt_dev)
                 ev = torch.cuda.Event()
                 ev.record()
                 geom["event"] = ev
