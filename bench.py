@@ -157,7 +157,7 @@ def rocprof_kernel(name):
     if kind.startswith("conv_fwd") or kind.startswith("conv_dgrad") or kind.startswith("stem_fwd"):
         tr = "true" if "dgrad" in kind else "false"
         if t and t[-1].startswith("dma"):
-            return "k_conv_igemm_dma", [dt] + t[1:-1] + [tr, t[-1][3:]]
+            return "k_conv_igemm_dma", [dt] + t[:-1] + [tr, t[-1][3:]]
         db = "true" if (t and t[-1] == "db") else "false"
         return "k_conv_igemm", [dt] + [x for x in t if x != "db"] + [tr, db]
     return None

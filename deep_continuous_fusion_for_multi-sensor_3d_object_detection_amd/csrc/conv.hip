@@ -393,15 +393,21 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
 // LDS rows have no pad (the DMA image is lane-linear): 16-B chunk c of row R sits at position c ^ ((R >> 1) & 7), which
 // keeps the 16 rows of a ds_read_b128 lane group on distinct banks; the swizzle is applied to the source chunk and to the reads.
 // ------------------------------------------------------------------------------------
-template <typename T, int TN, int TM, int WN, int WM, bool TRANSPOSED, int NS>
+template <typename T, int KB, int TN, int TM, int WN, int WM, bool TRANSPOSED, int NS>
 __global__ void __launch_bounds__(256) k_conv_igemm_dma(ConvArgs a)
 {
     static_assert(DT<T>::size == 2, "16-bit element types only");
-    constexpr int ES = 2, KB = 128;
+    static_assert(KB == 128 || KB == 64, "K chunks of 128 or 64 bytes");
+    constexpr int ES = 2;
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
-    constexpr int PW = BN / 32, PX = BM / 32;          // DMA pieces (8 rows) per wave and chunk: weights, pixels
+    constexpr int RP = 1024 / KB, CR = KB / 16;        // rows per 1-KB DMA piece, 16-byte chunks per row
+    constexpr int PW = BN / RP / 4, PX = BM / RP / 4;  // DMA pieces per wave and chunk: weights, pixels
+    static_assert(PW >= 1 && PX >= 1, "tile too small for this chunk size");
     constexpr int PPW = PW + PX;
     constexpr int STAGE = (BN + BM) * KB;
+    // swizzle key of a row: KB 128 -> (R >> 1) & 7 (8 chunks per row), KB 64 -> (R >> 2) & 3 (4 chunks per row): the 16
+    // rows of a ds_read_b128 lane group then sit on distinct banks
+    auto rowkey = [](int R) { return KB == 128 ? ((R >> 1) & 7) : ((R >> 2) & 3); };
     static_assert((NS - 1) * PPW < 64, "vmcnt range");
     __shared__ __attribute__((aligned(1024))) char lds[NS * STAGE];
 
@@ -447,20 +453,20 @@ __global__ void __launch_bounds__(256) k_conv_igemm_dma(ConvArgs a)
     const unsigned lds0 = lds_addr(lds);
 
     // DMA side: wave w owns weight pieces w*PW.. and pixel pieces w*PX..; lane = (row l8 of the piece, position chunk lc)
-    const int l8 = lane >> 3, lc = lane & 7;
+    const int l8 = lane / CR, lc = lane % CR;
     unsigned woff[PW];
     int xb[PX], xh[PX], xw[PX];
     unsigned xoff[PX];
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
-        const int row = (wid * PW + i) * 8 + l8;
-        woff[i] = (unsigned)(n0 + row) * (unsigned)(taps * rowbytes) + (unsigned)((lc ^ ((row >> 1) & 7)) * 16);
+        const int row = (wid * PW + i) * RP + l8;
+        woff[i] = (unsigned)(n0 + row) * (unsigned)(taps * rowbytes) + (unsigned)((lc ^ rowkey(row)) * 16);
     }
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
-        const int row = (wid * PX + i) * 8 + l8;
+        const int row = (wid * PX + i) * RP + l8;
         const int m = out_pixel(m0 + row);
-        xoff[i] = (unsigned)((lc ^ ((row >> 1) & 7)) * 16);
+        xoff[i] = (unsigned)((lc ^ rowkey(row)) * 16);
         if (m >= 0) {
             const int b = m / (a.Ho * a.Wo);
             const int rem = m - b * (a.Ho * a.Wo);
@@ -522,7 +528,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm_dma(ConvArgs a)
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
     // read side: row r of every 32-row tile has swizzle key (r >> 1) & 7; k-step ks, lane half h wants source chunk 2 ks + h
-    const int key = (r >> 1) & 7;
+    const int key = rowkey(r);
     const int rdW = (wn * TN * 32 + r) * KB, rdX = BN * KB + (wm * TM * 32 + r) * KB;
     int swz[KB / 32];
 #pragma unroll
@@ -648,11 +654,11 @@ int launch_igemm(const ConvArgs &a_in, hipStream_t s, const char *base, double f
         if constexpr (ES == 2 && KB_ == 128) {                                                                      \
             if (dma_mode && (dma_mode == 2 || db)) {                                                                 \
                 snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d,dma%d>", base, KB_, TN_, TM_, WN_, WM_, NS_);        \
-                DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm_dma<T, TN_, TM_, WN_, WM_, TR, NS_>), grid, dim3(256), 0, s, a)); \
+                DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm_dma<T, 128, TN_, TM_, WN_, WM_, TR, NS_>), grid, dim3(256), 0, s, a)); \
                 launched = true;                                                                                    \
             } else if (dma_mode == 3) {   /* many workgroups: 2-deep ring keeps 2+ of them per CU */                  \
                 snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d,dma2>", base, KB_, TN_, TM_, WN_, WM_);              \
-                DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm_dma<T, TN_, TM_, WN_, WM_, TR, 2>), grid, dim3(256), 0, s, a)); \
+                DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm_dma<T, 128, TN_, TM_, WN_, WM_, TR, 2>), grid, dim3(256), 0, s, a)); \
                 launched = true;                                                                                    \
             }                                                                                                       \
         }                                                                                                           \
