@@ -294,8 +294,11 @@ __global__ void __launch_bounds__(256) k_fusion_gather_bwd_pipe(const T *__restr
 // and one (L1-resident, the pairs of a point are adjacent) row read of P, all independent of each other -- no
 // idx -> point -> row chain, so a wave keeps 4 pairs' loads in flight and the kernel runs at memory rate instead of
 // one exposed latency per pixel.  A point's sum is flushed once per slice it appears in (fp32 atomics only there).
+// 16 waves per workgroup: the number of workgroups is capped (each ends with C x 4 same-address atomics on dW1d / db1), so
+// the waves that hide the gather latency have to come from inside the workgroup
+constexpr int FGI_THREADS = 1024;
 template <typename T, int CJ>
-__global__ void __launch_bounds__(256) k_fusion_gather_bwd_inv(const T *__restrict__ P, const float *__restrict__ xyz, const int *__restrict__ e_begin, const int *__restrict__ e_end,
+__global__ void __launch_bounds__(FGI_THREADS) k_fusion_gather_bwd_inv(const T *__restrict__ P, const float *__restrict__ xyz, const int *__restrict__ e_begin, const int *__restrict__ e_end,
                                                                const int *__restrict__ ent_pix, const int *__restrict__ ent_pt, FuseGeom g,
                                                                const float *__restrict__ w1d, const float *__restrict__ b1, int C,
                                                                const T *__restrict__ ghsum, float *gP, float *gw1d, float *gb1, int SL)
@@ -305,9 +308,9 @@ __global__ void __launch_bounds__(256) k_fusion_gather_bwd_inv(const T *__restri
     for (int i = threadIdx.x; i < C * 4; i += blockDim.x) sm[i] = 0.f;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (FGI_THREADS / 64) + (threadIdx.x >> 6));
     const int E0 = *e_begin, E = *e_end;
-    const int nwaves = gridDim.x * 4;                    // the grid is capped: a wave takes slices wave, wave + nwaves, ...
+    const int nwaves = gridDim.x * (FGI_THREADS / 64);   // the grid is capped: a wave takes slices wave, wave + nwaves, ...
     if (E0 + wave * SL < E) {                             // (fewer workgroups = fewer same-address atomics on dW1d / db1)
         float w0[CJ], w1[CJ], w2[CJ], bb[CJ], a0[CJ], a1[CJ], a2[CJ], ab[CJ], cur_acc[CJ];
 #pragma unroll
@@ -485,8 +488,8 @@ extern "C" int dcf_fusion_gather_bwd_inv(int dtype, const void *P, const float *
     const int waves = cdiv(max_entries, sl);
     static const char *cap_env = getenv("DCF_FUSION_BWD_BLOCKS");
     const int cap = cap_env ? atoi(cap_env) : 256;     // swept: 128 / 256 / 512 / uncapped = 0.52 / 0.34 / 0.36 / 0.44 ms per step
-    const int blocks = std::min(cdiv(waves, 4), cap);
-#define DCF_FGI(CJ_) DCF_LAUNCH("fusion_gather_bwd_inv", s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_>), dim3(blocks), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, sl))
+    const int blocks = std::min(cdiv(waves, FGI_THREADS / 64), cap);
+#define DCF_FGI(CJ_) DCF_LAUNCH("fusion_gather_bwd_inv", s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_>), dim3(blocks), dim3(FGI_THREADS), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, sl))
     DCF_DISPATCH_DTYPE(dtype, {
         if (Cb == 64) DCF_FGI(1);
         else if (Cb == 128) DCF_FGI(2);
