@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libdcf_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16, F16 = 0, 1, 2
-VOXEL_COMPAT, VOXEL_ACCUM, VOXEL_COMPAT_ROUNDS = 0, 1, 2
+VOXEL_COMPAT, VOXEL_ACCUM, VOXEL_COMPAT_ROUNDS, VOXEL_OCCUPANCY = 0, 1, 2, 3
 PROJ_COMPAT, PROJ_CORRECT = 0, 1
 
 c_int, c_float, c_i64, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p
@@ -40,6 +40,7 @@ SIGNATURES = {
     "dcf_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dcf_knn_bev": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, P, P, P]),
     "dcf_nchw_to_nhwc": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P]),
+    "dcf_nhwc_to_nchw": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "dcf_image_to_nhwc4": (c_int, [c_int, P, P, c_int, c_int, c_int, P]),
     "dcf_conv2d_fwd": (c_int, [c_int, P, P, P, P, P] + [c_int] * 12 + [P]),
     "dcf_conv2d_dgrad": (c_int, [c_int, P, P, P, P, P] + [c_int] * 11 + [P]),

@@ -101,12 +101,15 @@ class HipBackend(object):
         return self._wbase + (L.wdgrad_off if dgrad else L.wfwd_off)
 
     def set_bn_mode(self, train):
+        """Returns True when the mode changed (callers drop whatever they captured under the old one)."""
         train = bool(train)
-        if train != self.bn_train:
-            self.bn_train = train
-            self._upload_table(self.plan.layers)
-            self._sig = None
-            self.__dict__.pop("_bw_cache", None)      # cached tables describe the other BN mode
+        if train == self.bn_train:
+            return False
+        self.bn_train = train
+        self._upload_table(self.plan.layers)
+        self._sig = None
+        self.__dict__.pop("_bw_cache", None)      # cached tables describe the other BN mode
+        return True
 
     def _shift(self, L):
         if L.bn is None or self.bn_train:
@@ -290,6 +293,9 @@ class HipBackend(object):
         if x.dtype != torch.float32:
             raise H.DcfError("x_lidar must be float32 [B,Cz,L,W] (model.py:194)")
         return ops.nchw_to_nhwc(x.contiguous(), self.dtype)
+
+    def nhwc_to_nchw(self, x):
+        return ops.nhwc_to_nchw(x, self.dtype)
 
     def image_to_nhwc4(self, img):
         if img.dtype != torch.uint8:

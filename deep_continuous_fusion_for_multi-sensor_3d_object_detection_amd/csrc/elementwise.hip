@@ -33,6 +33,23 @@ __global__ void __launch_bounds__(256) k_nchw_to_nhwc(const float *x, T *y, int 
     }
 }
 
+// NHWC (compute type) -> NCHW fp32: the way back, for module surfaces that hand activations to torch code in the
+// reference's layout (model.py:76-79 returns NCHW stage outputs).  One thread per pixel: channel rows are read 4 at a time,
+// the stores of a wave are 64 consecutive pixels of one channel plane.
+template <typename T>
+__global__ void __launch_bounds__(256) k_nhwc_to_nchw(const T *x, float *y, int C, int64_t HW, int64_t total)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    const int64_t b = p / HW, q = p - b * HW;
+    const T *src = x + p * C;
+    float *dst = y + b * C * HW + q;
+    for (int c0 = 0; c0 < C; c0 += 4) {
+        const float4 v = ld4(src + c0);
+        dst[(int64_t)c0 * HW] = v.x; dst[(int64_t)(c0 + 1) * HW] = v.y; dst[(int64_t)(c0 + 2) * HW] = v.z; dst[(int64_t)(c0 + 3) * HW] = v.w;
+    }
+}
+
 // uint8 NCHW -> x/255 NHWC4 with a 3-pixel zero halo (rows and columns), row pitch (W+8)
 // pixels so that rows stay 16-B aligned in bf16.  Image tensor contract: data_import_carla.py:62.
 template <typename T>
@@ -851,6 +868,15 @@ extern "C" int dcf_nchw_to_nhwc(int dtype, const float *x, void *y, int B, int C
         if (C % 8 == 0) DCF_LAUNCH("nchw_to_nhwc", s, hipLaunchKernelGGL((k_nchw_to_nhwc<T, 8>), dim3(cdiv(total, 256)), dim3(256), 0, s, x, (T *)y, C, HW, total));
         else DCF_LAUNCH("nchw_to_nhwc", s, hipLaunchKernelGGL((k_nchw_to_nhwc<T, 4>), dim3(cdiv(total, 256)), dim3(256), 0, s, x, (T *)y, C, HW, total));
     })
+    return DCF_OK;
+}
+
+extern "C" int dcf_nhwc_to_nchw(int dtype, const void *x, float *y, int B, int C, int H, int W, dcf_stream_t stream)
+{
+    DCF_REQUIRE(x && y && C % 4 == 0, "dcf_nhwc_to_nchw: C must be a multiple of 4");
+    const int64_t HW = (int64_t)H * W, total = (int64_t)B * HW;
+    hipStream_t s = S(stream);
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("nhwc_to_nchw", s, hipLaunchKernelGGL(k_nhwc_to_nchw<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, y, C, HW, total)); })
     return DCF_OK;
 }
 

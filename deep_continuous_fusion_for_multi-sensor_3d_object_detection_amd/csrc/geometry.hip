@@ -10,6 +10,7 @@
 // Bit-exactness contract (checked against oracle/dcf_oracle.c): this file is
 // compiled with -ffp-contract=off and spells every fused step as __fmaf_rn, so each
 // product/sum rounds exactly where the reference's CPU arithmetic rounds.
+#include <stdlib.h>
 #include "dcf_common.h"
 
 namespace {
@@ -327,6 +328,19 @@ __global__ void __launch_bounds__(256) k_voxel_accum(const float *pts, int n, Li
     corners(x, y, z, aff, L, W, c8);
 #pragma unroll
     for (int c = 0; c < 8; ++c) atomicAdd(&grid[c8.vox[c]], c8.w[c]);
+}
+
+// interpolate=False (data_import_carla.py:231-234): the voxel holding the point (trunc'd ids = lower corner) is set to 1;
+// every writer stores the same value, so the result does not depend on the order
+__global__ void __launch_bounds__(256) k_voxel_occupancy(const float *pts, int n, Lim6 lim, Aff6 aff, int L, int W, float *grid)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    if (!in_range(x, y, z, lim)) return;
+    Corner8 c8;
+    corners(x, y, z, aff, L, W, c8);
+    grid[c8.vox[0]] = 1.0f;
 }
 
 // ------------------------------------------------------------------------------
@@ -878,6 +892,8 @@ extern "C" int dcf_voxelize(const float *pts, int n, const float *lim, const flo
                                                                    grid, (int *)owner_ws));
     } else if (mode == DCF_VOXEL_ACCUM) {
         DCF_LAUNCH("voxel_accum", s, hipLaunchKernelGGL(k_voxel_accum, dim3(nb), dim3(256), 0, s, pts, n, l, a, L, W, grid));
+    } else if (mode == DCF_VOXEL_OCCUPANCY) {
+        DCF_LAUNCH("voxel_occupancy", s, hipLaunchKernelGGL(k_voxel_occupancy, dim3(nb), dim3(256), 0, s, pts, n, l, a, L, W, grid));
     } else {
         dcf_set_error("dcf_voxelize: unknown mode %d", mode);
         return DCF_EINVAL;
@@ -978,7 +994,10 @@ extern "C" int dcf_knn_bev(const float *xyz, const int32_t *count_dev, int n_max
         DCF_LAUNCH("knn_fill", s, hipLaunchKernelGGL(k_knn_fill, dim3(nb), dim3(256), 0, s, xyz, count_dev, n_max, pkey, cursor, sorted));
     }
     const int nbp = cdiv(g.h8 * g.w8, 4);   // one wave per 8x8 pixel tile
-    const bool per_wave = (h * w <= 20000);   // coarse sites: one wave per pixel (lanes split the candidates)
+    // coarse sites: one wave per pixel (lanes split the candidates).  DCF_KNN_KERNEL = wave | tile forces one of the two
+    // kernels (read per call: the parity tests compare them on the same site; both produce the exact (d2, index) order)
+    const char *force = getenv("DCF_KNN_KERNEL");
+    const bool per_wave = force && force[0] == 'w' ? true : (force && force[0] == 't' ? false : (h * w <= 20000));
     const int nbw = cdiv(h * w, 4);
 #define KNN_CASE(KK)                                                                                                     \
     case KK:                                                                                                             \

@@ -29,7 +29,10 @@ class FrameGeometry(object):
         self.config = config
         self.grid = ops.GridSpec(config)
         self.crt = calib.carla_crt() if crt is None else np.ascontiguousarray(crt, dtype=np.float32)
-        self.voxel_mode = H.VOXEL_COMPAT if config.get("voxel_mode", "compat") == "compat" else H.VOXEL_ACCUM
+        modes = {"compat": H.VOXEL_COMPAT, "accum": H.VOXEL_ACCUM, "occupancy": H.VOXEL_OCCUPANCY}
+        if config.get("voxel_mode", "compat") not in modes:
+            raise ValueError("voxel_mode must be one of %s" % sorted(modes))
+        self.voxel_mode = modes[config.get("voxel_mode", "compat")]
         self.proj_mode = H.PROJ_COMPAT if config.get("projection_mode", "compat") == "compat" else H.PROJ_CORRECT
         self._owner = None
 
@@ -42,12 +45,14 @@ class FrameGeometry(object):
     def _pts(self, lidar_points):
         return lidar_points.to(device="cuda", dtype=torch.float32).contiguous()
 
-    def voxelize(self, lidar_points, voxel_out=None):
-        """Voxel grid [Cz,L,W] of one frame (data_import_carla.py:236-258), optionally written into voxel_out."""
+    def voxelize(self, lidar_points, voxel_out=None, mode=None):
+        """Voxel grid [Cz,L,W] of one frame (data_import_carla.py:231-258), optionally written into voxel_out.
+        mode: override of the configured voxel mode (H.VOXEL_OCCUPANCY = the reference's interpolate=False)."""
         pts = self._pts(lidar_points)
         g = self.grid
         owner = None
-        if self.voxel_mode == H.VOXEL_COMPAT:
+        mode = self.voxel_mode if mode is None else mode
+        if mode == H.VOXEL_COMPAT:
             # one owner-map workspace per (device, stream): frames voxelised on different streams must not share it
             key = (pts.device, H.stream_ptr())
             if self._owner is None:
@@ -55,7 +60,7 @@ class FrameGeometry(object):
             owner = self._owner.get(key)
             if owner is None:
                 owner = self._owner[key] = torch.zeros((2, g.dims[0] * g.dims[1] * g.dims[2]), dtype=torch.int32, device=pts.device)
-        return ops.voxelize(pts, g.lim, g.aff, g.dims, self.voxel_mode, owner, voxel_out)
+        return ops.voxelize(pts, g.lim, g.aff, g.dims, mode, owner, voxel_out)
 
     def voxelize_batch(self, points_list, out, nhwc_dtype=None):
         """Voxel grids of the frames of a batch written into out [B,Cz,L,W] fp32 -- or, with nhwc_dtype (a dtype code), into
@@ -97,12 +102,12 @@ class FrameGeometry(object):
         mp = int(self.config["max_num_pc"])
         return xyz[:mp], uv[:mp], cnt
 
-    def __call__(self, lidar_points, want_ids=False, voxel_out=None):
+    def __call__(self, lidar_points, want_ids=False, voxel_out=None, voxel_mode=None):
         """lidar_points [N,3] f32 (any device) -> (voxel [Cz,L,W], pointcloud_raw [max_num_pc,3],
         uv [max_num_pc,2], n_valid int32[1] on device, ids or None).  voxel_out: optional [Cz,L,W] slice of a
         batch tensor to write the grid into (saves the stack copy)."""
         pts = self._pts(lidar_points)
-        voxel = self.voxelize(pts, voxel_out)
+        voxel = self.voxelize(pts, voxel_out, voxel_mode)
         xyz, uv, cnt = self.project(pts)
         ids = None
         if want_ids:
@@ -199,9 +204,9 @@ class CarlaDataset(Dataset):
         return obj, lidar, image
 
     def Voxelization_Projection(self, lidar_data, interpolate=True):
-        if not interpolate:
-            raise NotImplementedError("occupancy (non-interpolated) voxels: data_import_carla.py:231-234 is not on the hot path")
-        voxel, pc, uv, cnt, ids = self.geometry(lidar_data, want_ids=self.want_bev_image)
+        """interpolate=False: occupancy grid (the voxel of the trunc'd ids := 1, data_import_carla.py:231-234)."""
+        voxel, pc, uv, cnt, ids = self.geometry(lidar_data, want_ids=self.want_bev_image,
+                                                voxel_mode=None if interpolate else H.VOXEL_OCCUPANCY)
         return voxel, pc, uv, cnt, ids
 
     def getLidarImage(self, in_range_points):

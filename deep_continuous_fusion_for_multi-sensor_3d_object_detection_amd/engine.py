@@ -167,11 +167,78 @@ class Bottleneck(object):
         return K.conv_dgrad(self.conv1, g1, tuple(x.shape), g3, pm)
 
 
+class StackPlan(object):
+    """Residual stages on their own: the execution plan behind the reference's ResidualBlock / ResidualBlockModule /
+    ResnetCustomed module surfaces (model.py:10-79).  stages = list (stage) of lists (block) of (key prefix, cin, cout);
+    taps = indices of the stages whose outputs are returned, in return order.  Input and outputs are NCHW fp32 like the
+    reference's; inside, the same Block objects and kernels as the full network."""
+
+    def __init__(self, stages, taps):
+        self.table = ParamTable()
+        self.layers = []
+        self.stages = []
+        self.taps = list(taps)
+        for blocks in stages:
+            bl = []
+            for pfx, ci, co in blocks:
+                if ci % 32 or co % 32:
+                    raise ValueError("channel counts must be multiples of 32 (MFMA 32x32 tiles)")
+                s = 2 if ci != co else 1                               # model.py:14-19, :43-45
+                c1 = self._conv(pfx + "conv1", ci, co, (3, 3), s, pfx + "bn1")
+                c2 = self._conv(pfx + "conv2", co, co, (3, 3), 1, pfx + "bn2")
+                dn = self._conv(pfx + "down_conv", ci, co, (1, 1), 2, pfx + "down_bn") if ci != co else None
+                bl.append(Block(c1, c2, dn))
+            for a_, b_ in zip(bl[:-1], bl[1:]):
+                a_.next_conv = b_.conv1
+            self.stages.append(bl)
+        for t in self.taps:
+            if t != len(self.stages) - 1 and self.stages[t + 1][0].down is None:
+                raise NotImplementedError("an intermediate output joins the backward through the next stage's shortcut convolution")
+        self.ctx = None
+
+    def forward(self, K, x_nchw, save=True):
+        x = K.nchw_to_nhwc(x_nchw)
+        outs = {}
+        for si, blocks in enumerate(self.stages):
+            for b in blocks:
+                x = b.forward(K, x, save)
+            outs[si] = x
+        self.ctx = True if save else None
+        return [K.nhwc_to_nchw(outs[t]) for t in self.taps]
+
+    def backward(self, K, gouts):
+        """gouts: gradients of the returned outputs (NCHW fp32, None = no gradient).  Returns dL/dx NCHW fp32."""
+        if not self.ctx:
+            raise RuntimeError("backward through a forward that ran without saving activations")
+        self.ctx = None
+        K.begin_backward(self.layers)
+        gmap = dict((t, K.nchw_to_nhwc(g.contiguous())) for t, g in zip(self.taps, gouts) if g is not None)
+        g, masked = None, False
+        for si in range(len(self.stages) - 1, -1, -1):
+            blocks = self.stages[si]
+            if g is None:
+                g, masked = gmap.get(si), False
+                if g is None:                       # nothing downstream of this stage carries a gradient
+                    for b in blocks:
+                        b.saved = None
+                    continue
+            for bi in range(len(blocks) - 1, -1, -1):
+                extra = gmap.get(si - 1) if bi == 0 else None
+                prev = blocks[bi - 1] if bi > 0 else (self.stages[si - 1][-1] if si > 0 else None)
+                g = blocks[bi].backward(K, g, extra, need_gx=True, g_masked=masked, prev=prev)
+                masked = prev is not None
+        K.end_backward(self.layers)
+        return None if g is None else K.nhwc_to_nchw(g)
+
+
 IMAGE_ARCHS = {   # name -> (block kind, blocks per layer, base widths, channel expansion)
     "resnet18": ("basic", (2, 2, 2, 2), (64, 128, 256, 512), 1),
     "resnet34": ("basic", (3, 4, 6, 3), (64, 128, 256, 512), 1),
     "resnet50": ("bottleneck", (3, 4, 6, 3), (64, 128, 256, 512), 4),
 }
+
+
+StackPlan._conv = None     # bound below to Plan._conv (same layer / parameter bookkeeping)
 
 
 class Plan(object):
@@ -523,3 +590,6 @@ class Plan(object):
             return None
         self.ctx.pop("fuse_gfp", None)
         return K.point_sample_bwd(gfp.view(B, n_max, -1), geom["uv"], geom["cnt"], n_max, s["fmap_shape"], gF)
+
+
+StackPlan._conv = Plan._conv

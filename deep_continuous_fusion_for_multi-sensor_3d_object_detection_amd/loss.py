@@ -75,10 +75,13 @@ class LossTotal(nn.Module):
         half = int(span / 2)
         positives, regress, owner = [], [], []
         centres = boxes[:, :2].tolist() if hasattr(boxes, "tolist") else [(float(b[0]), float(b[1])) for b in boxes]
-        for bx, by in centres:              # python floats of the fp32 values, like float(box[0]) in the reference
+        f32 = np.float32
+        for bx, by in centres:
             members = []
-            cx = int((bx * self._xs + self._xo) / rs)
-            cy = int((by * self._ys + self._yo) / rs)
+            # the reference does this arithmetic on 0-dim fp32 tensors (loss.py:85-86): one fp32 rounding per operation, then
+            # truncation -- in double precision a centre within fp32 rounding of a cell boundary lands one cell lower
+            cx = int((f32(bx) * f32(self._xs) + f32(self._xo)) / f32(rs))
+            cy = int((f32(by) * f32(self._ys) + f32(self._yo)) / f32(rs))
             if 0 <= cx <= H - 1 and 0 <= cy <= W - 1:
                 for dx in range(span):
                     for dy in range(span):

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import _hip as H
-from .engine import ParamTable, Plan
+from .engine import ParamTable, Plan, StackPlan
 
 
 class AnchorBoundingBoxFeature(nn.Module):
@@ -112,6 +112,10 @@ class _GraphSet(object):
         pred = m._plan.forward(K, self.sx, self.simg, self.sgeom, save=True)
         m._plan.backward(K, torch.zeros_like(pred))
         torch.cuda.synchronize()
+        # the captured launches carry raw addresses of the backend's per-signature arenas (split-K slabs, dbeta sums, layer
+        # table) and of its weight images: this set keeps them alive for as long as its graphs can be replayed, whatever the
+        # backend's own cache evicts meanwhile
+        self._arenas = (K.slabs, K.gsum, K.table, K.warena, K.ssarena)
         self.g_img = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_img):
             K.prepare()
@@ -190,42 +194,21 @@ class _StepGraphs(object):
         st.g_bwd.replay()
 
 
-class ObjectDetection_DCF(nn.Module):
-    def __init__(self, config):
-        super(ObjectDetection_DCF, self).__init__()
-        self.config = config
-        fu = dict(config.get("fusion") or {})
-        self.fusion_enabled = bool(fu.get("enabled", False))
-        self.K = int(fu.get("K", 3))
-        self.r_max = fu.get("r_max", None)
-        self.cf = int(fu.get("image_channels", 64))
-        dt = config.get("dtype", "f32")
-        # "fp8": forward convolutions with Cin >= fp8_min_cin take e4m3 operands (csrc/conv_fp8.hip); storage, the
-        # backward and everything else are bf16 (BASELINE.json configs[4])
-        self.fp8 = dt in ("fp8", "f8", "e4m3")
-        self.dtype = H.dtype_code("bf16" if self.fp8 else dt)
-        # "eval": running statistics always -- what train.py effectively does (test.py:37 puts the trained module in
-        # eval mode before the first step, SURVEY.md F4); "train": batch statistics always; "module": follow
-        # nn.Module.training exactly like nn.BatchNorm2d would.
-        self.bn_mode = config.get("bn_mode", "eval")
-        if self.bn_mode not in ("eval", "train", "module"):
-            raise ValueError("bn_mode must be eval, train or module (got %r)" % (self.bn_mode,))
-        stream = fu.get("image_stream", "resnet18")
-        from .engine import IMAGE_ARCHS
-        if self.fusion_enabled and stream not in IMAGE_ARCHS:
-            raise NotImplementedError("image_stream=%r (one of %s)" % (stream, sorted(IMAGE_ARCHS)))
-        self.use_graphs = bool(config.get("hip_graphs", False))
-        self._graphs = None
-        self._plan = Plan(config, with_image=self.fusion_enabled, cf=self.cf, image_arch=str(fu.get("image_stream", "resnet18")))
+class _FlatParamModule(nn.Module):
+    """nn.Module whose Parameters are strided views of ONE flat fp32 arena laid out by an engine.ParamTable (gradients:
+    a second arena with the same offsets), registered under the reference's dotted state_dict names."""
+
+    @property
+    def _table(self):
+        return self._plan.table
+
+    def _on_moved(self):
+        """Device changed: drop everything that holds device addresses."""
         self._backend = None
-        self._build_parameters()
-        self.reset_parameters(zero_init_last=bool(fu.get("zero_init_last", False)))
-        from .ops import GridSpec
-        self._grid = GridSpec(config)
 
     # ------------------------------------------------------------------ parameters
     def _build_parameters(self, device="cpu"):
-        t = self._plan.table
+        t = self._table
         self._flat = torch.zeros(max(t.n_params, 4), dtype=torch.float32, device=device)
         self._gradflat = torch.zeros_like(self._flat)
         self._bufflat = torch.zeros(max(t.n_buffers, 4), dtype=torch.float32, device=device)
@@ -272,7 +255,7 @@ class ObjectDetection_DCF(nn.Module):
                 if len(shape) >= 2:
                     bound = 1.0 / math.sqrt(float(np.prod(shape[1:])))
                     p.uniform_(-bound, bound)
-            for (key, shape, off, n, layout), p in zip(self._plan.table.entries, self._param_list):
+            for (key, shape, off, n, layout), p in zip(self._table.entries, self._param_list):
                 leaf = key.split(".")[-1]
                 if len(shape) == 1 and leaf == "weight":
                     p.fill_(1.0)
@@ -299,13 +282,11 @@ class ObjectDetection_DCF(nn.Module):
         for key, shape, off, n in self._buf_meta:
             node, leaf = self._resolve(key)
             node._buffers[leaf] = self._bufflat[off:off + n].view(shape)
-        for key, shape, off, n in self._plan.table.buffers:
+        for key, shape, off, n in self._table.buffers:
             if key.endswith("num_batches_tracked"):
                 node, leaf = self._resolve(key)
                 node._buffers[leaf] = fn(node._buffers[leaf])
-        self._backend = None
-        self._graphs = None
-        self._plan._anc_key = None
+        self._on_moved()
         return self
 
     @property
@@ -320,12 +301,7 @@ class ObjectDetection_DCF(nn.Module):
         for p, (shape, off, n, layout) in zip(self._param_list, self._param_meta):
             p.grad = ParamTable.view(self._gradflat, shape, off, n, layout)
 
-    def load_state_dict(self, state_dict, strict=True):
-        """Accepts the reference's checkpoints with or without DDP's 'module.' prefix (train.py:79)."""
-        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
-        return super(ObjectDetection_DCF, self).load_state_dict(sd, strict=strict)
-
-    # flat views for the fused optimiser / gradient all-reduce (train.py)
+    # flat views for a fused optimiser / gradient all-reduce (train.py)
     @property
     def flat_params(self):
         return self._flat
@@ -333,6 +309,50 @@ class ObjectDetection_DCF(nn.Module):
     @property
     def flat_grads(self):
         return self._gradflat
+
+
+class ObjectDetection_DCF(_FlatParamModule):
+    def __init__(self, config):
+        super(ObjectDetection_DCF, self).__init__()
+        self.config = config
+        fu = dict(config.get("fusion") or {})
+        self.fusion_enabled = bool(fu.get("enabled", False))
+        self.K = int(fu.get("K", 3))
+        self.r_max = fu.get("r_max", None)
+        self.cf = int(fu.get("image_channels", 64))
+        dt = config.get("dtype", "f32")
+        # "fp8": forward convolutions with Cin >= fp8_min_cin take e4m3 operands (csrc/conv_fp8.hip); storage, the
+        # backward and everything else are bf16 (BASELINE.json configs[4])
+        self.fp8 = dt in ("fp8", "f8", "e4m3")
+        self.dtype = H.dtype_code("bf16" if self.fp8 else dt)
+        # "eval": running statistics always -- what train.py effectively does (test.py:37 puts the trained module in
+        # eval mode before the first step, SURVEY.md F4); "train": batch statistics always; "module": follow
+        # nn.Module.training exactly like nn.BatchNorm2d would.
+        self.bn_mode = config.get("bn_mode", "eval")
+        if self.bn_mode not in ("eval", "train", "module"):
+            raise ValueError("bn_mode must be eval, train or module (got %r)" % (self.bn_mode,))
+        stream = fu.get("image_stream", "resnet18")
+        from .engine import IMAGE_ARCHS
+        if self.fusion_enabled and stream not in IMAGE_ARCHS:
+            raise NotImplementedError("image_stream=%r (one of %s)" % (stream, sorted(IMAGE_ARCHS)))
+        self.use_graphs = bool(config.get("hip_graphs", False))
+        self._graphs = None
+        self._plan = Plan(config, with_image=self.fusion_enabled, cf=self.cf, image_arch=str(fu.get("image_stream", "resnet18")))
+        self._backend = None
+        self._build_parameters()
+        self.reset_parameters(zero_init_last=bool(fu.get("zero_init_last", False)))
+        from .ops import GridSpec
+        self._grid = GridSpec(config)
+
+    def _on_moved(self):
+        self._backend = None
+        self._graphs = None
+        self._plan._anc_key = None
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts the reference's checkpoints with or without DDP's 'module.' prefix (train.py:79)."""
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        return super(ObjectDetection_DCF, self).load_state_dict(sd, strict=strict)
 
     # ------------------------------------------------------------------ forward
     def _ensure_backend(self, device):
@@ -387,7 +407,8 @@ class ObjectDetection_DCF(nn.Module):
             if torch.is_grad_enabled():
                 self.fusion_inverse(geom)
         bn_train = self.bn_mode == "train" or (self.bn_mode == "module" and self.training)
-        K.set_bn_mode(bn_train)
+        if K.set_bn_mode(bn_train):
+            self._graphs = None          # captured graphs describe the other BatchNorm mode (other layer table, other kernels)
         if bn_train:
             for b in self._nbt:
                 b += 1
@@ -403,6 +424,113 @@ class ObjectDetection_DCF(nn.Module):
 
     def _profiling(self):
         return self.graphs_off
+
+
+class _RunStack(torch.autograd.Function):
+    """autograd bridge of a StackPlan (same role as _RunPlan): several outputs, gradient for the input too."""
+
+    @staticmethod
+    def forward(ctx, x, token, module, need):
+        ctx.module, ctx.saved_graph = module, need
+        outs = module._plan.forward(module._backend, x, save=need)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        m = ctx.module
+        if not ctx.saved_graph:
+            raise RuntimeError("backward through a forward that ran without saving activations")
+        gx = m._plan.backward(m._backend, list(gouts))
+        m._bind_grads()
+        return gx, None, None, None
+
+
+class _ResidualStack(_FlatParamModule):
+    """Common body of the reference's three backbone building blocks (model.py:10-79) on the HIP engine: NCHW fp32 in,
+    NCHW fp32 out, the reference's parameter names, forward and backward through the same Block kernels as the full network.
+    compute dtype: class attribute `dtype` ("f32" | "bf16" | "f16"), or the `dtype=` keyword; BatchNorm follows
+    .train()/.eval() like nn.BatchNorm2d (bn_mode "module"), or is pinned with bn_mode "eval" / "train"."""
+    dtype = "f32"
+    bn_mode = "module"
+
+    def _setup(self, stages, taps, dtype=None, bn_mode=None):
+        if dtype is not None:
+            self.dtype = dtype
+        if bn_mode is not None:
+            self.bn_mode = bn_mode
+        self._plan = StackPlan(stages, taps)
+        self._backend = None
+        self._build_parameters()
+        self.reset_parameters()
+
+    def _ensure_backend(self, device):
+        if self._backend is None or self._backend.dev != device:
+            if device.type != "cuda":
+                raise H.DcfError("%s runs on the HIP device only: move the module with .cuda() (no CPU fallback exists "
+                                 "for the hot path)" % type(self).__name__)
+            from .backend_hip import HipBackend
+            self._backend = HipBackend(self._plan, self._flat, self._gradflat, self._bufflat, H.dtype_code(self.dtype))
+        return self._backend
+
+    def _run(self, x):
+        K = self._ensure_backend(x.device)
+        bn_train = self.bn_mode == "train" or (self.bn_mode == "module" and self.training)
+        K.set_bn_mode(bn_train)
+        if bn_train:
+            for b in self._nbt:
+                b += 1
+        need = torch.is_grad_enabled() and (self._param_list[0].requires_grad or x.requires_grad)
+        K.prepare()
+        return _RunStack.apply(x.contiguous(), self._param_list[0], self, need)
+
+
+class ResidualBlock(_ResidualStack):
+    """model.py:10-45: relu(bn2(conv2(relu(bn1(conv1 x)))) + shortcut(x)); stride 2 and a 1x1 shortcut convolution exactly
+    when in_channels != out_channels.  Keys: conv1, bn1, conv2, bn2 (, down_conv, down_bn)."""
+
+    def __init__(self, in_channels, out_channels, dtype=None, bn_mode=None):
+        super(ResidualBlock, self).__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self._setup([[("", in_channels, out_channels)]], [0], dtype, bn_mode)
+
+    @property
+    def should_apply_shortcut(self):
+        return self.in_channels != self.out_channels
+
+    def forward(self, x):
+        return self._run(x)[0]
+
+
+class ResidualBlockModule(_ResidualStack):
+    """model.py:48-61: num_resblock ResidualBlocks, the first one first_in_channel -> last_out_channel.
+    Keys: sequential.resblock_<i>.*"""
+
+    def __init__(self, first_in_channel, last_out_channel, num_resblock, dtype=None, bn_mode=None):
+        super(ResidualBlockModule, self).__init__()
+        blocks = [("sequential.resblock_%d." % i, first_in_channel if i == 0 else last_out_channel, last_out_channel)
+                  for i in range(num_resblock)]
+        self._setup([blocks], [0], dtype, bn_mode)
+
+    def forward(self, x):
+        return self._run(x)[0]
+
+
+class ResnetCustomed(_ResidualStack):
+    """model.py:64-79: five ResidualBlockModules; returns (x4, x3, x2) = the outputs of layer5, layer4, layer3.
+    Keys: layer<k>.sequential.resblock_<i>.*"""
+
+    def __init__(self, out_feature=(32, 64, 128, 192, 256), num_res_block=(1, 2, 4, 6, 6), dtype=None, bn_mode=None):
+        super(ResnetCustomed, self).__init__()
+        stages = []
+        for k in range(5):
+            cin = out_feature[0] if k == 0 else out_feature[k - 1]
+            stages.append([("layer%d.sequential.resblock_%d." % (k + 1, i), cin if i == 0 else out_feature[k], out_feature[k])
+                           for i in range(num_res_block[k])])
+        self._setup(stages, [4, 3, 2], dtype, bn_mode)
+
+    def forward(self, x):
+        x4, x3, x2 = self._run(x)
+        return x4, x3, x2
 
 
 class OffsettoBbox(nn.Module):

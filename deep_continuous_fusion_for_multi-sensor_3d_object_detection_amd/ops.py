@@ -31,6 +31,15 @@ def nchw_to_nhwc(x, dtype):
     return y
 
 
+def nhwc_to_nchw(x, dtype):
+    """NHWC tensor of the compute dtype -> NCHW fp32 (the reference's activation layout)."""
+    B, Hh, W, C = x.shape
+    _chk(x, "x")
+    y = torch.empty((B, C, Hh, W), dtype=torch.float32, device=x.device)
+    H.call("dcf_nhwc_to_nchw", dtype, x, y, B, C, Hh, W, H.stream_ptr())
+    return y
+
+
 def image_to_nhwc4(img_u8, dtype):
     B, C, Hh, W = img_u8.shape
     assert C == 3 and img_u8.dtype == torch.uint8

@@ -34,7 +34,8 @@ enum { DCF_OK = 0, DCF_EINVAL = -1, DCF_ELAUNCH = -2, DCF_EUNSUPPORTED = -3 };
 enum { DCF_F32 = 0, DCF_BF16 = 1, DCF_F16 = 2 };   /* compute / storage type of activations and weight images */
 /* COMPAT: the reference's last-writer-wins scatter (data_import_carla.py:236-258), three launches; COMPAT_ROUNDS: the same
  * result by the literal nine rounds (claim pass c, resolve pass c-1), kept as a cross-check; ACCUM: atomic accumulation. */
-enum { DCF_VOXEL_COMPAT = 0, DCF_VOXEL_ACCUM = 1, DCF_VOXEL_COMPAT_ROUNDS = 2 };
+enum { DCF_VOXEL_COMPAT = 0, DCF_VOXEL_ACCUM = 1, DCF_VOXEL_COMPAT_ROUNDS = 2,
+       DCF_VOXEL_OCCUPANCY = 3 /* interpolate=False: voxel of the trunc'd ids := 1 (data_import_carla.py:231-234) */ };
 enum { DCF_PROJ_COMPAT = 0, DCF_PROJ_CORRECT = 1 };
 
 const char *dcf_last_error(void);
@@ -109,6 +110,8 @@ int dcf_fusion_invert(const dcf_knn_map *maps, int nmaps, int K, int n_max, int3
 /* ------------------------------------------------------------ layout / input
  * NCHW fp32 -> NHWC dtype (the model keeps the reference's NCHW voxel input, model.py:194). */
 int dcf_nchw_to_nhwc(int dtype, const float *x, void *y, int B, int C, int H, int W, dcf_stream_t stream);
+/* NHWC dtype -> NCHW fp32: stage outputs handed back in the reference's layout (model.py:76-79). */
+int dcf_nhwc_to_nchw(int dtype, const void *x, float *y, int B, int C, int H, int W, dcf_stream_t stream);
 /* uint8 NCHW image -> x/255 as NHWC with C padded to 4 and a zero halo of 3 pixels (stem input). */
 int dcf_image_to_nhwc4(int dtype, const uint8_t *img, void *y, int B, int H, int W, dcf_stream_t stream);
 

@@ -62,6 +62,7 @@ static inline float idx_affine(float p, float scale, float offset)
  *          (highest point index) wins inside a pass -- what `V[idx] += w`
  *          does under deterministic algorithms.
  * mode 1 = accum : true trilinear splat, points added in index order.
+ * mode 2 = occupancy: interpolate=False (:231-234): grid[zl][xl][yl] = 1.
  * ids (optional) receives trunc'd (x,y,z) voxel ids as [3][n] int64 (:258).
  * ------------------------------------------------------------------------- */
 void dcf_oracle_voxelize(const float *pts, int n, const float *aff,
@@ -99,6 +100,8 @@ void dcf_oracle_voxelize(const float *pts, int n, const float *aff,
             for (int i = 0; i < n; ++i) tmp[i] = grid[vox[(size_t)i * 8 + c]] + wgt[(size_t)i * 8 + c];
             for (int i = 0; i < n; ++i) grid[vox[(size_t)i * 8 + c]] = tmp[i];
         }
+    } else if (mode == 2) {
+        for (int i = 0; i < n; ++i) grid[vox[(size_t)i * 8]] = 1.0f;
     } else {
         for (int i = 0; i < n; ++i)
             for (int c = 0; c < 8; ++c) grid[vox[(size_t)i * 8 + c]] += wgt[(size_t)i * 8 + c];
@@ -179,6 +182,35 @@ void dcf_oracle_knn_bev(const float *xyz, int n, int K, int h, int w, int stride
             for (int q = 0; q < K; ++q)
                 out[((size_t)q * h + i) * w + j] = (q < cnt) ? bi[q] : -1;
         }
+    }
+    free(bd); free(bi);
+}
+
+/* Same contract, for a LIST of pixels (pi[q], pj[q]) of the site instead of the whole
+ * site: lets the tests sample a full-size site at random without a whole-site brute force.
+ * out int32 [npix][K]. */
+void dcf_oracle_knn_pixels(const float *xyz, int n, int K, const int32_t *pi, const int32_t *pj, int npix, int stride,
+                           float xs, float xo, float ys, float yo, float rmax2, int32_t *out)
+{
+    float *bd = (float *)malloc(sizeof(float) * (size_t)K);
+    int32_t *bi = (int32_t *)malloc(sizeof(int32_t) * (size_t)K);
+    for (int q = 0; q < npix; ++q) {
+        float X = (((float)pi[q] + 0.5f) * (float)stride - xo) / xs;
+        float Y = (((float)pj[q] + 0.5f) * (float)stride - yo) / ys;
+        int cnt = 0;
+        for (int k = 0; k < n; ++k) {
+            float dx = xyz[3 * k] - X, dy = xyz[3 * k + 1] - Y;
+            float a = dx * dx, b = dy * dy;
+            float d2 = a + b;
+            if (rmax2 >= 0.0f && d2 > rmax2) continue;
+            if (cnt < K || d2 < bd[cnt - 1]) {
+                int pos = (cnt < K) ? cnt : K - 1;
+                while (pos > 0 && bd[pos - 1] > d2) { bd[pos] = bd[pos - 1]; bi[pos] = bi[pos - 1]; --pos; }
+                bd[pos] = d2; bi[pos] = k;
+                if (cnt < K) ++cnt;
+            }
+        }
+        for (int t = 0; t < K; ++t) out[(size_t)q * K + t] = (t < cnt) ? bi[t] : -1;
     }
     free(bd); free(bi);
 }

@@ -137,6 +137,12 @@ def gen_geometry(mods):
         out[name + "_uv"] = uv.numpy()[:n]
         out[name + "_xyz"] = pcr.numpy()[:n]
         out[name + "_n"] = np.int32(n)
+        # interpolate=False (occupancy grid, :231-234): the set voxels
+        occ = ds.Voxelization_Projection(torch.from_numpy(pts.copy()), interpolate=False)[0].numpy()
+        pin, _ = geometry_ref.range_filter(pts, geometry_ref.grid_constants(cfg)["lim"])
+        g_occ = geometry_ref.voxelize(pin, geometry_ref.grid_constants(cfg)["aff"], geometry_ref.grid_constants(cfg)["dims"], "occupancy")
+        assert np.array_equal(g_occ, occ) and set(np.unique(occ)) <= {0.0, 1.0}, name + ": occupancy grid differs"
+        out[name + "_occ_idx"] = np.flatnonzero(occ.reshape(-1)).astype(np.int32)
         print("geometry", name, "n_in", ids.shape[1], "n_valid", n, "nnz", nz.size)
     torch.use_deterministic_algorithms(False)
     np.savez_compressed(os.path.join(OUT, "geometry_carla.npz"), **out)
@@ -256,6 +262,39 @@ def gen_loss(mods):
     np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
 
 
+def gen_loss_boundary(mods):
+    """Box centres within fp32 rounding of a cell boundary: fl32(y*4 + 16) rounds UP to the boundary where double
+    precision stays below it, so the 5x5 positive window sits one cell higher than a float64 restatement would put it."""
+    cfg = tiny_cfg()
+    L = mods["loss"].LossTotal(cfg)
+    b = torch.zeros(1, 20, 9)
+    rows = [[5.3, float(np.float32(-1e-7)), -1.0, 4.2, 1.9, 1.6, 0.4, 6, 1],
+            [float(np.nextafter(np.float32(8.0), np.float32(0.0))), float(np.float32(2.0) - np.float32(3e-7)), -0.9, 3.8, 1.7, 1.5, 1.9, 6, 1]]
+    b[0, :2] = torch.tensor(rows)
+    nb = torch.tensor([2])
+    f64 = [int((float(b[0, i, 1]) * 4 + 16) / 4) for i in range(2)]
+    f32 = [int((b[0, i, 1] * 4 + 16) / 4) for i in range(2)]
+    assert f64 != f32, "not a boundary case"
+    logits = torch.from_numpy(detfill.uniform((1, 4, 16, 8), 655, -2.0, 2.0))
+    cls0 = torch.cat((torch.softmax(logits[:, :2], 1), torch.softmax(logits[:, 2:], 1)), 1)
+    reg0 = torch.from_numpy(detfill.uniform((1, 14, 16, 8), 656, -0.5, 0.5))
+    cls = cls0.clone().requires_grad_(True)
+    reg = reg0.clone().requires_grad_(True)
+    np.random.seed(5)
+    val = L(b, nb, cls, reg)
+    val.backward()
+    cls2 = cls0.clone().requires_grad_(True)
+    reg2 = reg0.clone().requires_grad_(True)
+    np.random.seed(5)
+    mine = loss_ref.loss_total(cfg, b, nb, cls2, reg2, model_ref.anchors(cfg))
+    mine.backward()
+    assert abs(mine.item() - val.item()) < 1e-6 and torch.allclose(reg.grad, reg2.grad, atol=1e-7)
+    np.savez_compressed(os.path.join(OUT, "loss_boundary.npz"), bboxes=b.numpy(), nbox=nb.numpy(), cls=cls0.numpy(), reg=reg0.numpy(),
+                        loss=np.float32(val.item()), gcls=cls.grad.numpy(), greg=reg.grad.numpy(),
+                        cell_f32=np.array(f32, np.int32), cell_f64=np.array(f64, np.int32))
+    print("loss boundary: cells fp32", f32, "float64", f64, "loss", val.item())
+
+
 def gen_adam(mods, cfg, sd):
     """3 train steps, B=1, eval-mode BN (test.py:37 puts the trained module in eval: F4),
     Adam lr/betas from the config (train.py:26-28), np.random.seed(100+step) before each loss."""
@@ -360,7 +399,13 @@ def main():
     geometry_ref.build()
     mods = import_reference()
     torch.manual_seed(0)
+    if "--only-loss-boundary" in sys.argv:
+        gen_loss_boundary(mods)
+        return
     cfg, crt, cases = gen_geometry(mods)
+    if "--only-geometry" in sys.argv:       # leaves the other fixtures' bytes alone
+        return
+    gen_loss_boundary(mods)
     gen_anchors_decode(mods)
     tcfg, sd = gen_model_tiny(mods)
     gen_loss(mods)

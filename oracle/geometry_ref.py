@@ -43,6 +43,9 @@ def lib():
         L.dcf_oracle_knn_bev.argtypes = [fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                          ctypes.c_float, ctypes.c_float, ip]
+        L.dcf_oracle_knn_pixels.restype = None
+        L.dcf_oracle_knn_pixels.argtypes = [fp, ctypes.c_int, ctypes.c_int, ip, ip, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                            ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ip]
         _LIB = L
     return _LIB
 
@@ -95,7 +98,7 @@ def voxelize(pts_in, aff, dims, mode="compat", want_ids=False):
     grid = np.empty((Cz, L, W), dtype=np.float32)
     ids = np.empty((3, max(n, 1)), dtype=np.int64) if want_ids else None
     aff = np.ascontiguousarray(aff, dtype=np.float32)
-    lib().dcf_oracle_voxelize(_fp(pts_in), n, _fp(aff), Cz, L, W, 0 if mode == "compat" else 1, _fp(grid),
+    lib().dcf_oracle_voxelize(_fp(pts_in), n, _fp(aff), Cz, L, W, {"compat": 0, "accum": 1, "occupancy": 2}[mode], _fp(grid),
                               ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)) if want_ids else None)
     if want_ids:
         return grid, ids[:, :n].copy()
@@ -123,6 +126,19 @@ def knn_bev(xyz, K, h, w, stride, aff, rmax=None):
     r2 = -1.0 if rmax is None else float(np.float32(rmax) * np.float32(rmax))
     lib().dcf_oracle_knn_bev(_fp(xyz) if n else _fp(np.zeros((1, 3), np.float32)), n, K, h, w, stride,
                              float(aff[0]), float(aff[1]), float(aff[2]), float(aff[3]), r2, _ip(out))
+    return out
+
+
+def knn_pixels(xyz, K, pi, pj, stride, aff, rmax=None):
+    """Brute-force KNN (same contract as knn_bev) of the listed pixels (pi[q], pj[q]) only -> int32 [npix, K]."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    pi = np.ascontiguousarray(pi, dtype=np.int32)
+    pj = np.ascontiguousarray(pj, dtype=np.int32)
+    n = xyz.shape[0]
+    out = np.empty((pi.shape[0], K), dtype=np.int32)
+    r2 = -1.0 if rmax is None else float(np.float32(rmax) * np.float32(rmax))
+    lib().dcf_oracle_knn_pixels(_fp(xyz) if n else _fp(np.zeros((1, 3), np.float32)), n, K, _ip(pi), _ip(pj), pi.shape[0], stride,
+                                float(aff[0]), float(aff[1]), float(aff[2]), float(aff[3]), r2, _ip(out))
     return out
 
 

@@ -200,3 +200,93 @@ def test_wgrad_group_equals_single_launches(dtype):
     torch.cuda.synchronize()
     for ref, refs, got, gots in want:
         assert torch.equal(ref, got) and torch.equal(refs, gots)
+
+
+# ---- launches with MORE than 512 workgroups: the register-staged k_conv_igemm<..., DB=false> instantiations (and the
+# big-tile kernels that replace them) that the cfg2 bench actually runs -- the small shapes above all dispatch to the
+# <= 512-workgroup LDS-DMA / double-buffered variants.  (B, H, W, Cin, Cout, k, stride, what it exercises)
+BIG_SHAPES = [
+    (1, 352, 400, 128, 128, 3, 1),   # 128x128 tiles: 1100 workgroups (stage-3 body at 4x the pixels)
+    (1, 352, 400, 64, 64, 3, 1),     # 64 ch x 128 px tiles: 1100 workgroups (stage-2 body)
+    (1, 704, 800, 32, 32, 3, 1),     # 32 ch x 128 px tiles: 4400 workgroups, 64-byte rows (stage-1 body, full size)
+    (1, 704, 800, 64, 128, 3, 2),    # stride 2: forward 1100 workgroups of 128x128; dgrad = parity classes, 4400 tiles of 64x128
+    (1, 353, 399, 128, 192, 3, 2),   # stride 2, odd sizes: unequal parity classes; 192 = 64-channel tiles
+    (2, 176, 200, 192, 192, 3, 1),   # conv3 / FPN shape: 192 channels -> 64 ch x 128 px tiles, batch boundary inside tiles
+    (1, 352, 400, 128, 192, 1, 1),   # 1x1 (latconv2 shape), 128 -> 192
+]
+
+
+def _assert_quantised_close(got, ref, dtype, what):
+    """Quantisation-aware comparison: the device accumulates in fp32 and rounds ONCE to the storage type, so every
+    element must be within one unit in the last place of the storage type of the fp32 reference (plus the fp32
+    accumulation-order slack, relative to the tensor's scale) -- far tighter than a max-relative bound."""
+    ulp = {0: 2.0 ** -22, 1: 2.0 ** -8, 2: 2.0 ** -11}[dtype]
+    slack = 2e-5 * float(ref.abs().max())
+    bad = (got - ref).abs() > ulp * ref.abs() + slack
+    assert not bool(bad.any()), "%s: %d of %d elements off by more than one storage ulp, worst %g at ref %g" % (
+        what, int(bad.sum()), bad.numel(), float((got - ref).abs()[bad].max()), float(ref[bad].abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [1, 2, 0])
+@pytest.mark.parametrize("shape", BIG_SHAPES)
+def test_conv_fwd_big_launch(shape, dtype):
+    ops = pkg("ops")
+    B, Hh, W, Cin, Cout, k, s = shape
+    pad = k // 2
+    x, w = _mk(shape, dtype, 51)
+    shift = rnd((Cout,), 52)
+    ref_lin = F.conv2d(x, w, None, s, pad)
+    res = q(rnd(tuple(ref_lin.shape), 53), dtype)
+    xd, wd = to_dev(x, dtype), to_dev(w, dtype)
+    y = ops.conv2d_fwd(dtype, xd, wd, None, None, k, k, s, pad, False, Cout)
+    _assert_quantised_close(from_dev(y), ref_lin, dtype, "plain")
+    y2 = ops.conv2d_fwd(dtype, xd, wd, shift.cuda(), to_dev(res, dtype), k, k, s, pad, True, Cout)
+    _assert_quantised_close(from_dev(y2), torch.relu(ref_lin + shift.view(1, -1, 1, 1) + res), dtype, "fused")
+
+
+@pytest.mark.parametrize("dtype", [1, 2, 0])
+@pytest.mark.parametrize("shape", BIG_SHAPES)
+def test_conv_dgrad_big_launch(shape, dtype):
+    ops = pkg("ops")
+    B, Hh, W, Cin, Cout, k, s = shape
+    pad = k // 2
+    x, w = _mk(shape, dtype, 61)
+    x.requires_grad_(True)
+    y = F.conv2d(x, w, None, s, pad)
+    gy = q(rnd(tuple(y.shape), 62), dtype)
+    y.backward(gy)
+    wt = w.permute(1, 2, 3, 0).contiguous().cuda().to(TORCH_DT[dtype])          # [Cin][kh][kw][Cout]
+    gyd = to_dev(gy, dtype)
+    gx = ops.conv2d_dgrad(dtype, gyd, wt, None, (B, Hh, W, Cin), k, k, s, pad)
+    _assert_quantised_close(from_dev(gx), x.grad, dtype, "dgrad")
+    res = q(rnd((B, Cin, Hh, W), 63), dtype)
+    mask = q(rnd((B, Cin, Hh, W), 64), dtype)
+    gx3 = ops.conv2d_dgrad(dtype, gyd, wt, to_dev(res, dtype), (B, Hh, W, Cin), k, k, s, pad, to_dev(mask, dtype))
+    got3 = from_dev(gx3)
+    _assert_quantised_close(got3, (x.grad + res) * (mask > 0), dtype, "dgrad+res+mask")
+    assert float((got3 * (mask <= 0)).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("shape", [BIG_SHAPES[0], BIG_SHAPES[5], BIG_SHAPES[3]])
+def test_conv_wgrad_big_launch(shape, dtype):
+    """Weight gradient at bench-size pixel counts (many pixel ranges per layer, ranges crossing image rows / frames)."""
+    ops = pkg("ops")
+    B, Hh, W, Cin, Cout, k, s = shape
+    pad = k // 2
+    x, w = _mk(shape, dtype, 71)
+    w.requires_grad_(True)
+    y = F.conv2d(x, w, None, s, pad)
+    gy = q(rnd(tuple(y.shape), 72), dtype)
+    y.backward(gy)
+    Ho, Wo = y.shape[-2:]
+    ns = ops.conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, k, k, s)
+    slabs = torch.full((ns, Cout, k, k, Cin), float("nan"), device="cuda")
+    gsum = torch.full((4 * ns, Cout), float("nan"), device="cuda")
+    ops.conv2d_wgrad(dtype, to_dev(x, dtype), to_dev(gy, dtype), slabs, ns, k, k, s, pad, gsum)
+    G = slabs.sum(0).cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(G).all()
+    e = rel_err(G, w.grad)
+    assert e < 2e-4, "wgrad rel err %g" % e                       # fp32 accumulation of exactly representable products
+    want = gy.sum((0, 2, 3))
+    assert float((gsum.sum(0).cpu() - want).abs().max()) < 2e-4 * float(gy.abs().sum((0, 2, 3)).max())

@@ -39,6 +39,20 @@ def test_voxel_project_golden_bit_exact(case):
     assert np.array_equal(pin.cpu().numpy()[:m], ref_in) and np.array_equal(src.cpu().numpy()[:m], ref_src)
 
 
+@pytest.mark.parametrize("case", ["two", "five", "n1k", "n10k"])
+def test_occupancy_voxels_golden(case):
+    """interpolate=False (data_import_carla.py:231-234) through the Dataset surface: exactly the reference's set voxels."""
+    D, H = pkg("data_import_carla"), pkg("_hip")
+    z = load_golden("geometry_carla.npz")
+    cfg = golden_cfg(z)
+    geo = D.FrameGeometry(cfg, z["crt"])
+    vox, _, _, cnt, _ = geo(torch.from_numpy(z[case + "_pts"]), voxel_mode=H.VOXEL_OCCUPANCY)
+    got = vox.cpu().numpy().reshape(-1)
+    assert set(np.unique(got)) <= {0.0, 1.0}
+    assert np.array_equal(np.flatnonzero(got).astype(np.int32), z[case + "_occ_idx"])
+    assert int(cnt.item()) == int(z[case + "_n"])
+
+
 def test_voxel_workspace_returned_zero_and_reusable():
     ops, H = pkg("ops"), pkg("_hip")
     z = load_golden("geometry_carla.npz")
@@ -251,3 +265,100 @@ def test_voxelize_batch_nhwc_equals_transposed_grid(dtype):
     ops.voxelize_batch_nhwc(dtype, frames, g.lim, g.aff, g.dims, owner, got)
     assert int(owner.abs().max()) == 0
     assert torch.equal(got.view(torch.int32 if dtype == 0 else torch.int16), want.view(torch.int32 if dtype == 0 else torch.int16))
+
+
+def _cfg2_cloud(seed=5, npts=100000):
+    """cfg2 geometry (BASELINE.json configs[1]): 100 k points, KITTI-like calibration -> the ~40 k in-frustum points the
+    KNN really sees, as the C oracle's projection produces them."""
+    det, calib = pkg("detfill"), pkg("calib")
+    cfg = golden_cfg(load_golden("geometry_carla.npz"))
+    cfg.update(dict(voxel_length=704, voxel_width=800, lidar_x_max=70.4, lidar_y_min=-40.0, lidar_y_max=40.0,
+                    image_height=375, image_width=1242, max_num_pc=npts))
+    g = _spec(cfg)
+    pts = det.synthetic_points(npts, (0.0, 70.4, -40.0, 40.0, -2.4, 0.8), seed=seed)
+    _, pc, _, n, _ = geometry_ref.voxelization_projection(pts, cfg, calib.kitti_like_crt(), proj_mode="correct")
+    return g, np.ascontiguousarray(pc[:n])
+
+
+def _knn_check_pixels(got, xyz, K, pi, pj, stride, aff, rmax=None):
+    ref = geometry_ref.knn_pixels(xyz, K, pi, pj, stride, aff, rmax)            # [npix, K]
+    mine = got[:, pi, pj].T
+    bad = np.flatnonzero((mine != ref).any(1))
+    assert bad.size == 0, "KNN differs at %d of %d pixels, first (%d,%d): got %s ref %s" % (
+        bad.size, pi.size, pi[bad[0]], pj[bad[0]], mine[bad[0]].tolist(), ref[bad[0]].tolist())
+
+
+@pytest.mark.parametrize("K", [3, 5])
+@pytest.mark.parametrize("stride", [2, 4])
+def test_knn_cfg2_whole_site_sampled_bruteforce(K, stride):
+    """The tile kernel (k_knn_search: sites > 20 000 px, the one that produces cfg2's stride-2 / stride-4 maps) against
+    the brute-force oracle over the WHOLE site: 4096 uniformly random pixels, every pixel of the last 24 rows (the far
+    field, beyond the point cloud's dense region), the first rows, and the left / right border columns (outside the
+    camera frustum: the coarse 8x8-block ring phase with bounding-box pruning)."""
+    ops = pkg("ops")
+    g, xyz = _cfg2_cloud()
+    n = xyz.shape[0]
+    assert 20000 < n < 80000
+    h, w = 704 // stride, 800 // stride
+    assert h * w > 20000
+    d = torch.from_numpy(xyz).cuda()
+    cnt = torch.tensor([n], dtype=torch.int32, device="cuda")
+    got = ops.knn_bev(d, cnt, K, h, w, stride, g.aff).cpu().numpy()
+    assert got.min() >= 0 and got.max() < n
+    rng = np.random.default_rng(1234 + K * 10 + stride)
+    pi = rng.integers(0, h, 4096).astype(np.int32)
+    pj = rng.integers(0, w, 4096).astype(np.int32)
+    _knn_check_pixels(got, xyz, K, pi, pj, stride, g.aff)
+    ii, jj = np.meshgrid(np.arange(h - 24, h), np.arange(w), indexing="ij")     # far field: last 24 rows, all columns
+    _knn_check_pixels(got, xyz, K, ii.ravel().astype(np.int32), jj.ravel().astype(np.int32), stride, g.aff)
+    ii, jj = np.meshgrid(np.arange(0, h, 3), np.concatenate([np.arange(0, 8), np.arange(w - 8, w)]), indexing="ij")
+    _knn_check_pixels(got, xyz, K, ii.ravel().astype(np.int32), jj.ravel().astype(np.int32), stride, g.aff)
+
+
+@pytest.mark.parametrize("stride,K", [(2, 3), (4, 5), (8, 3)])
+def test_knn_tile_kernel_equals_wave_kernel_full_site(stride, K, monkeypatch):
+    """k_knn_search (one wave per 8x8 tile, window + coarse rings) and k_knn_search_wave (one wave per pixel, lanes split
+    the candidates) are two implementations of the same exact (d2, index) order: whole-site equality at cfg2 size, in both
+    directions of the dispatch threshold (a fine site forced onto the wave kernel, a coarse one onto the tile kernel)."""
+    ops = pkg("ops")
+    g, xyz = _cfg2_cloud(seed=9)
+    n = xyz.shape[0]
+    h, w = 704 // stride, 800 // stride
+    d = torch.from_numpy(xyz).cuda()
+    cnt = torch.tensor([n], dtype=torch.int32, device="cuda")
+    monkeypatch.setenv("DCF_KNN_KERNEL", "tile")
+    a = ops.knn_bev(d, cnt, K, h, w, stride, g.aff)
+    monkeypatch.setenv("DCF_KNN_KERNEL", "wave")
+    b = ops.knn_bev(d, cnt, K, h, w, stride, g.aff)
+    monkeypatch.delenv("DCF_KNN_KERNEL")
+    c = ops.knn_bev(d, cnt, K, h, w, stride, g.aff)
+    assert torch.equal(a, b) and torch.equal(a, c)
+    # ... and with a radius cut that leaves pixels with fewer than K neighbours
+    monkeypatch.setenv("DCF_KNN_KERNEL", "tile")
+    a = ops.knn_bev(d, cnt, K, h, w, stride, g.aff, rmax=1.5)
+    monkeypatch.setenv("DCF_KNN_KERNEL", "wave")
+    b = ops.knn_bev(d, cnt, K, h, w, stride, g.aff, rmax=1.5)
+    assert torch.equal(a, b) and int((a < 0).sum()) > 0
+
+
+@pytest.mark.parametrize("where", ["far_corner", "near_corner", "two_clusters"])
+def test_knn_tile_kernel_far_cluster_full_site(where):
+    """A fine site (> 20 000 px, tile kernel) whose only points are one or two tiny clusters: almost every tile finds its
+    12x12-cell window empty and reaches the cluster through many coarse 8x8-block rings.  Whole site against brute force
+    (few points: the full-site brute force is cheap)."""
+    ops = pkg("ops")
+    g, _ = _cfg2_cloud()
+    stride, K = 4, 3
+    h, w = 704 // stride, 800 // stride
+    base = {"far_corner": [(69.7, 39.2)], "near_corner": [(0.3, -39.6)], "two_clusters": [(69.9, -39.9), (35.0, 3.0)]}[where]
+    rows = []
+    for cx, cy in base:
+        for t in range(7):
+            rows.append([cx + 0.013 * t, cy - 0.007 * t, -1.0 + 0.1 * t])
+    xyz = np.asarray(rows, dtype=np.float32)
+    d = torch.from_numpy(xyz).cuda()
+    cnt = torch.tensor([xyz.shape[0]], dtype=torch.int32, device="cuda")
+    got = ops.knn_bev(d, cnt, K, h, w, stride, g.aff).cpu().numpy()
+    assert np.array_equal(got, geometry_ref.knn_bev(xyz, K, h, w, stride, g.aff))
+    got = ops.knn_bev(d, cnt, K, h, w, stride, g.aff, rmax=30.0).cpu().numpy()
+    assert np.array_equal(got, geometry_ref.knn_bev(xyz, K, h, w, stride, g.aff, rmax=30.0))

@@ -30,6 +30,24 @@ def test_product_loss_matches_reference_golden():
     assert s.item() > float(z["loss_seed0"])          # both samples now contribute
 
 
+def test_product_loss_cell_boundary_matches_reference():
+    """A box centre within fp32 rounding of a cell boundary (tests/golden/loss_boundary.npz, made by the imported
+    reference): the positive window must sit where the reference's fp32 tensor arithmetic puts it (loss.py:85-86), one
+    cell above what the same expression gives in double precision."""
+    z = load_golden("loss_boundary.npz")
+    assert not np.array_equal(z["cell_f32"], z["cell_f64"])
+    cfg = golden_cfg(load_golden("model_tiny.npz"))
+    L = pkg("loss").LossTotal(cfg)
+    cls = torch.from_numpy(z["cls"]).requires_grad_(True)
+    reg = torch.from_numpy(z["reg"]).requires_grad_(True)
+    np.random.seed(5)
+    val = L(torch.from_numpy(z["bboxes"]), torch.from_numpy(z["nbox"]), cls, reg)
+    val.backward()
+    assert abs(val.item() - float(z["loss"])) < 1e-6
+    assert np.abs(cls.grad.numpy() - z["gcls"]).max() < 1e-7
+    assert np.abs(reg.grad.numpy() - z["greg"]).max() < 1e-7
+
+
 def test_anchor_surface_bit_exact():
     z = load_golden("anchors_decode.npz")
     cfg = golden_cfg(load_golden("geometry_carla.npz"))

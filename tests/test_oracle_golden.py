@@ -24,6 +24,18 @@ def test_geometry_oracle_bit_exact(case):
     assert not pc[n:].any() and not uv[n:].any()
 
 
+@pytest.mark.parametrize("case", ["two", "five", "n1k", "n10k"])
+def test_occupancy_grid_oracle_equals_reference(case):
+    """interpolate=False (data_import_carla.py:231-234): the set of voxels the imported reference set to 1."""
+    z = load_golden("geometry_carla.npz")
+    cfg = golden_cfg(z)
+    g = geometry_ref.grid_constants(cfg)
+    pin, _ = geometry_ref.range_filter(z[case + "_pts"], g["lim"])
+    occ = geometry_ref.voxelize(pin, g["aff"], g["dims"], "occupancy")
+    assert set(np.unique(occ)) <= {0.0, 1.0}
+    assert np.array_equal(np.flatnonzero(occ.reshape(-1)).astype(np.int32), z[case + "_occ_idx"])
+
+
 def test_voxel_last_writer_wins_not_accumulate():
     """five points in one voxel -> compat grid sums to 1.0 per corner family."""
     z = load_golden("geometry_carla.npz")
@@ -125,3 +137,38 @@ def test_full_carla_cfg1():
     got = pred[:, z["sample_h"], z["sample_w"]]
     assert np.abs(got - z["sample_pred"]).max() <= 1e-4 * np.abs(z["sample_pred"]).max()
     assert np.allclose(pred.astype(np.float64).sum((1, 2)), z["chan_sum"], rtol=1e-4, atol=1e-2)
+
+
+def _tiny_x():
+    det = pkg("detfill")
+    u = det.uniform((2, 32, 64, 32), 4242, 0.0, 1.0)
+    m = det.uniform((2, 32, 64, 32), 4242 + 17, 0.0, 1.0) < 0.12
+    return torch.from_numpy((u * m).astype(np.float32))
+
+
+def test_quantisation_aware_statement_pinned_by_reference_golden():
+    """oracle/model_quant_ref.py without rounding (qdtype=None) IS the fp32 network with the BatchNorm folded the way the
+    device folds it: forward and every checked gradient equal the imported reference's golden vectors.  With rounding on,
+    it moves away from them by a few storage ulps only (sanity of the rounding points)."""
+    from oracle import model_quant_ref
+    z = load_golden("model_tiny.npz")
+    cfg = golden_cfg(z)
+    det = pkg("detfill")
+    sd = model_ref.make_state_dict(model_ref.lidar_state_shapes(cfg))
+    x = _tiny_x()
+    with torch.no_grad():
+        pred = model_quant_ref.forward(sd, cfg, x, None).numpy()
+    assert np.abs(pred - z["pred_eval"]).max() <= 1e-4 * np.abs(z["pred_eval"]).max()
+    R = torch.from_numpy(det.uniform((1, 32, 16, 8), 777, -1.0, 1.0))
+    grads = {}
+    for dt in (None, torch.bfloat16, torch.float16):
+        params = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+        out = model_quant_ref.forward(params, cfg, x[:1].clone(), dt)
+        (out * R).sum().backward()
+        grads[dt] = {k: params[k].grad.numpy() for k in [str(s) for s in z["grad_keys"]]}
+    for k, g in grads[None].items():
+        ref = z["g_eval_" + k]
+        assert np.abs(g - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-6, k
+    for dt, lo, hi in ((torch.bfloat16, 1e-4, 2.5e-1), (torch.float16, 1e-5, 2.5e-1)):
+        worst = max(np.abs(grads[dt][k] - grads[None][k]).max() / (np.abs(grads[None][k]).max() + 1e-12) for k in grads[None])
+        assert lo < worst < hi, (dt, worst)
