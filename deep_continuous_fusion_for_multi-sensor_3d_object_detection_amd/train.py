@@ -45,11 +45,32 @@ def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _through_host(t):
+    """gloo with a device tensor (DCF_DIST_BACKEND=gloo: several ranks sharing one GPU in the functional tests): the
+    collective runs on a host copy.  RCCL (the product path) takes the device tensor itself."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
 def allreduce_grads(flat_grads):
     """Sum the gradient arena over ranks (RCCL over xGMI on the GPU box, gloo in the CPU tests)."""
     if world() > 1:
-        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
+        if _through_host(flat_grads):
+            h = flat_grads.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            flat_grads.copy_(h)
+        else:
+            dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
     return world()
+
+
+def broadcast_from_rank0(t):
+    if world() > 1:
+        if _through_host(t):
+            h = t.cpu()
+            dist.broadcast(h, 0)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, 0)
 
 
 class Train(nn.Module):
@@ -60,10 +81,14 @@ class Train(nn.Module):
         self.model = ObjectDetection_DCF(config).cuda()
         self.loss_value = None
         self.optimizer = FlatAdam(self.model, config["learning_rate"], (config["beta1"], 0.999))
-        if world() > 1:  # identical replicas: rank 0's parameters and buffers win
-            dist.broadcast(self.model.flat_params, 0)
-            dist.broadcast(self.model._bufflat, 0)
+        self.sync_replicas()
         self._side = None
+
+    def sync_replicas(self):
+        """Identical replicas: rank 0's parameters, buffers and optimiser moments win (called at construction; call it
+        again after loading weights on rank 0 only)."""
+        for t in (self.model.flat_params, self.model._bufflat, self.optimizer.m, self.optimizer.v):
+            broadcast_from_rank0(t)
 
     def geometry_async(self, frame_geometry, points_list, crts=None, wait_event=None):
         """Per-frame geometry (voxelise, project, KNN of the fusion sites) on a side HIP stream, so that these

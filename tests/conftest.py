@@ -15,6 +15,32 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Start the child processes of tests/test_gpu_dp.py (two data-parallel ranks sharing GPU 0 + the one-rank run they
+    must equal) BEFORE this process initialises the GPU: torch.cuda.device_count() does not, anything later does, and a
+    process that has initialised HIP must not exec another program on the GPU pool."""
+    import socket
+    import subprocess
+    import tempfile
+    import torch
+    config = session.config
+    expr = getattr(config.option, "markexpr", "") or ""
+    if "not gpu" in expr or os.environ.get("DCF_NO_DP_CHILDREN") or torch.cuda.device_count() < 1:
+        return
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    outdir = tempfile.mkdtemp(prefix="dcf_dp_")
+    child = os.path.join(ROOT, "tests", "dp_child.py")
+    procs = []
+    for name, world, rank in (("w1_r0", 1, 0), ("w2_r0", 2, 0), ("w2_r1", 2, 1)):
+        log = open(os.path.join(outdir, name + ".log"), "w")
+        procs.append((name, subprocess.Popen([sys.executable, child, str(world), str(rank), port, outdir], stdout=log, stderr=subprocess.STDOUT,
+                                             cwd=ROOT)))
+    config._dcf_dp_children = (outdir, procs)
+
+
 @pytest.fixture(scope="session")
 def dcf():
     """The product package (its directory name has a hyphen, so it is imported by name)."""

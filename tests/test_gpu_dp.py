@@ -1,0 +1,38 @@
+"""GPU suite: data-parallel equivalence of Train.one_step with world_size 2 ON ONE GPU (N ranks x B frames
+must equal one rank x N*B frames up to re-association).  Two rank processes share GPU 0 and all-reduce the flat gradient
+arena through gloo; a third process runs the same two frames as one batch.  The children are started by conftest.py at
+session start, BEFORE this pytest process touches the GPU (a process that has initialised HIP must not exec another
+program on this pool), and run while the other GPU tests do.  Reference: /root/reference/train.py:24,51-56 (DDP averages the
+gradients of identical replicas)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_ranks_equal_one_rank_with_twice_the_batch(request):
+    kids = getattr(request.config, "_dcf_dp_children", None)
+    if not kids:
+        pytest.skip("data-parallel children were not started (no GPU at session start)")
+    outdir, procs = kids
+    for name, p in procs:
+        try:
+            rc = p.wait(timeout=900)
+        except Exception:
+            p.kill()
+            raise AssertionError("child %s did not finish" % name)
+        log = open(os.path.join(outdir, name + ".log")).read()
+        assert rc == 0, "child %s failed:\n%s" % (name, log[-3000:])
+    one = torch.load(os.path.join(outdir, "w1_r0.pt"))
+    r0 = torch.load(os.path.join(outdir, "w2_r0.pt"))
+    r1 = torch.load(os.path.join(outdir, "w2_r1.pt"))
+    for step in range(2):
+        a, b, c = one["params"][step], r0["params"][step], r1["params"][step]
+        assert torch.equal(b, c), "replicas diverged at step %d" % step          # same all-reduced gradient, same Adam step
+        scale = float(a.abs().max())
+        err = float((a - b).abs().max())
+        assert err < 1e-5 * scale, "step %d: 2 ranks x 1 frame vs 1 rank x 2 frames differ by %g (scale %g)" % (step, err, scale)
+    # the step moved the parameters at all (learning rate 1e-3, Adam: ~1e-3 per step)
+    assert float((one["params"][1] - one["params"][0]).abs().max()) > 1e-4
