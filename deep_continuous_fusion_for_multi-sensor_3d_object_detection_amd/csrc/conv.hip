@@ -28,12 +28,9 @@
 #include <vector>
 #include <type_traits>
 #include "dcf_common.h"
+#include "conv_common.h"
 
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
     const char *x;       // gathered tensor [B][Hi][Wi][Ck]
@@ -59,63 +56,12 @@ struct ConvArgs {
 
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
-// ---- LDS-DMA helpers (used by k_conv_igemm_dma and k_conv_wgrad3g)
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// One LDS-DMA instruction: 64 lanes x 16 B, lane l from buffer offset voff[l], to LDS bytes [lds_dst, lds_dst + 1024).
-// A lane whose offset is outside the descriptor's range has ZEROS written for it (probed on MI355X:
-// tools/probe/lds_dma_oob.hip) -- padding, junk rows and masked channels cost one v_cndmask.
-// Inline asm on purpose: hipcc counts a *builtin* LDS-DMA as a pending LDS write and drains it with vmcnt(0)
-// before the next ds_read, which would serialise the ring; an asm one is ours to count (wait_vmcnt above).
-// M0 (the DMA destination base) is compiler-reserved: saved and restored inside the statement.
-__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(rsrc), "s"(lds_dst)
-                 : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const void *p)
-{
-    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
-}
-
-template <typename V> __device__ __forceinline__ V opaque(V v) { asm volatile("" : "+v"(v)); return v; }   // stop re-derivation of lane constants
-
 __device__ long long g_dcf_dbg_t[8];     // DCF_WGRAD3_DBG / DCF_IGEMM_DBG & 2: phase timestamps (s_memtime) of workgroup 0, wave 0
 #define DCF_STAMP(i) do { if ((a.dbg & 2) && blockIdx.x == 0 && threadIdx.x == 0) g_dcf_dbg_t[i] = clock64(); } while (0)
 // DBG & 4: first start / last end over ALL workgroups on the 100 MHz wall clock, plus the sum of workgroup lifetimes
 __device__ unsigned long long g_dcf_dbg_w[4];
 #define DCF_WSTART() long long w_start__ = 0; do { if ((a.dbg & 4) && threadIdx.x == 0) { w_start__ = wall_clock64(); atomicMin(&g_dcf_dbg_w[0], (unsigned long long)w_start__); } } while (0)
 #define DCF_WEND() do { if ((a.dbg & 4) && threadIdx.x == 0) { const long long e__ = wall_clock64(); atomicMax(&g_dcf_dbg_w[1], (unsigned long long)e__); atomicAdd(&g_dcf_dbg_w[2], (unsigned long long)(e__ - w_start__)); atomicMax(&g_dcf_dbg_w[3], (unsigned long long)(e__ - w_start__)); } } while (0)
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-    // one 16-byte fragment pair = one K=16 MFMA
-    __device__ static __forceinline__ void run(const uint4 &a, const uint4 &b, f32x16 &acc)
-    {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-    }
-};
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-template <> struct Mma<f16_t> {
-    __device__ static __forceinline__ void run(const uint4 &a, const uint4 &b, f32x16 &acc)
-    {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
-    }
-};
-template <> struct Mma<float> {
-    // one 16-byte fragment pair = four K=2 MFMAs (lane half h owns k = 4h+j of each 8-group;
-    // the k permutation is the same for both operands, so the sum is unchanged)
-    __device__ static __forceinline__ void run(const uint4 &a, const uint4 &b, f32x16 &acc)
-    {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
-    }
-};
 
 // ------------------------------------------------------------------------------------
 // forward / dgrad kernel.  Block = 256 threads = WN x WM waves; wave tile TN*32 output
@@ -1557,6 +1503,15 @@ __global__ void __launch_bounds__(256) k_conv_wgrad_grp(WgGroup g)
 
 }  // namespace
 
+// row-sharing kernel for the 3x3 / stride-1 / pad-1 layers (conv_rs.hip)
+int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *shift, const void *res, const void *mask, void *y,
+                          int B, int H, int W, int Ck, int Cn, int relu, int flip, const char *name_base, double flops, hipStream_t s);
+static bool use_rs(int dtype, int kh, int kw, int stride, int pad)
+{
+    static const char *e = getenv("DCF_CONV_RS");
+    return !(e && atoi(e) == 0) && dtype != DCF_F32 && kh == 3 && kw == 3 && stride == 1 && pad == 1;
+}
+
 // ================================================================== C ABI
 static int check_conv(const char *who, int dtype, int Cin, int Cout, int kh, int kw, int stride)
 {
@@ -1588,6 +1543,10 @@ extern "C" int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const flo
     a.xbytes = (unsigned)((int64_t)B * H * W * a.pixbytes);
     a.wbytes = (unsigned)((int64_t)Cout * kh * kw * a.pixbytes);
     const double flops = 2.0 * a.M * Cout * (double)Cin * kh * kw;
+    if (use_rs(dtype, kh, kw, stride, pad)) {
+        rc = dcf_conv3x3_rs_launch(dtype, x, w, shift, res, nullptr, y, B, H, W, Cin, Cout, relu, 0, dtype == DCF_F16 ? "conv_fwd_f16" : "conv_fwd_bf16", flops, S(stream));
+        if (rc != DCF_EUNSUPPORTED) return rc;
+    }
     if (dtype == DCF_F32) return launch_igemm<float, false>(a, S(stream), "conv_fwd_f32", flops);
     if (dtype == DCF_F16) return launch_igemm<f16_t, false>(a, S(stream), "conv_fwd_f16", flops);
     return launch_igemm<bf16_t, false>(a, S(stream), "conv_fwd_bf16", flops);
@@ -1619,6 +1578,10 @@ extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const
     a.xbytes = (unsigned)((int64_t)B * Ho * Wo * a.pixbytes);
     a.wbytes = (unsigned)((int64_t)Cin * kh * kw * a.pixbytes);
     const double flops = 2.0 * B * Ho * Wo * Cout * (double)Cin * kh * kw;   // algorithmic (= the forward conv's)
+    if (use_rs(dtype, kh, kw, stride, pad)) {
+        rc = dcf_conv3x3_rs_launch(dtype, gy, wt, nullptr, res, mask, gx, B, H, W, Cout, Cin, 0, 1, dtype == DCF_F16 ? "conv_dgrad_f16" : "conv_dgrad_bf16", flops, S(stream));
+        if (rc != DCF_EUNSUPPORTED) return rc;
+    }
     if (dtype == DCF_F32) return launch_igemm<float, true>(a, S(stream), "conv_dgrad_f32", flops);
     if (dtype == DCF_F16) return launch_igemm<f16_t, true>(a, S(stream), "conv_dgrad_f16", flops);
     return launch_igemm<bf16_t, true>(a, S(stream), "conv_dgrad_bf16", flops);

@@ -1,0 +1,63 @@
+// conv_common.h -- device helpers shared by the convolution kernels (conv.hip, conv_rs.hip): MFMA wrappers per element
+// type, the inline-asm LDS-DMA instruction and its counted wait.  gfx950 only.
+#pragma once
+#include "dcf_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// ---- LDS-DMA helpers (used by k_conv_igemm_dma and k_conv_wgrad3g)
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// One LDS-DMA instruction: 64 lanes x 16 B, lane l from buffer offset voff[l], to LDS bytes [lds_dst, lds_dst + 1024).
+// A lane whose offset is outside the descriptor's range has ZEROS written for it (probed on MI355X:
+// tools/probe/lds_dma_oob.hip) -- padding, junk rows and masked channels cost one v_cndmask.
+// Inline asm on purpose: hipcc counts a *builtin* LDS-DMA as a pending LDS write and drains it with vmcnt(0)
+// before the next ds_read, which would serialise the ring; an asm one is ours to count (wait_vmcnt above).
+// M0 (the DMA destination base) is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+}
+
+template <typename V> __device__ __forceinline__ V opaque(V v) { asm volatile("" : "+v"(v)); return v; }   // stop re-derivation of lane constants
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    // one 16-byte fragment pair = one K=16 MFMA
+    __device__ static __forceinline__ void run(const uint4 &a, const uint4 &b, f32x16 &acc)
+    {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+};
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <> struct Mma<f16_t> {
+    __device__ static __forceinline__ void run(const uint4 &a, const uint4 &b, f32x16 &acc)
+    {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // one 16-byte fragment pair = four K=2 MFMAs (lane half h owns k = 4h+j of each 8-group;
+    // the k permutation is the same for both operands, so the sum is unchanged)
+    __device__ static __forceinline__ void run(const uint4 &a, const uint4 &b, f32x16 &acc)
+    {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+};
+
+}  // namespace

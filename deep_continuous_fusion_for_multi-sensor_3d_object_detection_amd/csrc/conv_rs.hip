@@ -1,0 +1,413 @@
+// conv_rs.hip -- row-sharing implicit GEMM for the 3x3 / stride-1 / pad-1 convolutions (forward and input gradient),
+// 16-bit element types, gfx950.
+//
+// These are 47 of the network's convolutions (/root/reference/model.py:15-28 ResidualBlock bodies, :153 conv3; the
+// camera trunk's BasicBlocks): ~1.0 TFLOP of the ~1.2 TFLOP a cfg2 forward + dgrad needs.  The generic implicit GEMM
+// (conv.hip) stages, per tap and 64-channel chunk, one weight tile and one pixel tile: 32-64 flop per staged byte, and
+// what a CU can pull out of its XCD's L2 into LDS (~70 GB/s, MI355X_MICROARCH.md "Indexed rows: gather into LDS") caps
+// such a kernel at 25-45 % of the MFMA rate.  Here the staged bytes per flop drop 1.5-2.4x:
+//
+//   * ROW SHARING.  Output pixels are enumerated over the zero-PADDED image (rows of W + 2 positions; positions 0 and
+//     W + 1 of every row are padding: their outputs are dropped, their inputs read as zero).  In that flattened space the
+//     input of tap (ki, kj) for position p is position p + (ki - 1)(W + 2) + (kj - 1), so the three horizontal taps of a
+//     kernel row read ONE staged pixel tile of BM + 2 rows at row offsets 0, 1, 2 -- an x tile is staged once per
+//     (kernel row, channel chunk) instead of once per tap.
+//   * BIG, SHAPED TILES.  One 512-thread workgroup per CU; a tile is BN = 128 or 64 channels x BM = 32 * npt positions
+//     with npt chosen per layer on the host so that the tile count fills the 256 CUs in whole rounds (the generic
+//     kernel's 550 tiles of 128x128 on the 128-channel stage leave a third round 15 % full).
+//   * LDS-DMA rings, one barrier per tap.  `buffer_load ... lds` (inline asm, counted vmcnt) fills a 3-deep weight ring
+//     (one slot per tap) two taps ahead and a 2-deep pixel ring (one slot per kernel row x chunk) one stage ahead; padding,
+//     tile tails and image borders are out-of-range buffer offsets for which the DMA writes zeros.  Per tap:
+//     counted wait -> s_barrier -> issue -> MFMAs.
+//   * dgrad is the same kernel on the [Cin][tap][Cout] weight image with the taps mirrored.
+//
+// Algorithmic work per launch: 2*B*H*W*Cout*Cin*9 flop; bytes B*H*W*(Cin + Cout)*2 (+ residual / mask reads).
+#include <stdlib.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "dcf_common.h"
+#include "conv_common.h"
+
+namespace {
+
+struct RsArgs {
+    const char *x;        // [B][H][W][Ck]
+    const char *w;        // [Cn][9][Ck]
+    const float *shift;   // [Cn] or null
+    const char *res;      // [B*H*W][Cn] or null
+    const char *mask;     // [B*H*W][Cn] or null: output *= (mask > 0)
+    char *y;              // [B*H*W][Cn]
+    int B, H, W, Ck, Cn;
+    int relu, flip;       // flip = 1: input gradient (taps mirrored)
+    int npt;              // 32-position tiles per workgroup
+    int mtiles;           // position tiles of the launch
+    int Q;                // padded positions B*H*(W+2)
+    unsigned xbytes, wbytes;
+};
+
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the immediate must be a constant: one scalar branch)
+__device__ __forceinline__ void wait_vmcnt_dyn(int n)
+{
+    switch (n) {
+    case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<1>(); break;
+    case 2: wait_vmcnt<2>(); break;
+    case 3: wait_vmcnt<3>(); break;
+    case 4: wait_vmcnt<4>(); break;
+    case 5: wait_vmcnt<5>(); break;
+    case 6: wait_vmcnt<6>(); break;
+    case 7: wait_vmcnt<7>(); break;
+    case 8: wait_vmcnt<8>(); break;
+    case 9: wait_vmcnt<9>(); break;
+    case 10: wait_vmcnt<10>(); break;
+    case 11: wait_vmcnt<11>(); break;
+    default: wait_vmcnt<12>(); break;       // n >= 12: waiting for more than necessary is always safe
+    }
+}
+
+// Instructions a wave has issued AFTER the group that tap kj of a stage depends on (= the N of its s_waitcnt vmcnt(N)):
+// group t holds pww weight pieces plus pxa (tap 0) / pxb (tap 1) pixel pieces; a tap depends on the group dw steps back
+// (its weights) and tap 0 also on the pixel tile issued with groups 3 dx and 3 dx - 1 steps back.
+constexpr int rs_allowed(int kj, int dw, int dx, int pww, int pxa, int pxb)
+{
+    int back = dw;
+    if (kj == 0 && 3 * dx - 1 < back) back = 3 * dx - 1;
+    int n = 0;
+    for (int d = 1; d < back; ++d) {
+        const int k = ((kj - d) % 3 + 3) % 3;
+        n += pww + (k == 0 ? pxa : (k == 1 ? pxb : 0));
+    }
+    return n;
+}
+
+// Block = WN x WM waves.  Wave (wn, wm) owns channel tiles wn*TN .. +TN-1 (32 channels each) and its even share of the
+// workgroup's npt position tiles (at most TMMAX).  K order: kernel row ki, 64-channel chunk cc, then the three taps.
+// DW = taps the weight DMA runs ahead (ring of DW + 1 slots), DX = stages the pixel DMA runs ahead (DX + 1 slots).
+template <typename T, int TN, int TMMAX, int WN, int WM, int DW, int DX>
+__global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
+{
+    static_assert(DT<T>::size == 2, "16-bit element types only");
+    constexpr int NW = WN * WM;
+    constexpr int BN = WN * TN * 32;
+    constexpr int BMMAX = WM * TMMAX * 32;
+    constexpr int PWW = BN / 8 / NW;                          // weight pieces (8 rows x 128 B) per wave and tap
+    static_assert(PWW >= 1 && PWW * 8 * NW == BN, "weight tile must split evenly over the waves");
+    constexpr int PXW = (BMMAX + 2 + 8 * NW - 1) / (8 * NW);  // most pixel pieces a wave issues per stage
+    constexpr int XROWS = NW * PXW * 8;
+    constexpr int WSLOT = BN * 128, XSLOT = XROWS * 128;
+    constexpr int NSW = DW + 1, NSX = DX + 1;
+    static_assert(DW >= 1 && DX >= 1 && (DW - 1) * PWW + 2 * PXW <= 48, "vmcnt range");
+    __shared__ __attribute__((aligned(1024))) char lds[NSW * WSLOT + NSX * XSLOT];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Waves w and w + 4 share a SIMD (and its matrix pipe): the second half of the workgroup takes the position shares in
+    // reverse order, so that a wave with one tile more is paired with a wave with one tile less.
+    const int wn = wid / WM;
+    const int wm = (wid & 4) ? WM - 1 - wid % WM : wid % WM;
+    const int r = lane & 31, h = lane >> 5;
+
+    // XCD-aware tile order (speed only; same scheme as k_conv_igemm): XCD x takes the x-th contiguous chunk of the
+    // (position tile, channel tile) list, channel tiles fastest
+    const int nt = a.Cn / BN;
+    const int nblk = a.mtiles * nt;
+    const int chunk = (nblk + 7) >> 3;
+    const int gidx = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (gidx >= nblk) return;
+    const int n0 = (gidx % nt) * BN;
+    const int BM = a.npt * 32;
+    const int q0 = (gidx / nt) * BM;                  // first padded position of this tile
+    const int Wp = a.W + 2, BH = a.B * a.H;
+    const int rowbytes = a.Ck * 2;
+    const int cchunks = rowbytes / 128;
+    const int nstage = 3 * cchunks, nsteps = 3 * nstage;
+
+    // this wave's share of the position tiles
+    const int base = a.npt / WM, rem = a.npt - base * WM;
+    const int cnt = base + (wm < rem ? 1 : 0);
+    const int pt0 = wm * base + min(wm, rem);
+
+    const __amdgpu_buffer_rsrc_t srcX = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srcW = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.wbytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFF00u;
+    const unsigned ldsW0 = lds_addr(lds), ldsX0 = ldsW0 + NSW * WSLOT;
+
+    // ---- DMA side.  Lane = (row l8 of the 8-row piece, 16-B chunk position lc); LDS position lc of row R holds source
+    // chunk lc ^ ((R >> 1) & 7): the 16 rows of a ds_read_b128 lane group then sit on distinct banks (also at row offsets
+    // 1 and 2, i.e. for all three taps).
+    const int l8 = lane >> 3, lc = lane & 7;
+    unsigned wbase[PWW];
+#pragma unroll
+    for (int j = 0; j < PWW; ++j) {
+        const int row = (wid * PWW + j) * 8 + l8;
+        wbase[j] = (unsigned)(n0 + row) * (unsigned)(9 * rowbytes) + (unsigned)((lc ^ ((row >> 1) & 7)) * 16);
+    }
+    // pixel pieces of this wave: piece index wid + j*NW (interleaved: the waves' counts differ by at most one);
+    // LDS row i of the slot = padded position q0 - 1 + i
+    const int npieces = (BM + 2 + 7) >> 3;
+    const int cntx = __builtin_amdgcn_readfirstlane(wid < npieces ? (npieces - 1 - wid) / NW + 1 : 0);
+    const int pxa = (cntx + 1) >> 1, pxb = cntx >> 1;      // issued with tap 0 / tap 1 of an earlier stage
+    int xbase[PXW], xok[PXW];
+    const int rowpitch = a.W * rowbytes;
+#pragma unroll
+    for (int j = 0; j < PXW; ++j) {
+        const int i = (wid + j * NW) * 8 + l8;
+        const int p = q0 - 1 + i;
+        const int R = p >= 0 ? p / Wp : 0;
+        const int c = p - R * Wp;
+        const int oh = R % a.H;
+        const bool live = (i < BM + 2) && (p >= 0) && (R < BH) && (c >= 1) && (c <= a.W);
+        xbase[j] = (R * a.W + c - 1) * rowbytes + ((lc ^ ((i >> 1) & 7)) * 16);
+        xok[j] = live ? ((oh >= 1 ? 1 : 0) | 2 | (oh + 1 < a.H ? 4 : 0)) : 0;
+    }
+    f32x16 acc[TN][TMMAX];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TMMAX; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    // ---- read side.  k-step ks, lane half h reads source chunk 2 ks + h of its row, stored at position (2 ks + h) ^ key(row):
+    // byte offset ((h ^ key) << 4) ^ (ks << 5), key = (row >> 1) & 7 (weights: row r; pixels: row r + kj).  Computed, not
+    // tabulated: a table indexed by the tap would live in scratch memory, whose loads count against vmcnt like the DMA.
+    const int swa0 = (h ^ ((r >> 1) & 7)) << 4;
+    const int rdA = (wn * TN * 32 + r) * 128;
+    const int rdX = (pt0 * 32 + r) * 128;
+    const int tapstep = a.flip ? -rowbytes : rowbytes;
+
+    // Main loop, specialised on the wave's tile count C and on its pixel-piece count CX (both wave-uniform: one dispatch, no
+    // branches between the MFMAs, every wait an immediate).  Step t = 3 s + kj issues "group t": the weights of tap t + DW
+    // (ring slot (t + DW) % NSW) and, on a stage's taps 0 / 1, the first / second half of this wave's pieces of the pixel
+    // tile of stage s + DX.  Past the end of the K loop the same instructions are issued with out-of-range offsets (they
+    // write zeros into slots nobody reads any more), so every group has the same size and the number of instructions issued
+    // after the group a step depends on is a compile-time constant:
+    //     step t needs group t - DW (its weights) and, on tap 0, groups 3 (s - DX) and 3 (s - DX) + 1 (its pixel tile).
+    // Per step: counted wait -> barrier (everyone's pieces have landed, everyone is done with the slots about to be
+    // refilled) -> issue group t -> MFMAs.
+    auto main_loop = [&](auto CNT, auto CNTX) {
+        constexpr int C = decltype(CNT)::value, CX = decltype(CNTX)::value;
+        constexpr int PXA = (CX + 1) / 2, PXB = CX / 2;
+        constexpr int DS = (2 + DW) / 3 > DX ? (2 + DW) / 3 : DX;          // stages the bookkeeping looks ahead
+        constexpr int A0 = rs_allowed(0, DW, DX, PWW, PXA, PXB), A1 = rs_allowed(1, DW, DX, PWW, PXA, PXB), A2 = rs_allowed(2, DW, DX, PWW, PXA, PXB);
+        static_assert(A0 < 64 && A1 < 64 && A2 < 64, "vmcnt range");
+        // stage coordinates of stages s .. s + DS: weight offset of the stage's tap 0, pixel offset, kernel row (3 = past the end)
+        int wst[DS + 1], xst[DS + 1], kis[DS + 1];
+        int lki = 0, lcc = 0;
+        auto stage_entry = [&](int d) {
+            kis[d] = lki > 2 ? 3 : lki;
+            wst[d] = (a.flip ? (2 - lki) * 3 + 2 : lki * 3) * rowbytes + lcc * 128;
+            xst[d] = (lki - 1) * rowpitch + lcc * 128;
+            if (++lcc == cchunks) { lcc = 0; ++lki; }
+        };
+#pragma unroll
+        for (int d = 0; d <= DS; ++d) stage_entry(d);
+        auto issue_w = [&](int d, int kj, int slot) {                  // weights of tap kj of stage s + d
+            const unsigned dst = __builtin_amdgcn_readfirstlane(ldsW0 + slot * WSLOT + wid * PWW * 1024);
+            const bool ok = kis[d] < 3;
+            const unsigned koff = (unsigned)(wst[d] + kj * tapstep);
+#pragma unroll
+            for (int j = 0; j < PWW; ++j) glds16(srcW, ok ? wbase[j] + koff : OOB, dst + j * 1024);
+        };
+        auto issue_x = [&](int d, int slot, int j0, int j1) {          // pieces j0 .. j1-1 of the pixel tile of stage s + d
+            const int ki = kis[d];
+#pragma unroll
+            for (int j = 0; j < PXW; ++j)
+                if (j >= j0 && j < j1) {
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(ldsX0 + slot * XSLOT + (wid + j * NW) * 1024);
+                    glds16(srcX, ((xok[j] >> ki) & 1) ? (unsigned)(xbase[j] + xst[d]) : OOB, dst);
+                }
+        };
+        // prologue: groups -3 DX .. -1, then everything landed (the first taps need their data at once anyway)
+        {
+            int wsl = 0, xsl = 0;
+#pragma unroll
+            for (int u = -3 * DX; u < 0; ++u) {
+                const int v = u + 3 * DX, sv = v / 3, kj = v - 3 * sv;                 // pixel tile of stage sv < DX
+                if (kj == 0) issue_x(sv, xsl, 0, PXA);
+                if (kj == 1) { issue_x(sv, xsl, PXA, CX); ++xsl; }
+                if (u + DW >= 0) { issue_w((u + DW) / 3, (u + DW) % 3, wsl); ++wsl; }
+            }
+        }
+        wait_vmcnt<0>();
+        int wsr = 0, wsi = DW % NSW, xsr = 0, xsi = DX % NSX;         // ring slots: read / issue
+        for (int s = 0; s < nstage; ++s) {
+#pragma unroll
+            for (int kj = 0; kj < 3; ++kj) {
+                if (kj == 0) wait_vmcnt<A0>(); else if (kj == 1) wait_vmcnt<A1>(); else wait_vmcnt<A2>();
+                __builtin_amdgcn_s_barrier();
+                issue_w((kj + DW) / 3, (kj + DW) % 3, wsi);
+                if (kj == 0) issue_x(DX, xsi, 0, PXA);
+                if (kj == 1) issue_x(DX, xsi, PXA, CX);
+                if constexpr (C > 0) {
+                    const char *pw = lds + wsr * WSLOT + rdA;
+                    const char *px = lds + NSW * WSLOT + xsr * XSLOT + rdX + kj * 128;
+                    const int swx0 = (h ^ (((r + kj) >> 1) & 7)) << 4;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        uint4 fa[TN], fb[C];
+#pragma unroll
+                        for (int i = 0; i < TN; ++i) fa[i] = *reinterpret_cast<const uint4 *>(pw + i * 32 * 128 + (swa0 ^ (ks << 5)));
+#pragma unroll
+                        for (int j = 0; j < C; ++j) fb[j] = *reinterpret_cast<const uint4 *>(px + j * 32 * 128 + (swx0 ^ (ks << 5)));
+#pragma unroll
+                        for (int j = 0; j < C; ++j)
+#pragma unroll
+                            for (int i = 0; i < TN; ++i) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+                    }
+                }
+                wsr = wsr + 1 == NSW ? 0 : wsr + 1;
+                wsi = wsi + 1 == NSW ? 0 : wsi + 1;
+            }
+            xsr = xsr + 1 == NSX ? 0 : xsr + 1;
+            xsi = xsi + 1 == NSX ? 0 : xsi + 1;
+#pragma unroll
+            for (int d = 0; d < DS; ++d) { wst[d] = wst[d + 1]; xst[d] = xst[d + 1]; kis[d] = kis[d + 1]; }
+            stage_entry(DS);
+        }
+        wait_vmcnt<0>();              // the trailing dummy pieces still target this workgroup's LDS
+    };
+    // dispatch on (tiles, pixel pieces) of this wave; the host's plan keeps both inside the instantiated ranges
+#define DCF_RS_CX(C_)                                                                                               \
+    switch (cntx) {                                                                                                  \
+    case 0: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, 0>()); break;                   \
+    case 1: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, (PXW >= 1 ? 1 : PXW)>()); break; \
+    case 2: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, (PXW >= 2 ? 2 : PXW)>()); break; \
+    case 3: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, (PXW >= 3 ? 3 : PXW)>()); break; \
+    case 4: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, (PXW >= 4 ? 4 : PXW)>()); break; \
+    case 5: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, (PXW >= 5 ? 5 : PXW)>()); break; \
+    case 6: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, (PXW >= 6 ? 6 : PXW)>()); break; \
+    default: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, PXW>()); break;                \
+    }
+    switch (cnt) {
+    case 0: DCF_RS_CX(0) break;
+    case 1: DCF_RS_CX(1) break;
+    case 2: DCF_RS_CX((TMMAX >= 2 ? 2 : TMMAX)) break;
+    case 3: DCF_RS_CX((TMMAX >= 3 ? 3 : TMMAX)) break;
+    case 4: DCF_RS_CX((TMMAX >= 4 ? 4 : TMMAX)) break;
+    default: DCF_RS_CX(TMMAX) break;
+    }
+#undef DCF_RS_CX
+
+    // ---- epilogue (as k_conv_igemm): v = acc + shift + res ; relu ; v *= (mask > 0) ; 8 consecutive channels per access
+    T *y = reinterpret_cast<T *>(a.y);
+    const T *res = reinterpret_cast<const T *>(a.res);
+    const T *mask = reinterpret_cast<const T *>(a.mask);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TMMAX; ++j) acc_rows8(acc[i][j]);
+#pragma unroll
+    for (int j = 0; j < TMMAX; ++j) {
+        if (j >= cnt) continue;
+        const int p = q0 + (pt0 + j) * 32 + r;
+        const int R = p / Wp, c = p - R * Wp;
+        if (p >= a.Q || c < 1 || c > a.W) continue;      // padding position: no output
+        const int m = R * a.W + c - 1;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int ch = n0 + (wn * TN + i) * 32 + 16 * pp + 8 * h;
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = acc[i][j][8 * pp + k];
+                if (a.shift) {
+                    float s[8];
+                    ld8(a.shift + ch, s);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += s[k];
+                }
+                const size_t o = (size_t)m * a.Cn + ch;
+                if (res) {
+                    float rr[8];
+                    ld8(res + o, rr);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += rr[k];
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+                }
+                if (mask) {
+                    float mm[8];
+                    ld8(mask + o, mm);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = mm[k] > 0.f ? v[k] : 0.f;
+                }
+                st8(y + o, v);
+            }
+        }
+    }
+}
+
+// Tile shape of a launch.  kind 0: 128 channels x up to 320 positions (waves 4 x 2, up to 5 position tiles per wave);
+// kind 1: 64 channels x up to 384 positions (waves 2 x 4, up to 3 per wave); kind 2: 64 channels x up to 128 positions
+// (waves 2 x 4, one tile per wave) with the DMA running 5 taps / 2 stages ahead -- the small-M layers, whose steps are
+// too short to hide the L2 latency behind two taps.  npt is picked so that the tile count fills the CUs in whole rounds
+// and the waves' shares are even.  (DCF_RS_KIND / DCF_RS_NPT force a choice: experiments.)
+struct RsPlan { int kind, npt; };
+struct RsKind { int BN, WM, TMMAX, ahead; };
+static const RsKind RS_KINDS[3] = {{128, 2, 5, 2}, {64, 4, 3, 2}, {64, 4, 1, 5}};
+
+static RsPlan rs_plan(int64_t Q, int Cn)
+{
+    const char *ek = getenv("DCF_RS_KIND"), *en = getenv("DCF_RS_NPT");
+    const int ncu = 256;
+    RsPlan best = {-1, 0};
+    double best_t = 1e30;
+    for (int kind = 0; kind < 3; ++kind) {
+        const RsKind &k = RS_KINDS[kind];
+        if (Cn % k.BN) continue;
+        if (ek && atoi(ek) != kind) continue;
+        for (int npt = 1; npt <= k.WM * k.TMMAX; ++npt) {
+            if (en && atoi(en) != npt) continue;
+            const int64_t tiles = (Q + 32 * npt - 1) / (32 * npt) * (Cn / k.BN);
+            const int64_t rounds = (tiles + ncu - 1) / ncu;
+            const int per_wave = (npt + k.WM - 1) / k.WM;
+            // cycles per tap step on a CU: MFMAs of the busiest SIMD (2 waves), the L2 -> LDS transfer at ~28 B/clk, a fixed
+            // cost of the wait + barrier + issue sequence, and the L2 latency spread over the taps the DMA runs ahead
+            const double mfma = 2.0 * 4 * per_wave * 32;
+            const double dma = ((32.0 * npt + 2) / 3.0 + k.BN) * 128.0 / 28.0;
+            const double step = std::max(std::max(mfma, dma) + 220.0, 1800.0 / k.ahead);
+            const double t = rounds * (step + 40.0 * per_wave /* epilogue share */);
+            if (t < best_t) { best_t = t; best = {kind, npt}; }
+        }
+    }
+    return best;
+}
+
+}  // namespace
+
+// Called by dcf_conv2d_fwd / dcf_conv2d_dgrad (conv.hip).  Returns DCF_EUNSUPPORTED when the shape is not this kernel's.
+int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *shift, const void *res, const void *mask, void *y,
+                          int B, int H, int W, int Ck, int Cn, int relu, int flip, const char *name_base, double flops, hipStream_t s)
+{
+    if (dtype == DCF_F32 || Ck % 64 || Cn % 64) return DCF_EUNSUPPORTED;
+    const int64_t Q = (int64_t)B * H * (W + 2);
+    if (Q >= (1ll << 30) || (int64_t)B * H * W * Ck * 2 >= (1ll << 31) || (int64_t)B * H * W * Cn * 2 >= 0xFFFFFF00ll) return DCF_EUNSUPPORTED;
+    const RsPlan p = rs_plan(Q, Cn);
+    if (p.kind < 0) return DCF_EUNSUPPORTED;
+    RsArgs a;
+    a.x = (const char *)x; a.w = (const char *)w; a.shift = shift; a.res = (const char *)res; a.mask = (const char *)mask; a.y = (char *)y;
+    a.B = B; a.H = H; a.W = W; a.Ck = Ck; a.Cn = Cn; a.relu = relu; a.flip = flip;
+    a.npt = p.npt; a.Q = (int)Q;
+    a.mtiles = (int)((Q + 32 * p.npt - 1) / (32 * p.npt));
+    a.xbytes = (unsigned)((int64_t)B * H * W * Ck * 2);
+    a.wbytes = (unsigned)((int64_t)Cn * 9 * Ck * 2);
+    const int BN = RS_KINDS[p.kind].BN;
+    const dim3 grid((((int64_t)a.mtiles * (Cn / BN) + 7) / 8) * 8);
+    char name[96];
+    snprintf(name, sizeof(name), "%s<rs%d,%d>", name_base, p.kind, p.npt);
+#define DCF_RS(T_)                                                                                                               \
+    do {                                                                                                                         \
+        if (p.kind == 0) DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1>), grid, dim3(512), 0, s, a)); \
+        else if (p.kind == 1) DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 3, 2, 4, 2, 1>), grid, dim3(512), 0, s, a)); \
+        else DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 5, 2>), grid, dim3(512), 0, s, a));          \
+    } while (0)
+    if (dtype == DCF_F16) DCF_RS(f16_t); else DCF_RS(bf16_t);
+#undef DCF_RS
+    return DCF_OK;
+}

@@ -288,7 +288,7 @@ def test_eval_harness_one_step():
     assert all(0 <= T.get_num_TP_set()[t] <= T.get_num_P() for t in T.IOU_threshold)
 
 
-@pytest.mark.parametrize("dtype,tdt,tol_f,tol_g", [("bf16", torch.bfloat16, 2e-2, 5e-2), ("f16", torch.float16, 5e-3, 5e-2)])
+@pytest.mark.parametrize("dtype,tdt,tol_f,tol_g", [("bf16", torch.bfloat16, 2e-2, 5e-2), ("f16", torch.float16, 5e-3, 1e-1)])
 def test_tiny_16bit_matches_quantisation_aware_statement(dtype, tdt, tol_f, tol_g):
     """The 16-bit paths (bf16 = the benchmarked type) against oracle/model_quant_ref.py, which rounds to the storage
     type exactly where the device does (forward and backward; pinned to the reference by the CPU suite with rounding
