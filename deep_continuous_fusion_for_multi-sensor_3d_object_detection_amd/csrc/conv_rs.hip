@@ -45,6 +45,7 @@ struct RsArgs {
     int mtiles;           // position tiles of the launch
     int Q;                // padded positions B*H*(W+2)
     unsigned xbytes, wbytes;
+    int dbg;              // experiments (DCF_RS_DBG, tools/rs_ablate.py): 1 no MFMAs, 2 pixel DMA reads nothing, 4 no epilogue, 16 weight DMA reads nothing
 };
 
 // s_waitcnt vmcnt(n) for a wave-uniform runtime n (the immediate must be a constant: one scalar branch)
@@ -206,7 +207,7 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
         for (int d = 0; d <= DS; ++d) stage_entry(d);
         auto issue_w = [&](int d, int kj, int slot) {                  // weights of tap kj of stage s + d
             const unsigned dst = __builtin_amdgcn_readfirstlane(ldsW0 + slot * WSLOT + wid * PWW * 1024);
-            const bool ok = kis[d] < 3;
+            const bool ok = kis[d] < 3 && !(a.dbg & 16);
             const unsigned koff = (unsigned)(wst[d] + kj * tapstep);
 #pragma unroll
             for (int j = 0; j < PWW; ++j) glds16(srcW, ok ? wbase[j] + koff : OOB, dst + j * 1024);
@@ -217,7 +218,7 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
             for (int j = 0; j < PXW; ++j)
                 if (j >= j0 && j < j1) {
                     const unsigned dst = __builtin_amdgcn_readfirstlane(ldsX0 + slot * XSLOT + (wid + j * NW) * 1024);
-                    glds16(srcX, ((xok[j] >> ki) & 1) ? (unsigned)(xbase[j] + xst[d]) : OOB, dst);
+                    glds16(srcX, (((xok[j] >> ki) & 1) && !(a.dbg & 2)) ? (unsigned)(xbase[j] + xst[d]) : OOB, dst);
                 }
         };
         // prologue: groups -3 DX .. -1, then everything landed (the first taps need their data at once anyway)
@@ -238,10 +239,12 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
             for (int kj = 0; kj < 3; ++kj) {
                 if (kj == 0) wait_vmcnt<A0>(); else if (kj == 1) wait_vmcnt<A1>(); else wait_vmcnt<A2>();
                 __builtin_amdgcn_s_barrier();
+                // (issuing the second half-workgroup's DMA after its MFMAs instead -- waves w and w + 4 share a SIMD -- was
+                // measured: no gain, 26.7 -> 27.3 us on the 128-channel stage)
                 issue_w((kj + DW) / 3, (kj + DW) % 3, wsi);
                 if (kj == 0) issue_x(DX, xsi, 0, PXA);
                 if (kj == 1) issue_x(DX, xsi, PXA, CX);
-                if constexpr (C > 0) {
+                if constexpr (C > 0) if (!(a.dbg & 1)) {
                     const char *pw = lds + wsr * WSLOT + rdA;
                     const char *px = lds + NSW * WSLOT + xsr * XSLOT + rdX + kj * 128;
                     const int swx0 = (h ^ (((r + kj) >> 1) & 7)) << 4;
@@ -291,6 +294,7 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
     }
 #undef DCF_RS_CX
 
+    if (a.dbg & 4) return;
     // ---- epilogue (as k_conv_igemm): v = acc + shift + res ; relu ; v *= (mask > 0) ; 8 consecutive channels per access
     T *y = reinterpret_cast<T *>(a.y);
     const T *res = reinterpret_cast<const T *>(a.res);
@@ -394,6 +398,7 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
     a.x = (const char *)x; a.w = (const char *)w; a.shift = shift; a.res = (const char *)res; a.mask = (const char *)mask; a.y = (char *)y;
     a.B = B; a.H = H; a.W = W; a.Ck = Ck; a.Cn = Cn; a.relu = relu; a.flip = flip;
     a.npt = p.npt; a.Q = (int)Q;
+    { const char *e = getenv("DCF_RS_DBG"); a.dbg = e ? atoi(e) : 0; }
     a.mtiles = (int)((Q + 32 * p.npt - 1) / (32 * p.npt));
     a.xbytes = (unsigned)((int64_t)B * H * W * Ck * 2);
     a.wbytes = (unsigned)((int64_t)Cn * 9 * Ck * 2);

@@ -406,15 +406,58 @@ def test_cfg2_size_16bit_step_matches_fp32_path(dtype):
         assert float((a - b).abs().max() / b.abs().max()) < (2e-2 if dtype == "bf16" else 4e-3), name
         assert float((a - b).norm() / b.norm()) < (1e-2 if dtype == "bf16" else 2e-3), name
     assert float((g16 - g32).norm() / g32.norm()) < (5e-2 if dtype == "bf16" else 1e-2)
-    worst, wk = 0.0, None
+    errs = []
     for (key, shape, off, n, layout) in m32._plan.table.entries:
         if n < 4096:
             continue
         a, b = g16[off:off + n], g32[off:off + n]
-        e = float((a - b).abs().max() / (b.abs().max() + 1e-20))
-        if e > worst:
-            worst, wk = e, key
-    assert worst < (1e-1 if dtype == "bf16" else 3e-2), "gradient of %s: rel err %g" % (wk, worst)
+        errs.append((float((a - b).abs().max() / (b.abs().max() + 1e-20)), float((a - b).norm() / (b.norm() + 1e-20)), key))
+    errs.sort(reverse=True)
+    print("worst per-tensor gradient errors (max-rel, L2-rel):", errs[:6])
+    # Per tensor these are bounds on ROUNDING NOISE, not on implementation error (that is what the quantisation-aware test
+    # below is for): the weight gradient of an early, wide layer is a sum over 10^5 pixels of terms that largely cancel,
+    # and the noise grows with the terms, not with the sum -- measured 0.14 relative L2 / 0.28 of the maximum on
+    # layer3.resblock_0.conv1 with the generic kernels and with the row-sharing ones alike.  A dropped tile or a wrong tap
+    # in any layer gives O(1).
+    bound = 1.0 if dtype == "bf16" else 0.25
+    assert max(e[1] for e in errs) < 0.25 * bound, "gradient of %s: relative L2 error %g" % (max(errs, key=lambda e: e[1])[2], max(e[1] for e in errs))
+    assert errs[0][0] < 0.5 * bound, "gradient of %s: rel err %g" % (errs[0][2], errs[0][0])
+
+
+def test_cfg2_size_bf16_lidar_step_matches_quantisation_aware_statement():
+    """The benchmarked type at the benchmarked size: the LiDAR stream (the reference's own network, model.py:140-204) at
+    704x800, one frame, bf16, forward and backward against oracle/model_quant_ref.py (rounds where the device rounds; pinned
+    to the reference by the CPU suite).  Every convolution launch here has the shape it has in the bench -- row-sharing
+    tiles, > 512-workgroup implicit GEMMs, parity-class stride-2 dgrads, grouped weight gradients -- and what separates
+    the two sides is fp32 summation order only: forward <= 2e-2 of the maximum, every weight gradient <= 5e-2 relative L2."""
+    from oracle import geometry_ref, model_quant_ref, model_ref
+    det, calib = pkg("detfill"), pkg("calib")
+    cfg = _cfg2_config("bf16", fusion=False)
+    pts = det.synthetic_points(100000, (0.0, 70.4, -40.0, 40.0, -2.4, 0.8), 41)
+    grid, _, _, _, _ = geometry_ref.voxelization_projection(pts, cfg, calib.kitti_like_crt(), proj_mode="correct")
+    x = torch.from_numpy(grid).unsqueeze(0)
+    net = pkg("model").ObjectDetection_DCF(cfg)
+    det.fill_state_dict(net)
+    net = net.cuda()
+    R = torch.from_numpy(det.uniform((1, 32, 176, 200), 43, -1.0, 1.0))
+    R[:, 18:] = 0
+    pred = net(x.cuda(), torch.zeros(1, 3, 8, 8, dtype=torch.uint8, device="cuda"))
+    (pred * R.cuda()).sum().backward()
+    sd = model_ref.make_state_dict(model_ref.lidar_state_shapes(cfg))
+    params = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+    ref = model_quant_ref.forward(params, cfg, x, torch.bfloat16)
+    (ref * R).sum().backward()
+    got = pred.detach().cpu()
+    for name, sl in (("cls", slice(0, 4)), ("reg", slice(4, 18)), ("bbox", slice(18, 32))):
+        err = float((got[:, sl] - ref.detach()[:, sl]).abs().max() / ref.detach()[:, sl].abs().max())
+        assert err < 2e-2, "cfg2-size bf16 %s: rel err %g vs the quantisation-aware statement" % (name, err)
+    errs = []
+    for k, p in net.named_parameters():
+        want = params[k].grad
+        errs.append((float((p.grad.cpu() - want).norm() / (want.norm() + 1e-20)), k))
+    errs.sort(reverse=True)
+    print("worst weight-gradient errors vs the quantisation-aware statement:", errs[:4])
+    assert errs[0][0] < 5e-2, "gradient of %s: relative L2 error %g" % (errs[0][1], errs[0][0])
 
 
 def _backbone_sd(cfg):
