@@ -95,6 +95,7 @@ class HipBackend(object):
         self.table = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.dev)
         self.nconv = len(layers)
         self.max_cout = max(L.cout for L in layers)
+        self._couts = (ctypes.c_int32 * len(layers))(*[L.cout for L in layers])      # host copy for dcf_wgrad_finalize_rows
 
     def _w(self, L, dgrad=False):
         # raw device address (the arenas never move): a tensor slice per launch costs the host ~3 us, x160 per step
@@ -161,8 +162,8 @@ class HipBackend(object):
 
     def end_backward(self, layers):
         self._flush_wgrads()
-        H.call("dcf_wgrad_finalize", self.table, self.nconv, self.max_cout, self.params, self.buffers, self.ssarena, self.slabs, self.gsum,
-               self.grads, BN_EPS, H.stream_ptr())
+        H.call("dcf_wgrad_finalize_rows", self.table, self.nconv, ctypes.addressof(self._couts), self.params, self.buffers, self.ssarena,
+               self.slabs, self.gsum, self.grads, BN_EPS, H.stream_ptr())
 
     # ------------------------------------------------------------------ convolutions
     def _amax(self, L):

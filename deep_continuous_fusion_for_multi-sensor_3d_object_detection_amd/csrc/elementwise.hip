@@ -576,17 +576,37 @@ __global__ void __launch_bounds__(256) k_weight_prep(const dcf_conv_param *table
 // Gradient finalisation, one block per (conv, output channel): fixed-order reduction of the
 // wgrad slabs (16 B per lane, 4 independent partial sums), then the folded-BN chain rule
 //   dW = scale*G ; dbeta = sum g ; dgamma = (<W,G> - mean*dbeta) * rsqrt(var+eps).
+// rows = kernel-argument copy of the layers' first rows (prefix sums of cout): the grid is exactly one block per (conv, output
+// channel) instead of max_cout x nconv blocks of which three quarters exit at once
+#define DCF_FIN_MAXCONV 256
+struct FinRows { int n; int first[DCF_FIN_MAXCONV + 1]; };
+
 __global__ void __launch_bounds__(256) k_wgrad_finalize(const dcf_conv_param *table, const float *params, const float *buffers,
                                                         const float *ssarena, const float *slabs, const float *gsum, float *grads, float eps,
-                                                        int grouped)
+                                                        int grouped, FinRows rows)
 {
-    const dcf_conv_param d = table[blockIdx.y];
-    const int co = blockIdx.x;
+    int li, co;
+    if (rows.n > 0) {                            // binary search of the block's layer in the (scalar, cached) kernel arguments
+        int lo = 0, hi = rows.n;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if ((int)blockIdx.x >= rows.first[mid]) lo = mid; else hi = mid;
+        }
+        li = lo; co = blockIdx.x - rows.first[lo];
+    } else {
+        li = blockIdx.y; co = blockIdx.x;
+    }
+    const dcf_conv_param d = table[li];
     if (co >= d.cout) return;
     const int K = d.taps * d.cin;
     const int64_t slab_elems = (int64_t)d.cout_pad * K;
     const float scale = ssarena[d.shift_off + co];
     float dot = 0.f;
+    // dbeta: per-wave partial sums written by the wgrad kernel, reduced with a fixed thread mapping (loaded first: independent of
+    // the slab reduction below, so their latency hides under it)
+    float db = 0.f;
+    if (d.gamma_off >= 0)
+        for (int sp = threadIdx.x; sp < 4 * d.nsplit; sp += blockDim.x) db += gsum[d.gsum_off + (int64_t)sp * d.cout_pad + co];
     // Rows shorter than the block (K/4 < 256 lanes: the 1x1 and 32-channel layers, which are also the ones with hundreds
     // of slabs) are reduced by G = 256/(K/4) thread groups, group g taking slabs g, g+G, ...; the group sums meet in LDS
     // and are added in group order, so the result does not depend on timing.
@@ -599,6 +619,7 @@ __global__ void __launch_bounds__(256) k_wgrad_finalize(const dcf_conv_param *ta
     for (int k = kbeg; k < K; k += kstep) {
         const int64_t e = (int64_t)co * K + k;
         const float *sp = slabs + d.slab_off + e;
+        const float4 w = ld4(params + d.w_off + e);
         float4 part[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) part[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -632,15 +653,11 @@ __global__ void __launch_bounds__(256) k_wgrad_finalize(const dcf_conv_param *ta
             if (((k & 31) >> 2) == 7) G4[0] = G4[1] = G4[2] = 0.f;
             G4[3] = 0.f;
         }
-        const float4 w = ld4(params + d.w_off + e);
         dot += (w.x * G4[0] + w.y * G4[1]) + (w.z * G4[2] + w.w * G4[3]);
         const float sc = d.gamma_off >= 0 ? scale : 1.f;
         st4(grads + d.w_off + e, make_float4(sc * G4[0], sc * G4[1], sc * G4[2], sc * G4[3]));
     }
     if (d.gamma_off < 0) return;
-    // dbeta: per-wave partial sums written by the wgrad kernel, reduced with a fixed thread mapping
-    float db = 0.f;
-    for (int sp = threadIdx.x; sp < 4 * d.nsplit; sp += blockDim.x) db += gsum[d.gsum_off + (int64_t)sp * d.cout_pad + co];
     __shared__ float red[8];
     dot = wave_sum(dot);
     db = wave_sum(db);
@@ -1018,16 +1035,43 @@ extern "C" int dcf_weight_prep(int dtype, const dcf_conv_param *table, int nconv
     return DCF_OK;
 }
 
-extern "C" int dcf_wgrad_finalize(const dcf_conv_param *table, int nconv, int max_cout, const float *params, const float *buffers,
-                                  const float *ssarena, const float *slabs, const float *gsum, float *grads, float eps,
-                                  dcf_stream_t stream)
+static int wgrad_finalize_impl(const char *who, const dcf_conv_param *table, int nconv, int max_cout, const int32_t *cout_host, const float *params,
+                               const float *buffers, const float *ssarena, const float *slabs, const float *gsum, float *grads, float eps,
+                               dcf_stream_t stream)
 {
-    DCF_REQUIRE(table && nconv > 0 && max_cout > 0 && params && ssarena && slabs && gsum && grads, "dcf_wgrad_finalize: bad arguments");
+    DCF_REQUIRE(table && nconv > 0 && params && ssarena && slabs && gsum && grads, "%s: bad arguments", who);
     hipStream_t s = S(stream);
     static const char *grp_env = getenv("DCF_FINALIZE_GROUPS");
     const int grouped = grp_env ? atoi(grp_env) : 1;
-    DCF_LAUNCH("wgrad_finalize", s, hipLaunchKernelGGL(k_wgrad_finalize, dim3(max_cout, nconv), dim3(256), 0, s, table, params, buffers, ssarena, slabs, gsum, grads, eps, grouped));
+    FinRows rows;
+    rows.n = 0;
+    dim3 grid(max_cout, nconv);
+    if (cout_host && nconv <= DCF_FIN_MAXCONV) {
+        int tot = 0;
+        for (int i = 0; i < nconv; ++i) { rows.first[i] = tot; tot += cout_host[i]; }
+        for (int i = nconv; i <= DCF_FIN_MAXCONV; ++i) rows.first[i] = tot;
+        rows.n = nconv;
+        grid = dim3(tot);
+    }
+    DCF_REQUIRE(grid.x > 0, "%s: empty grid", who);
+    DCF_LAUNCH("wgrad_finalize", s, hipLaunchKernelGGL(k_wgrad_finalize, grid, dim3(256), 0, s, table, params, buffers, ssarena, slabs, gsum, grads, eps, grouped, rows));
     return DCF_OK;
+}
+
+extern "C" int dcf_wgrad_finalize(const dcf_conv_param *table, int nconv, int max_cout, const float *params, const float *buffers,
+                                  const float *ssarena, const float *slabs, const float *gsum, float *grads, float eps, dcf_stream_t stream)
+{
+    DCF_REQUIRE(max_cout > 0, "dcf_wgrad_finalize: bad arguments");
+    return wgrad_finalize_impl("dcf_wgrad_finalize", table, nconv, max_cout, nullptr, params, buffers, ssarena, slabs, gsum, grads, eps, stream);
+}
+
+extern "C" int dcf_wgrad_finalize_rows(const dcf_conv_param *table, int nconv, const int32_t *cout_host, const float *params, const float *buffers,
+                                       const float *ssarena, const float *slabs, const float *gsum, float *grads, float eps, dcf_stream_t stream)
+{
+    DCF_REQUIRE(cout_host, "dcf_wgrad_finalize_rows: bad arguments");
+    int mx = 1;
+    for (int i = 0; i < nconv; ++i) mx = cout_host[i] > mx ? cout_host[i] : mx;
+    return wgrad_finalize_impl("dcf_wgrad_finalize_rows", table, nconv, mx, cout_host, params, buffers, ssarena, slabs, gsum, grads, eps, stream);
 }
 
 extern "C" int dcf_adam_step(float *params, const float *grads, float *m, float *v, int64_t n, float lr, float beta1,

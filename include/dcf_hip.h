@@ -185,6 +185,11 @@ int dcf_weight_prep(int dtype, const dcf_conv_param *table, int nconv, const flo
 int dcf_wgrad_finalize(const dcf_conv_param *table, int nconv, int max_cout, const float *params, const float *buffers,
                        const float *ssarena, const float *slabs, const float *gsum, float *grads, float eps,
                        dcf_stream_t stream);
+/* Same, with the layers' cout values on the HOST (cout_host[nconv], nconv <= 256): one workgroup per (conv, output channel)
+ * exactly, instead of a max_cout x nconv grid whose surplus workgroups exit at once. */
+int dcf_wgrad_finalize_rows(const dcf_conv_param *table, int nconv, const int32_t *cout_host, const float *params, const float *buffers,
+                            const float *ssarena, const float *slabs, const float *gsum, float *grads, float eps,
+                            dcf_stream_t stream);
 
 /* ------------------------------------------------------------- fp8 forward convolutions (csrc/conv_fp8.hip)
  * BASELINE.json configs[4] / SURVEY.md 8(d) cfg5 ("fp8 MFMA convs, fp32 accumulate, bf16 epilogue"); the reference has
