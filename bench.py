@@ -101,11 +101,32 @@ def train_step(trainer, pool, ids):
     trainer.one_step(x_lidar, x_image, boxes, nb, geom=geom)
 
 
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E (6.3 TB/s measured with a float4 copy)
+
+
+def mfma_peak(name):
+    """Dense MFMA peak of the element type a kernel name carries (TFLOP/s), MI355X_MICROARCH.md."""
+    return 5000.0 if "fp8" in name else (2500.0 if ("bf16" in name or "f16" in name) else 157.3)
+
+
+KERNEL_CLASSES = (      # (class, name prefixes) -- SURVEY.md 8(d) "binding roof per class"
+    ("conv forward (MFMA implicit GEMM)", ("conv_fwd", "stem_fwd")),
+    ("conv input gradient", ("conv_dgrad",)),
+    ("conv weight gradient", ("conv_wgrad", "stem_wgrad")),
+    ("weight prep / slab finalisation / Adam", ("weight_prep", "wgrad_finalize", "adam")),
+    ("voxelise + project + compact", ("voxel_", "project_", "compact_", "range_")),
+    ("KNN (sort + search + inverse maps)", ("knn_", "scan_", "inv_")),
+    ("fusion gather / point sampling", ("fusion_", "point_sample", "rowscale_")),
+    ("elementwise (resize, pool, ReLU mask, head, casts, loss)", ("resize_", "maxpool_", "relu_", "head_", "cast", "loss_", "nchw_", "nhwc_", "image_")),
+)
+
+
 def roofline_leg(trainer, pool, B, steps):
     """Instrumented pass of the same train step: libdcf_hip brackets every launch with HIP events on the
-    launch stream and records the launch's algorithmic flops (conv kernels: 2*M*Cout*Cin*taps; dgrad is
-    priced at the forward conv's flops).  Kernel names are template instantiations, so the average
-    durations line up with `rocprofv3 --kernel-trace --stats` rows (profiles/)."""
+    launch stream and records the launch's ALGORITHMIC work as the launch itself declares it inside the library:
+    flops (conv kernels: 2*M*Cout*Cin*taps; dgrad is priced at the forward conv's flops) and / or bytes (the tensors a
+    kernel has to read and write once, whatever its tiling re-reads).  Kernel names are template
+    instantiations, so the average durations line up with `rocprofv3 --kernel-trace --stats` rows (profiles/)."""
     Hm = pkg("_hip")
     trainer.model.graphs_off = True                    # per-launch event brackets need eager launches
     Hm.call("dcf_prof_reset")
@@ -118,26 +139,59 @@ def roofline_leg(trainer, pool, B, steps):
     trainer.model.graphs_off = False
     prof = Hm.prof_read()
     Hm.call("dcf_prof_reset")
-    empty = prof.pop("__empty_bracket__", (0.0, 1, 0.0))
+    empty = prof.pop("__empty_bracket__", (0.0, 1, 0.0, 0.0))
     bracket_ms = empty[0] / max(empty[1], 1)             # cost of the event pair itself, subtracted per launch
-    prof = {n: (max(v[0] - bracket_ms * v[1], 1e-9), v[1], v[2]) for n, v in prof.items()}
+    prof = {n: [max(v[0] - bracket_ms * v[1], 1e-9), v[1], v[2], v[3]] for n, v in prof.items()}
+    # table-driven launches cannot see their sizes inside the library: priced here from the model
+    K = trainer.model._backend
+    P = float(trainer.model.flat_params.numel())
+    if "weight_prep" in prof:
+        prof["weight_prep"][3] = prof["weight_prep"][1] * (P * 4.0 + float(K.warena.numel()))
+    if "wgrad_finalize" in prof and K.slabs is not None:
+        prof["wgrad_finalize"][3] = prof["wgrad_finalize"][1] * (float(K.slabs.numel()) * 4.0 + P * 8.0)
     total_ms = sum(v[0] for v in prof.values())
-    table = sorted(((n, v[0], v[1], v[2]) for n, v in prof.items()), key=lambda t: -t[1])
-    name, ms, calls, work = table[0]                       # dominant kernel by GPU time
-    if work > 0:
-        achieved = work / (ms * 1e-3) / 1e12
-        peak = 5000.0 if "fp8" in name else (2500.0 if ("bf16" in name or "f16" in name) else 157.3)   # dense MFMA peaks, MI355X_MICROARCH.md
-        roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None}
+
+    def rates(name, ms, work, byts):
+        tf = work / (ms * 1e-3) / 1e12 if work > 0 else None
+        gb = byts / (ms * 1e-3) / 1e9 if byts > 0 else None
+        fm = tf / mfma_peak(name) if tf is not None else None
+        fh = gb / HBM_PEAK_GBS if gb is not None else None
+        if fm is None and fh is None:
+            return tf, gb, None, None
+        bound = "mfma" if (fh is None or (fm is not None and fm >= fh)) else "hbm"
+        return tf, gb, bound, (fm if bound == "mfma" else fh)
+
+    table = sorted(((n, v[0], v[1], v[2], v[3]) for n, v in prof.items()), key=lambda t: -t[1])
+    name, ms, calls, work, byts = table[0]                 # dominant kernel by GPU time
+    tf, gb, bound, frac = rates(name, ms, work, byts)
+    if bound == "hbm":
+        roof = {"kernel": name, "bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac, 4), "traffic": None}
     else:
-        roof = {"kernel": name, "bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None}
+        roof = {"kernel": name, "bound": "mfma", "achieved": round(tf, 2) if tf else None, "peak": mfma_peak(name), "unit": "TFLOP/s",
+                "frac": round(frac, 4) if frac else None, "traffic": None}
     roof.update({"avg_launch_us": round(ms * 1e3 / max(calls, 1), 2), "launches_per_step": calls / steps,
                  "share_of_gpu_time": round(ms / total_ms, 3) if total_ms else None, "flops_per_step": work / steps,
+                 "algorithmic_bytes_per_launch": round(byts / max(calls, 1)) if byts else None,
                  "gpu_ms_per_step_all_kernels": round(total_ms / steps, 3), "event_bracket_us_subtracted": round(bracket_ms * 1e3, 2)})
-    roof["traffic"], roof["traffic_source"] = pmc_traffic(name)
-    breakdown = [{"kernel": n, "ms_per_step": round(m / steps, 4), "calls_per_step": c / steps,
-                  "tflops": round(w / (m * 1e-3) / 1e12, 1) if w > 0 and m > 0 else None} for n, m, c, w in table[:40]]
-    return roof, breakdown
+    roof["traffic"], roof["traffic_source"], roof["traffic_stale"] = pmc_traffic(name)
+    breakdown = []
+    for n, m, c, w, by in table[:48]:
+        tf, gb, bound, frac = rates(n, m, w, by)
+        breakdown.append({"kernel": n, "ms_per_step": round(m / steps, 4), "calls_per_step": c / steps, "tflops": round(tf, 1) if tf else None,
+                          "gbps": round(gb, 1) if gb else None, "bound": bound, "frac": round(frac, 4) if frac else None})
+    classes = []
+    for cname, prefixes in KERNEL_CLASSES:
+        rows = [t for t in table if t[0].startswith(prefixes)]
+        if not rows:
+            continue
+        m = sum(t[1] for t in rows); w = sum(t[3] for t in rows); by = sum(t[4] for t in rows)
+        pk = max(mfma_peak(t[0]) for t in rows)
+        tf = w / (m * 1e-3) / 1e12 if w > 0 else None
+        gb = by / (m * 1e-3) / 1e9 if by > 0 else None
+        classes.append({"class": cname, "ms_per_step": round(m / steps, 4), "share_of_gpu_time": round(m / total_ms, 3),
+                        "tflops": round(tf, 1) if tf else None, "frac_mfma": round(tf / pk, 4) if tf else None,
+                        "gbps": round(gb, 1) if gb else None, "frac_hbm": round(gb / HBM_PEAK_GBS, 4) if gb else None})
+    return roof, breakdown, classes
 
 
 def rocprof_kernel(name):
@@ -154,6 +208,8 @@ def rocprof_kernel(name):
         return "k_conv_wgrad3", [dt] + t
     if kind.startswith("conv_wgrad") or kind.startswith("stem_wgrad"):
         return ("k_conv_wgrad", [dt] + t) if t else None
+    if t and t[0].startswith("rs"):                          # row-sharing kernel: 'conv_fwd_bf16<rs0,9>' = tile kind 0, 9 position tiles
+        return "k_conv3x3_rs", [dt] + {0: ["1", "5", "4", "2", "2", "1"], 1: ["1", "3", "2", "4", "2", "1"], 2: ["1", "1", "2", "4", "5", "2"]}[int(t[0][2:])]
     if kind.startswith("conv_fwd") or kind.startswith("conv_dgrad") or kind.startswith("stem_fwd"):
         tr = "true" if "dgrad" in kind else "false"
         if t and t[-1].startswith("dma"):
@@ -166,19 +222,34 @@ def rocprof_kernel(name):
 PMC_TAG = ""          # profiles/rNNx_<tag>pmc_traffic.csv of the workload being run ("" = cfg2, the default)
 
 
+def _csrc_digest():
+    """sha256 over the kernel sources: tools/pmc_summary.py stores it next to a PMC summary, so that a summary collected
+    on other kernels than the ones running now is recognisable."""
+    import glob, hashlib
+    hsh = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, PKG, "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, PKG, "csrc", "*.h"))):
+        hsh.update(open(f, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def pmc_traffic(name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
     command (profiles/*_pmc_traffic.csv; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).
-    A bench run cannot collect PMC counters itself; returns (None, None) when no matching row exists."""
+    A bench run cannot collect PMC counters itself; returns (None, None, None) when no matching row exists.
+    Third value: True when the summary was collected on different kernel sources than the ones in the tree."""
     import csv, glob
     if PMC_TAG is None:
-        return None, None
+        return None, None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9][a-z]_" + PMC_TAG + "pmc_traffic.csv")))
     if not files:
-        return None, None
+        return None, None, None
     want = rocprof_kernel(name)
     if want is None:
-        return None, None
+        return None, None, None
+    stale = None
+    meta = files[-1][:-4] + ".meta.json"
+    if os.path.exists(meta):
+        stale = json.load(open(meta)).get("csrc_digest") != _csrc_digest()
     for row in csv.DictReader(open(files[-1])):
         k = row["kernel"]
         head = k.split(">(")[0] if ">(" in k else ""          # "... k_conv_wgrad3g<2, 2, 2, 8" of "...>((anonymous namespace)::WgArgs)"
@@ -189,34 +260,42 @@ def pmc_traffic(name):
         if (func, args) != want:
             continue
         b = (2.0 * float(row["FETCH_SIZE_KB_per_launch_raw"]) + float(row["WRITE_SIZE_KB_per_launch"])) * 1024.0
-        return round(b), os.path.basename(files[-1])
-    return None, None
+        return round(b), os.path.basename(files[-1]), stale
+    return None, None, None
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(cfg, pool_seed):
-    """The CPU restatement (oracle/, 'port') on a bounded sample of the same workload: ONE frame,
-    geometry in C, KNN on every 8th BEV row of each site (scaled x8), one fwd+bwd+Adam step of the
-    torch-CPU fp32 model with fusion.  Returns frames/s."""
-    from oracle import geometry_ref, model_ref
+    """The CPU restatement (oracle/, kind 'port': the reference has no camera stream / KNN / fusion code to run, SURVEY.md
+    F1) on a bounded sample of the same workload: ONE cfg2 frame through the whole step on all host cores --
+    geometry (C, one thread), the fused model forward of oracle/model_ref.py (camera ResNet-18 + FPN, LiDAR stream, and at
+    each of the four sites the brute-force KNN (C, one thread) + bilinear gather + per-neighbour MLP), the reference's
+    LossTotal restated in oracle/loss_ref.py on 8 boxes, backward, Adam -- and, as the one-thread figure SURVEY.md 8(d)
+    asks for, the LiDAR stream's forward + backward on one thread on a 1/16-area crop, scaled by 16.  frames/s."""
+    from oracle import geometry_ref, loss_ref, model_ref
     det = pkg("detfill")
+    D = pkg("data_import_carla")
     c = copy.deepcopy(cfg)
     threads = min(os.cpu_count() or 1, 32)        # more threads than this oversubscribes oneDNN on these shapes
     torch.set_num_threads(threads)
     lim6 = (c["lidar_x_min"], c["lidar_x_max"], c["lidar_y_min"], c["lidar_y_max"], c["lidar_z_min"], c["lidar_z_max"])
     pts = det.synthetic_points(c["max_num_pc"], lim6, pool_seed)
     img = torch.from_numpy(det.synthetic_image(c["image_height"], c["image_width"], pool_seed)).unsqueeze(0)
+    boxes, nb = D.synthetic_boxes(c, pool_seed)
     crt = pkg("calib").kitti_like_crt()
     t0 = time.time()
     grid, pc, uv, n, _ = geometry_ref.voxelization_projection(pts, c, crt, proj_mode="correct")
     t_geo = time.time() - t0
     g = geometry_ref.grid_constants(c)
-    t0 = time.time()
-    sub = 8
-    for si in range(1, 5):
-        s = 2 ** si
-        h, w = c["voxel_length"] // s, c["voxel_width"] // s
-        geometry_ref.knn_bev(pc[:n], c["fusion"]["K"], max(h // sub, 1), w, s * 1, g["aff"])  # h/8 rows: 1/8 of the pixels
-    t_knn = (time.time() - t0) * sub
     shapes = {}
     shapes.update(model_ref.lidar_state_shapes(c))
     shapes.update(model_ref.image_state_shapes(64))
@@ -225,28 +304,34 @@ def cpu_baseline(cfg, pool_seed):
     params = [v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k]
     opt = torch.optim.Adam(params, lr=c["learning_rate"], betas=(c["beta1"], 0.999))
     x = torch.from_numpy(grid).unsqueeze(0)
-    # reuse GPU-independent KNN: the model step below recomputes it with the brute-force oracle on a coarse
-    # row subsample would change the maths, so the model step is timed WITHOUT fusion gathers' KNN (timed above).
-    t_lidar = t_img = 1e30
-    for rep in range(2):                           # second repetition excludes oneDNN primitive creation
-        t0 = time.time()
-        pred = model_ref.forward(sd, c, x, None, bn_mode="eval")
-        loss = (pred[:, :18] ** 2).mean()
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        t_lidar = min(t_lidar, time.time() - t0)
-        t0 = time.time()
-        with torch.enable_grad():
-            fmap = model_ref.image_stream(sd, img, "eval")
-            fmap.square().mean().backward()
-        t_img = min(t_img, time.time() - t0)
-        if t_lidar + t_img > 20.0:
-            break
-    total = t_geo + t_knn + t_lidar + t_img
-    return {"value": round(1.0 / total, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "1 frame: C geometry %.2fs + brute-force KNN on 1/8 of BEV rows x8 = %.2fs + torch-CPU fp32 LiDAR-stream "
-                      "fwd+bwd+Adam %.2fs + ResNet-18/FPN image stream fwd+bwd %.2fs (fusion gather/MLP not included)" % (t_geo, t_knn, t_lidar, t_img)}
+    anc = model_ref.anchors(c)
+    np.random.seed(7)
+    t0 = time.time()
+    pred = model_ref.forward(sd, c, x, img, torch.from_numpy(pc).unsqueeze(0), torch.from_numpy(uv).unsqueeze(0), [n], "eval",
+                             fusion={"K": c["fusion"]["K"], "aff": g["aff"], "rmax": None})
+    t_fwd = time.time() - t0
+    t0 = time.time()
+    loss = loss_ref.loss_total(c, boxes.unsqueeze(0), torch.tensor([nb]), pred[:, 0:4], pred[:, 4:18], anc)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    t_bwd = time.time() - t0
+    total = t_geo + t_fwd + t_bwd
+    # one thread: LiDAR stream forward + backward on a 176 x 192 crop of the grid, scaled by the area ratio (16.7)
+    torch.set_num_threads(1)
+    c1 = copy.deepcopy(c)
+    ratio = (c["voxel_length"] * c["voxel_width"]) / (176.0 * 192.0)
+    c1.update(dict(voxel_length=176, voxel_width=192))
+    t0 = time.time()
+    p1 = model_ref.forward(sd, c1, x[:, :, :176, :192].contiguous(), None, bn_mode="eval")
+    (p1[:, :18] ** 2).mean().backward()
+    t_one = (time.time() - t0) * ratio
+    torch.set_num_threads(threads)
+    return {"value": round(1.0 / total, 4), "unit": "frames/s", "cores": threads, "kind": "port", "cpu": cpu_model_name(),
+            "one_thread_lidar_stream_fwd_bwd_frames_per_s": round(1.0 / t_one, 4),
+            "sample": "1 cfg2 frame, whole step: C geometry %.2fs + fused forward (ResNet-18 camera stream, LiDAR stream, 4 sites of brute-force KNN "
+                      "+ gather + per-neighbour MLP) %.2fs + LossTotal + backward + Adam %.2fs on %d threads; one-thread figure = LiDAR stream "
+                      "fwd+bwd on a 176x192 crop scaled by the area ratio (%.1fs)" % (t_geo, t_fwd, t_bwd, threads, t_one)}
 
 
 def main():
@@ -265,6 +350,7 @@ def main():
                     "(measured equal on this workload: the step is kernel-bound, not launch-bound)")
     ap.add_argument("--from-host", action="store_true", help="feed the timed steps from host memory through FrameLoader "
                     "(pinned staging + H2D on a copy stream): the PCIe-inclusive rate")
+    ap.add_argument("--no-from-host", action="store_true", help="skip the short PCIe-inclusive leg reported as `from_host`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -322,10 +408,25 @@ def main():
     loss = float(trainer.loss_value.item())
     log("timed region done: %.3f s" % dt)
 
-    roof, breakdown, cpu = None, None, None
+    roof, breakdown, classes, cpu, from_host = None, None, None, None, None
+    if not args.from_host and not args.no_from_host and ws == 1:
+        # PCIe-inclusive rate of the same step (frames start in host memory: pinned staging + H2D one batch ahead on a copy
+        # stream, frame_loader.FrameLoader); reported beside `value`, never as `value`
+        n_fh = min(args.steps, 12)
+        fl = iter(pkg("frame_loader").FrameLoader(HostFrames(pool, n_fh + 3, args.batch), args.batch))
+        trainer.one_step_raw(pool.geometry, next(fl))
+        trainer.one_step_raw(pool.geometry, next(fl))
+        barrier()
+        t1 = time.perf_counter()
+        for s in range(n_fh):
+            trainer.one_step_raw(pool.geometry, next(fl))
+        barrier()
+        dt_fh = time.perf_counter() - t1
+        from_host = {"value": round(args.batch * n_fh / dt_fh, 3), "unit": "frames/s", "ms_per_step": round(dt_fh / n_fh * 1e3, 3), "steps": n_fh,
+                     "note": "same step fed from host memory through FrameLoader (PCIe-inclusive)"}
     if not args.no_roofline:
         # every rank runs the instrumented steps (they contain the gradient all-reduce); rank 0 reports its own
-        roof, breakdown = roofline_leg(trainer, pool, args.batch, 2)
+        roof, breakdown, classes = roofline_leg(trainer, pool, args.batch, 2)
     if ws > 1:
         dist.barrier()
     if rank == 0 and ws == 1 and not args.no_cpu_baseline:
@@ -345,7 +446,7 @@ def main():
                                           args.knn, args.bn_mode, " (reference F4)" if args.bn_mode == "eval" else "", args.batch),
                           "global_batch": args.batch * ws, "parallelism": "dp%d" % ws, "final_loss": round(loss, 4),
                           "input": "host memory through FrameLoader (PCIe-inclusive)" if args.from_host else "resident in HBM"},
-               "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown}
+               "roofline": roof, "cpu_baseline": cpu, "from_host": from_host, "kernel_classes": classes, "kernel_breakdown": breakdown}
         print(json.dumps(out))
     if ws > 1:
         dist.destroy_process_group()

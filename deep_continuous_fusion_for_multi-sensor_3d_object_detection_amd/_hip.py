@@ -30,6 +30,7 @@ SIGNATURES = {
     "dcf_prof_reset": (c_int, []),
     "dcf_prof_calibrate": (c_int, [P, c_int]),
     "dcf_prof_read": (c_int, [P, P, P, P, c_int]),
+    "dcf_prof_read2": (c_int, [P, P, P, P, P, c_int]),
     "dcf_compact_workspace_bytes": (c_size_t, [c_int]),
     "dcf_range_filter": (c_int, [P, c_int, P, P, P, P, P, P]),
     "dcf_voxelize_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -197,10 +198,11 @@ def prof_read(cap=256):
     tot = (ctypes.c_double * cap)()
     cnt = (ctypes.c_int64 * cap)()
     wk = (ctypes.c_double * cap)()
-    k = lib().dcf_prof_read(ctypes.cast(names, c_void_p), ctypes.cast(tot, c_void_p), ctypes.cast(cnt, c_void_p),
-                            ctypes.cast(wk, c_void_p), cap)
+    by = (ctypes.c_double * cap)()
+    k = lib().dcf_prof_read2(ctypes.cast(names, c_void_p), ctypes.cast(tot, c_void_p), ctypes.cast(cnt, c_void_p),
+                             ctypes.cast(wk, c_void_p), ctypes.cast(by, c_void_p), cap)
     out = {}
     for i in range(k):
         nm = names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode()
-        out[nm] = (tot[i], cnt[i], wk[i])       # (total ms, launches, algorithmic flops)
+        out[nm] = (tot[i], cnt[i], wk[i], by[i])       # (total ms, launches, algorithmic flops, algorithmic bytes)
     return out

@@ -569,6 +569,8 @@ __global__ void __launch_bounds__(256) k_conv_igemm_dma(ConvArgs a)
 template <typename T, bool TR>
 int launch_igemm(const ConvArgs &a_in, hipStream_t s, const char *base, double flops)
 {
+    // algorithmic bytes: the gathered tensor and the weights read once, the output written once (+ residual / mask reads)
+    const double bytes = (double)a_in.xbytes + (double)a_in.wbytes + (double)a_in.M * a_in.Cn * DT<T>::size * (1 + (a_in.res ? 1 : 0) + (a_in.mask ? 1 : 0));
     char name[64];
     const ConvArgs &a = a_in;
     constexpr int ES = DT<T>::size;
@@ -600,17 +602,17 @@ int launch_igemm(const ConvArgs &a_in, hipStream_t s, const char *base, double f
         if constexpr (ES == 2 && KB_ == 128) {                                                                      \
             if (dma_mode && (dma_mode == 2 || db)) {                                                                 \
                 snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d,dma%d>", base, KB_, TN_, TM_, WN_, WM_, NS_);        \
-                DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm_dma<T, 128, TN_, TM_, WN_, WM_, TR, NS_>), grid, dim3(256), 0, s, a)); \
+                DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv_igemm_dma<T, 128, TN_, TM_, WN_, WM_, TR, NS_>), grid, dim3(256), 0, s, a)); \
                 launched = true;                                                                                    \
             } else if (dma_mode == 3) {   /* many workgroups: 2-deep ring keeps 2+ of them per CU */                  \
                 snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d,dma2>", base, KB_, TN_, TM_, WN_, WM_);              \
-                DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm_dma<T, 128, TN_, TM_, WN_, WM_, TR, 2>), grid, dim3(256), 0, s, a)); \
+                DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv_igemm_dma<T, 128, TN_, TM_, WN_, WM_, TR, 2>), grid, dim3(256), 0, s, a)); \
                 launched = true;                                                                                    \
             }                                                                                                       \
         }                                                                                                           \
         if (launched) {                                                                                             \
-        } else if (db) DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR, true>), grid, dim3(256), 0, s, a)); \
-        else DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR, false>), grid, dim3(256), 0, s, a)); \
+        } else if (db) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR, true>), grid, dim3(256), 0, s, a)); \
+        else DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR, false>), grid, dim3(256), 0, s, a)); \
         if (a.dbg & 4) {                                                                                            \
             unsigned long long w[4];                                                                                \
             (void)hipStreamSynchronize(s);                                                                              \
@@ -1671,6 +1673,7 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
     a.gbytes = (unsigned)((int64_t)a.M * Cout * (dtype == DCF_F32 ? 4 : 2));
     hipStream_t s = S(stream);
     const double flops = 2.0 * a.M * Cout * (double)Cin * kh * kw;
+    const double wbytes_ = (double)a.xbytes + (double)a.gbytes + (double)nsplit * Cout * kh * kw * Cin * 4.0;
     int TM, TN, KR;
     if (pad == 1 && H == Ho && W == Wo && wgrad3_tiles(Cin, Cout, kh, kw, stride, TM, TN, KR)) {
         const bool dma = dtype != DCF_F32 && wgrad3_dma(Wo, TM, TN) && (int64_t)B * H * W * a.pixbytes < (1ll << 31) && (int64_t)a.M * Cout * 2 < (1ll << 31);
@@ -1706,10 +1709,10 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
         }
 #define DCF_WG3(T_, NAME_)                                                                                                                           \
     do {                                                                                                                                             \
-        if (KR == 3) DCF_LAUNCH_W(NAME_ "<1,1,3>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3<T_, 1, 1, 3>), grid3, dim3(256), 0, s, a));            \
-        else if (TM == 2 && TN == 2) DCF_LAUNCH_W(NAME_ "<2,2,1>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3<typename std::conditional<std::is_same<T_, float>::value, bf16_t, T_>::type, 2, 2, 1>), grid3, dim3(256), 0, s, a)); \
-        else if (TM == 2) DCF_LAUNCH_W(NAME_ "<2,1,1>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3<T_, 2, 1, 1>), grid3, dim3(256), 0, s, a));       \
-        else DCF_LAUNCH_W(NAME_ "<1,2,1>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3<T_, 1, 2, 1>), grid3, dim3(256), 0, s, a));                    \
+        if (KR == 3) DCF_LAUNCH_WB(NAME_ "<1,1,3>", flops, wbytes_, s, hipLaunchKernelGGL((k_conv_wgrad3<T_, 1, 1, 3>), grid3, dim3(256), 0, s, a));            \
+        else if (TM == 2 && TN == 2) DCF_LAUNCH_WB(NAME_ "<2,2,1>", flops, wbytes_, s, hipLaunchKernelGGL((k_conv_wgrad3<typename std::conditional<std::is_same<T_, float>::value, bf16_t, T_>::type, 2, 2, 1>), grid3, dim3(256), 0, s, a)); \
+        else if (TM == 2) DCF_LAUNCH_WB(NAME_ "<2,1,1>", flops, wbytes_, s, hipLaunchKernelGGL((k_conv_wgrad3<T_, 2, 1, 1>), grid3, dim3(256), 0, s, a));       \
+        else DCF_LAUNCH_WB(NAME_ "<1,2,1>", flops, wbytes_, s, hipLaunchKernelGGL((k_conv_wgrad3<T_, 1, 2, 1>), grid3, dim3(256), 0, s, a));                    \
     } while (0)
         if (dtype == DCF_F32) DCF_WG3(float, "conv_wgrad3_f32");
         else if (dtype == DCF_F16) DCF_WG3(f16_t, "conv_wgrad3_f16");
@@ -1724,10 +1727,10 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
     dim3 grid(a.co_tiles * a.ci_tiles * kh * kw * nsplit);
 #define DCF_WG(T_, NAME_)                                                                                                                       \
     do {                                                                                                                                        \
-        if (TM == 2 && TN == 2) DCF_LAUNCH_W(NAME_ "<2,2>", flops, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 2, 2>), grid, dim3(256), 0, s, a));   \
-        else if (TM == 2) DCF_LAUNCH_W(NAME_ "<2,1>", flops, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 2, 1>), grid, dim3(256), 0, s, a));         \
-        else if (TN == 2) DCF_LAUNCH_W(NAME_ "<1,2>", flops, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 1, 2>), grid, dim3(256), 0, s, a));         \
-        else DCF_LAUNCH_W(NAME_ "<1,1>", flops, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 1, 1>), grid, dim3(256), 0, s, a));                      \
+        if (TM == 2 && TN == 2) DCF_LAUNCH_WB(NAME_ "<2,2>", flops, wbytes_, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 2, 2>), grid, dim3(256), 0, s, a));   \
+        else if (TM == 2) DCF_LAUNCH_WB(NAME_ "<2,1>", flops, wbytes_, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 2, 1>), grid, dim3(256), 0, s, a));         \
+        else if (TN == 2) DCF_LAUNCH_WB(NAME_ "<1,2>", flops, wbytes_, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 1, 2>), grid, dim3(256), 0, s, a));         \
+        else DCF_LAUNCH_WB(NAME_ "<1,1>", flops, wbytes_, s, hipLaunchKernelGGL((k_conv_wgrad<T_, 1, 1>), grid, dim3(256), 0, s, a));                      \
     } while (0)
     if (dtype == DCF_F32) DCF_WG(float, "conv_wgrad_f32");
     else if (dtype == DCF_F16) DCF_WG(f16_t, "conv_wgrad_f16");
@@ -1779,7 +1782,7 @@ extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_st
         for (int dt = DCF_BF16; dt <= DCF_F16; ++dt) {
             WgGroup g;
             int cnt = 0, blocks = 0;
-            double flops = 0.0;
+            double flops = 0.0, bytes = 0.0;     // algorithmic: x and gy read once, one fp32 slab set written
             auto flush = [&]() -> int {
                 if (cnt == 0) return DCF_OK;
                 for (int k = cnt; k <= DCF_WG_GROUP; ++k) g.off[k] = blocks;
@@ -1787,18 +1790,18 @@ extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_st
                 g.n = cnt;
 #define DCF_GRP_GEN(TM_, TN_)                                                                                                                      \
     do {                                                                                                                                           \
-        if (dt == DCF_F16) DCF_LAUNCH_W("conv_wgrad_grp_f16<" #TM_ "," #TN_ ">", flops, s, hipLaunchKernelGGL((k_conv_wgrad_grp<f16_t, TM_, TN_>), dim3(blocks), dim3(256), 0, s, g)); \
-        else DCF_LAUNCH_W("conv_wgrad_grp_bf16<" #TM_ "," #TN_ ">", flops, s, hipLaunchKernelGGL((k_conv_wgrad_grp<bf16_t, TM_, TN_>), dim3(blocks), dim3(256), 0, s, g)); \
+        if (dt == DCF_F16) DCF_LAUNCH_WB("conv_wgrad_grp_f16<" #TM_ "," #TN_ ">", flops, bytes, s, hipLaunchKernelGGL((k_conv_wgrad_grp<f16_t, TM_, TN_>), dim3(blocks), dim3(256), 0, s, g)); \
+        else DCF_LAUNCH_WB("conv_wgrad_grp_bf16<" #TM_ "," #TN_ ">", flops, bytes, s, hipLaunchKernelGGL((k_conv_wgrad_grp<bf16_t, TM_, TN_>), dim3(blocks), dim3(256), 0, s, g)); \
     } while (0)
                 if (bk == 0) {
-                    if (dt == DCF_F16) DCF_LAUNCH_W("conv_wgrad3g_grp_f16<2,2,2,8>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3g_grp<f16_t, 2, 2, 2, 8>), dim3(blocks), dim3(512), 0, s, g));
-                    else DCF_LAUNCH_W("conv_wgrad3g_grp_bf16<2,2,2,8>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3g_grp<bf16_t, 2, 2, 2, 8>), dim3(blocks), dim3(512), 0, s, g));
+                    if (dt == DCF_F16) DCF_LAUNCH_WB("conv_wgrad3g_grp_f16<2,2,2,8>", flops, bytes, s, hipLaunchKernelGGL((k_conv_wgrad3g_grp<f16_t, 2, 2, 2, 8>), dim3(blocks), dim3(512), 0, s, g));
+                    else DCF_LAUNCH_WB("conv_wgrad3g_grp_bf16<2,2,2,8>", flops, bytes, s, hipLaunchKernelGGL((k_conv_wgrad3g_grp<bf16_t, 2, 2, 2, 8>), dim3(blocks), dim3(512), 0, s, g));
                 } else if (bk == 1) DCF_GRP_GEN(2, 2);
                 else if (bk == 2) DCF_GRP_GEN(2, 1);
                 else if (bk == 3) DCF_GRP_GEN(1, 2);
                 else DCF_GRP_GEN(1, 1);
 #undef DCF_GRP_GEN
-                cnt = 0; blocks = 0; flops = 0.0;
+                cnt = 0; blocks = 0; flops = 0.0; bytes = 0.0;
                 return DCF_OK;
             };
             for (int i = 0; i < n; ++i) {
@@ -1840,6 +1843,7 @@ extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_st
                     blocks += (a.co_tiles * a.ci_tiles * it.kh * it.kw * it.nsplit + 7) / 8 * 8;
                 }
                 flops += 2.0 * it.B * Ho * Wo * (double)it.Cout * it.Cin * it.kh * it.kw;
+                bytes += (double)a.xbytes + (double)a.gbytes + (double)it.nsplit * it.Cout * it.kh * it.kw * it.Cin * 4.0;
                 if (++cnt == DCF_WG_GROUP) { int rc = flush(); if (rc) return rc; }
             }
             int rc = flush();

@@ -406,11 +406,12 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
     const dim3 grid((((int64_t)a.mtiles * (Cn / BN) + 7) / 8) * 8);
     char name[96];
     snprintf(name, sizeof(name), "%s<rs%d,%d>", name_base, p.kind, p.npt);
+    const double bytes = (double)a.xbytes + (double)a.wbytes + (double)B * H * W * Cn * 2.0 * (1 + (res ? 1 : 0) + (mask ? 1 : 0));
 #define DCF_RS(T_)                                                                                                               \
     do {                                                                                                                         \
-        if (p.kind == 0) DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1>), grid, dim3(512), 0, s, a)); \
-        else if (p.kind == 1) DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 3, 2, 4, 2, 1>), grid, dim3(512), 0, s, a)); \
-        else DCF_LAUNCH_W(name, flops, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 5, 2>), grid, dim3(512), 0, s, a));          \
+        if (p.kind == 0) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1>), grid, dim3(512), 0, s, a)); \
+        else if (p.kind == 1) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 3, 2, 4, 2, 1>), grid, dim3(512), 0, s, a)); \
+        else DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 5, 2>), grid, dim3(512), 0, s, a));          \
     } while (0)
     if (dtype == DCF_F16) DCF_RS(f16_t); else DCF_RS(bf16_t);
 #undef DCF_RS

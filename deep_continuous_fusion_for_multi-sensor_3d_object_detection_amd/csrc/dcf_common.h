@@ -30,16 +30,19 @@ void dcf_set_error(const char *fmt, ...);
 // ---------------------------------------------------------------- launch + profiling
 // Every kernel launch goes through DCF_LAUNCH so that the optional event timing
 // (dcf_prof_enable) brackets it on the stream it is launched on.
-void dcf_prof_begin(const char *name, hipStream_t s, double work = 0.0);
+void dcf_prof_begin(const char *name, hipStream_t s, double work = 0.0, double bytes = 0.0);
 void dcf_prof_end(hipStream_t s);
 extern int g_dcf_prof_on;
 
-#define DCF_LAUNCH(name, stream, ...) DCF_LAUNCH_W(name, 0.0, stream, __VA_ARGS__)
+#define DCF_LAUNCH(name, stream, ...) DCF_LAUNCH_WB(name, 0.0, 0.0, stream, __VA_ARGS__)
+// same, with the launch's ALGORITHMIC work recorded next to its time: flops (MFMA-bound kernels) ...
+#define DCF_LAUNCH_W(name, work, stream, ...) DCF_LAUNCH_WB(name, work, 0.0, stream, __VA_ARGS__)
+// ... and / or bytes: the tensors the kernel has to read and write once, whatever its tiling re-reads (HBM-bound kernels)
+#define DCF_LAUNCH_B(name, bytes, stream, ...) DCF_LAUNCH_WB(name, 0.0, bytes, stream, __VA_ARGS__)
 
-// same, with the launch's ALGORITHMIC work (flops or bytes) recorded next to its time
-#define DCF_LAUNCH_W(name, work, stream, ...)                                       \
+#define DCF_LAUNCH_WB(name, work, bytes, stream, ...)                               \
     do {                                                                            \
-        if (g_dcf_prof_on) dcf_prof_begin(name, stream, work);                      \
+        if (g_dcf_prof_on) dcf_prof_begin(name, stream, work, bytes);               \
         __VA_ARGS__;                                                                \
         if (g_dcf_prof_on) dcf_prof_end(stream);                                    \
         hipError_t e__ = hipGetLastError();                                         \
@@ -51,6 +54,7 @@ extern int g_dcf_prof_on;
 
 static inline hipStream_t S(dcf_stream_t s) { return (hipStream_t)s; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline double esize_of(int dtype) { return dtype == DCF_F32 ? 4.0 : 2.0; }
 
 // ---------------------------------------------------------------- dtype helpers
 typedef unsigned short bf16_t;  // raw bits

@@ -882,8 +882,8 @@ extern "C" int dcf_nchw_to_nhwc(int dtype, const float *x, void *y, int B, int C
     const int64_t HW = (int64_t)H * W, total = (int64_t)B * HW;
     hipStream_t s = S(stream);
     DCF_DISPATCH_DTYPE(dtype, {
-        if (C % 8 == 0) DCF_LAUNCH("nchw_to_nhwc", s, hipLaunchKernelGGL((k_nchw_to_nhwc<T, 8>), dim3(cdiv(total, 256)), dim3(256), 0, s, x, (T *)y, C, HW, total));
-        else DCF_LAUNCH("nchw_to_nhwc", s, hipLaunchKernelGGL((k_nchw_to_nhwc<T, 4>), dim3(cdiv(total, 256)), dim3(256), 0, s, x, (T *)y, C, HW, total));
+        if (C % 8 == 0) DCF_LAUNCH_B("nchw_to_nhwc", (double)total * C * (4.0 + sizeof(T)), s, hipLaunchKernelGGL((k_nchw_to_nhwc<T, 8>), dim3(cdiv(total, 256)), dim3(256), 0, s, x, (T *)y, C, HW, total));
+        else DCF_LAUNCH_B("nchw_to_nhwc", (double)total * C * (4.0 + sizeof(T)), s, hipLaunchKernelGGL((k_nchw_to_nhwc<T, 4>), dim3(cdiv(total, 256)), dim3(256), 0, s, x, (T *)y, C, HW, total));
     })
     return DCF_OK;
 }
@@ -893,7 +893,7 @@ extern "C" int dcf_nhwc_to_nchw(int dtype, const void *x, float *y, int B, int C
     DCF_REQUIRE(x && y && C % 4 == 0, "dcf_nhwc_to_nchw: C must be a multiple of 4");
     const int64_t HW = (int64_t)H * W, total = (int64_t)B * HW;
     hipStream_t s = S(stream);
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("nhwc_to_nchw", s, hipLaunchKernelGGL(k_nhwc_to_nchw<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, y, C, HW, total)); })
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("nhwc_to_nchw", (double)total * C * (4.0 + sizeof(T)), s, hipLaunchKernelGGL(k_nhwc_to_nchw<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, y, C, HW, total)); })
     return DCF_OK;
 }
 
@@ -902,7 +902,7 @@ extern "C" int dcf_image_to_nhwc4(int dtype, const uint8_t *img, void *y, int B,
     DCF_REQUIRE(img && y, "dcf_image_to_nhwc4: null pointer");
     const int64_t total = (int64_t)B * (H + 6) * (W + 8);
     hipStream_t s = S(stream);
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("image_to_nhwc4", s, hipLaunchKernelGGL(k_image_to_nhwc4<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, img, (T *)y, B, H, W)); })
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("image_to_nhwc4", (double)B * H * W * 3 + (double)total * 4 * sizeof(T), s, hipLaunchKernelGGL(k_image_to_nhwc4<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, img, (T *)y, B, H, W)); })
     return DCF_OK;
 }
 
@@ -928,7 +928,7 @@ extern "C" int dcf_relu_bwd_chansum(int dtype, void *gy, const void *y, float *g
     const int64_t stride = chan_stride(nvec, cg, blocks);
     hipStream_t s = S(stream);
     DCF_DISPATCH_DTYPE(dtype, {
-        DCF_LAUNCH("relu_bwd_chansum", s, hipLaunchKernelGGL(k_relu_bwd_chansum<T>, dim3(blocks), dim3(256), sizeof(float) * C, s, (T *)gy, (const T *)y, gsum,
+        DCF_LAUNCH_B("relu_bwd_chansum", (double)nvec * 4 * sizeof(T) * (relu ? 3 : 1), s, hipLaunchKernelGGL(k_relu_bwd_chansum<T>, dim3(blocks), dim3(256), sizeof(float) * C, s, (T *)gy, (const T *)y, gsum,
                                                               nvec, cg, relu, stride));
     })
     return DCF_OK;
@@ -942,7 +942,7 @@ extern "C" int dcf_resize_bilinear_fwd(int dtype, const void *x, const void *add
     const float sh = resize_scale(Hi, Ho, align_corners), sw = resize_scale(Wi, Wo, align_corners);
     hipStream_t s = S(stream);
     DCF_DISPATCH_DTYPE(dtype, {
-        DCF_LAUNCH("resize_fwd", s, hipLaunchKernelGGL(k_resize_fwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, (const T *)add, (T *)y, B, Hi, Wi,
+        DCF_LAUNCH_B("resize_fwd", ((double)B * Hi * Wi * C + (double)total * 4 * (add ? 2 : 1)) * sizeof(T), s, hipLaunchKernelGGL(k_resize_fwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, (const T *)add, (T *)y, B, Hi, Wi,
                                                         Ho, Wo, C / 4, align_corners, sh, sw));
     })
     return DCF_OK;
@@ -956,7 +956,7 @@ extern "C" int dcf_resize_bilinear_bwd(int dtype, const void *gy, void *gx, int 
     const float sh = resize_scale(Hi, Ho, align_corners), sw = resize_scale(Wi, Wo, align_corners);
     hipStream_t s = S(stream);
     DCF_DISPATCH_DTYPE(dtype, {
-        DCF_LAUNCH("resize_bwd", s, hipLaunchKernelGGL(k_resize_bwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)gy, (T *)gx, B, Hi, Wi, Ho, Wo, C / 4,
+        DCF_LAUNCH_B("resize_bwd", ((double)B * Ho * Wo * C + (double)total * 4) * sizeof(T), s, hipLaunchKernelGGL(k_resize_bwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)gy, (T *)gx, B, Hi, Wi, Ho, Wo, C / 4,
                                                         align_corners, sh, sw));
     })
     return DCF_OK;
@@ -968,7 +968,7 @@ extern "C" int dcf_maxpool3x3s2_fwd(int dtype, const void *x, void *y, int B, in
     DCF_REQUIRE(x && y && C % 4 == 0 && Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, "dcf_maxpool3x3s2_fwd: bad arguments");
     const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
     hipStream_t s = S(stream);
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("maxpool_fwd", s, hipLaunchKernelGGL(k_maxpool_fwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, (T *)y, B, H, W, Ho, Wo, C / 4)); })
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("maxpool_fwd", ((double)B * H * W * C + (double)total * 4) * sizeof(T), s, hipLaunchKernelGGL(k_maxpool_fwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, (T *)y, B, H, W, Ho, Wo, C / 4)); })
     return DCF_OK;
 }
 
@@ -978,7 +978,7 @@ extern "C" int dcf_maxpool3x3s2_fwd_idx(int dtype, const void *x, void *y, uint3
     DCF_REQUIRE(x && y && idx && C % 4 == 0 && Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, "dcf_maxpool3x3s2_fwd_idx: bad arguments");
     const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
     hipStream_t s = S(stream);
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("maxpool_fwd", s, hipLaunchKernelGGL(k_maxpool_fwd_idx<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, (T *)y, idx, B, H, W, Ho, Wo, C / 4)); })
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("maxpool_fwd", ((double)B * H * W * C + (double)total * 4) * sizeof(T), s, hipLaunchKernelGGL(k_maxpool_fwd_idx<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, (T *)y, idx, B, H, W, Ho, Wo, C / 4)); })
     return DCF_OK;
 }
 
@@ -988,7 +988,7 @@ extern "C" int dcf_maxpool3x3s2_bwd_idx(int dtype, const uint32_t *idx, const vo
     DCF_REQUIRE(idx && gy && gx && C % 4 == 0, "dcf_maxpool3x3s2_bwd_idx: bad arguments");
     const int64_t total = (int64_t)B * H * W * (C / 4);
     hipStream_t s = S(stream);
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("maxpool_bwd", s, hipLaunchKernelGGL(k_maxpool_bwd_idx<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, idx, (const T *)gy, (T *)gx, B, H, W, Ho, Wo, C / 4)); })
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("maxpool_bwd", ((double)B * Ho * Wo * C + (double)total * 4) * sizeof(T), s, hipLaunchKernelGGL(k_maxpool_bwd_idx<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, idx, (const T *)gy, (T *)gx, B, H, W, Ho, Wo, C / 4)); })
     return DCF_OK;
 }
 
@@ -999,8 +999,8 @@ extern "C" int dcf_maxpool3x3s2_bwd(int dtype, const void *x, const void *y, con
     const int64_t total = (int64_t)B * H * W * (C / 4);
     hipStream_t s = S(stream);
     DCF_DISPATCH_DTYPE(dtype, {
-        if (y) DCF_LAUNCH("maxpool_bwd", s, hipLaunchKernelGGL(k_maxpool_bwd_y<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, (const T *)y, (const T *)gy, (T *)gx, B, H, W, Ho, Wo, C / 4));
-        else DCF_LAUNCH("maxpool_bwd", s, hipLaunchKernelGGL(k_maxpool_bwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, (const T *)gy, (T *)gx, B, H, W, Ho, Wo, C / 4));
+        if (y) DCF_LAUNCH_B("maxpool_bwd", ((double)B * Ho * Wo * C + (double)total * 4) * sizeof(T), s, hipLaunchKernelGGL(k_maxpool_bwd_y<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, (const T *)y, (const T *)gy, (T *)gx, B, H, W, Ho, Wo, C / 4));
+        else DCF_LAUNCH_B("maxpool_bwd", ((double)B * Ho * Wo * C + (double)total * 4) * sizeof(T), s, hipLaunchKernelGGL(k_maxpool_bwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)x, (const T *)gy, (T *)gx, B, H, W, Ho, Wo, C / 4));
     })
     return DCF_OK;
 }
@@ -1011,7 +1011,7 @@ extern "C" int dcf_head_fwd(int dtype, const void *head, int Cp, const float *an
     DCF_REQUIRE(head && anchors && pred && Cp >= 20 && Cp % 4 == 0, "dcf_head_fwd: bad arguments (Cp=%d)", Cp);
     const int hw = h * w;
     hipStream_t s = S(stream);
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("head_fwd", s, hipLaunchKernelGGL(k_head_fwd<T>, dim3(cdiv((int64_t)B * hw, 256)), dim3(256), 0, s, (const T *)head, Cp, anchors, pred, B, hw)); })
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("head_fwd", (double)B * hw * (Cp * sizeof(T) + 32 * 4.0), s, hipLaunchKernelGGL(k_head_fwd<T>, dim3(cdiv((int64_t)B * hw, 256)), dim3(256), 0, s, (const T *)head, Cp, anchors, pred, B, hw)); })
     return DCF_OK;
 }
 
@@ -1022,7 +1022,7 @@ extern "C" int dcf_head_bwd(int dtype, const void *head, int Cp, const float *an
     DCF_REQUIRE(anchors && pred && gpred && ghead && Cp >= 20 && Cp % 4 == 0, "dcf_head_bwd: bad arguments");
     const int hw = h * w;
     hipStream_t s = S(stream);
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("head_bwd", s, hipLaunchKernelGGL(k_head_bwd<T>, dim3(cdiv((int64_t)B * hw, 256)), dim3(256), 0, s, Cp, anchors, pred, gpred, (T *)ghead, B, hw)); })
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("head_bwd", (double)B * hw * (Cp * sizeof(T) + 2 * 32 * 4.0), s, hipLaunchKernelGGL(k_head_bwd<T>, dim3(cdiv((int64_t)B * hw, 256)), dim3(256), 0, s, Cp, anchors, pred, gpred, (T *)ghead, B, hw)); })
     return DCF_OK;
 }
 
@@ -1081,7 +1081,7 @@ extern "C" int dcf_adam_step(float *params, const float *grads, float *m, float 
     if (n == 0) return DCF_OK;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     hipStream_t s = S(stream);
-    DCF_LAUNCH("adam", s, hipLaunchKernelGGL(k_adam, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, s, params, grads, m, v, n, (float)(lr / bc1), beta1, beta2,
+    DCF_LAUNCH_B("adam", (double)n * 28.0, s, hipLaunchKernelGGL(k_adam, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, s, params, grads, m, v, n, (float)(lr / bc1), beta1, beta2,
                                              (float)(1.0 / sqrt(bc2)), eps, gscale));
     return DCF_OK;
 }
@@ -1093,7 +1093,7 @@ extern "C" int dcf_cast(int dtype_src, const void *src, int dtype_dst, void *dst
     const int64_t n4 = n / 4;
     if (n4 == 0) return DCF_OK;
     dim3 g(cdiv(n4, 256)), b(256);
-#define DCF_CAST(TS_, TD_) DCF_LAUNCH("cast", s, hipLaunchKernelGGL((k_cast<TS_, TD_>), g, b, 0, s, (const TS_ *)src, (TD_ *)dst, n4))
+#define DCF_CAST(TS_, TD_) DCF_LAUNCH_B("cast", (double)n4 * 4 * (sizeof(TS_) + sizeof(TD_)), s, hipLaunchKernelGGL((k_cast<TS_, TD_>), g, b, 0, s, (const TS_ *)src, (TD_ *)dst, n4))
     if (dtype_src == DCF_F32 && dtype_dst == DCF_BF16) DCF_CAST(float, bf16_t);
     else if (dtype_src == DCF_BF16 && dtype_dst == DCF_F32) DCF_CAST(bf16_t, float);
     else if (dtype_src == DCF_F32 && dtype_dst == DCF_F32) DCF_CAST(float, float);
@@ -1112,7 +1112,7 @@ extern "C" int dcf_rowscale_bias_fwd(int dtype, void *y, const float *cnt, const
     const int64_t nvec = npix * (C / 4);
     if (nvec == 0) return DCF_OK;
     hipStream_t s = S(stream);
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("rowscale_bias_fwd", s, hipLaunchKernelGGL(k_rowscale_bias_fwd<T>, dim3(cdiv(nvec, 256)), dim3(256), 0, s, (T *)y, cnt, b2, nvec, C / 4)); })
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("rowscale_bias_fwd", (double)nvec * 8 * sizeof(T) + npix * 4.0, s, hipLaunchKernelGGL(k_rowscale_bias_fwd<T>, dim3(cdiv(nvec, 256)), dim3(256), 0, s, (T *)y, cnt, b2, nvec, C / 4)); })
     return DCF_OK;
 }
 
@@ -1126,7 +1126,7 @@ extern "C" int dcf_rowscale_bias_bwd(int dtype, const void *gy, const float *cnt
     // every workgroup ends with C same-address atomics on gb2: 256 workgroups instead of 1024 (0.118 -> 0.068 ms per step)
     const int64_t stride = chan_stride(nvec, cg, blocks, 64);
     hipStream_t s = S(stream);
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("rowscale_bias_bwd", s, hipLaunchKernelGGL(k_rowscale_bias_bwd<T>, dim3(blocks), dim3(256), sizeof(float) * C, s, (const T *)gy, cnt, gb2, nvec, cg, stride)); })
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("rowscale_bias_bwd", (double)nvec * 4 * sizeof(T) + npix * 4.0, s, hipLaunchKernelGGL(k_rowscale_bias_bwd<T>, dim3(blocks), dim3(256), sizeof(float) * C, s, (const T *)gy, cnt, gb2, nvec, cg, stride)); })
     return DCF_OK;
 }
 

@@ -410,7 +410,7 @@ extern "C" int dcf_point_sample_fwd(int dtype, const void *fmap, int Hf, int Wf,
     if (n_max == 0) return DCF_OK;
     hipStream_t s = S(stream);
     const int64_t total = (int64_t)n_max * (Cf / 4);
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("point_sample_fwd", s, hipLaunchKernelGGL(k_point_sample_fwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)fmap, Hf, Wf, Cf / 4, uv, count_dev, n_max, (T *)fp)); })
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("point_sample_fwd", (double)n_max * (5.0 * Cf * sizeof(T) + 8.0), s, hipLaunchKernelGGL(k_point_sample_fwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)fmap, Hf, Wf, Cf / 4, uv, count_dev, n_max, (T *)fp)); })
     return DCF_OK;
 }
 
@@ -421,7 +421,7 @@ extern "C" int dcf_point_sample_bwd(int dtype, const void *gfp, int Hf, int Wf, 
     if (n_max == 0) return DCF_OK;
     hipStream_t s = S(stream);
     const int64_t total = (int64_t)n_max * Cf;
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("point_sample_bwd", s, hipLaunchKernelGGL(k_point_sample_bwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)gfp, Hf, Wf, Cf, uv, count_dev, n_max, gfmap)); })
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("point_sample_bwd", (double)n_max * (Cf * sizeof(T) + 4.0 * Cf * 4.0 + 8.0), s, hipLaunchKernelGGL(k_point_sample_bwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)gfp, Hf, Wf, Cf, uv, count_dev, n_max, gfmap)); })
     return DCF_OK;
 }
 
@@ -434,7 +434,7 @@ extern "C" int dcf_fusion_gather_fwd(int dtype, const void *P, const float *xyz,
     g.h = h; g.w = w; g.stride = stride; g.K = K; g.xs = xs; g.xo = xo; g.ys = ys; g.yo = yo;
     hipStream_t s = S(stream);
     const int64_t total = (int64_t)h * w * (Cb / 4);
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("fusion_gather_fwd", s, hipLaunchKernelGGL(k_fusion_gather_fwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)P, xyz, idx, g, w1d, b1, Cb / 4, (T *)hsum, cnt)); })
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("fusion_gather_fwd", (double)h * w * (K * (4.0 + (double)Cb * sizeof(T)) + Cb * sizeof(T) + 4.0), s, hipLaunchKernelGGL(k_fusion_gather_fwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)P, xyz, idx, g, w1d, b1, Cb / 4, (T *)hsum, cnt)); })
     return DCF_OK;
 }
 
@@ -457,14 +457,14 @@ extern "C" int dcf_fusion_gather_bwd(int dtype, const void *P, const float *xyz,
     const int64_t groups = (hw + chunk - 1) / chunk;
     static const char *pipe_env = getenv("DCF_FUSION_PIPE");
     const bool pipe = !(pipe_env && atoi(pipe_env) == 0);
-#define DCF_FGB(KT_) DCF_LAUNCH("fusion_gather_bwd", s, hipLaunchKernelGGL((k_fusion_gather_bwd_pipe<T, KT_>), dim3(cdiv(groups * Cb, 256)), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, idx, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, chunk))
+#define DCF_FGB(KT_) DCF_LAUNCH_B("fusion_gather_bwd", (double)hw * (K * (4.0 + 2.0 * Cb * sizeof(T)) + Cb * sizeof(T)), s, hipLaunchKernelGGL((k_fusion_gather_bwd_pipe<T, KT_>), dim3(cdiv(groups * Cb, 256)), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, idx, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, chunk))
     DCF_DISPATCH_DTYPE(dtype, {
         if (pipe && K == 1) DCF_FGB(1);
         else if (pipe && K == 2) DCF_FGB(2);
         else if (pipe && K == 3) DCF_FGB(3);
         else if (pipe && K == 4) DCF_FGB(4);
         else if (pipe && K == 5) DCF_FGB(5);
-        else DCF_LAUNCH("fusion_gather_bwd", s, hipLaunchKernelGGL(k_fusion_gather_bwd<T>, dim3(cdiv(groups * Cb, 256)), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, idx, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, chunk));
+        else DCF_LAUNCH_B("fusion_gather_bwd", (double)hw * (K * (4.0 + 2.0 * Cb * sizeof(T)) + Cb * sizeof(T)), s, hipLaunchKernelGGL(k_fusion_gather_bwd<T>, dim3(cdiv(groups * Cb, 256)), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, idx, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, chunk));
     })
 #undef DCF_FGB
     return DCF_OK;
@@ -489,7 +489,7 @@ extern "C" int dcf_fusion_gather_bwd_inv(int dtype, const void *P, const float *
     static const char *cap_env = getenv("DCF_FUSION_BWD_BLOCKS");
     const int cap = cap_env ? atoi(cap_env) : 256;     // swept: 128 / 256 / 512 / uncapped = 0.52 / 0.34 / 0.36 / 0.44 ms per step
     const int blocks = std::min(cdiv(waves, FGI_THREADS / 64), cap);
-#define DCF_FGI(CJ_) DCF_LAUNCH("fusion_gather_bwd_inv", s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_>), dim3(blocks), dim3(FGI_THREADS), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, sl))
+#define DCF_FGI(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_inv", (double)max_entries * (8.0 + 2.0 * Cb * sizeof(T)), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_>), dim3(blocks), dim3(FGI_THREADS), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, sl))
     DCF_DISPATCH_DTYPE(dtype, {
         if (Cb == 64) DCF_FGI(1);
         else if (Cb == 128) DCF_FGI(2);

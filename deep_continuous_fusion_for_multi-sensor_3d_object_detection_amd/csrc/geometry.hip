@@ -835,9 +835,9 @@ extern "C" int dcf_range_filter(const float *pts, int n, const float *lim, float
     memcpy(p.lim.v, lim, sizeof(p.lim.v));
     int nb = cdiv(n, CP_TILE);
     int *bs = (int *)ws;
-    DCF_LAUNCH("compact_count", s, hipLaunchKernelGGL(k_compact_count<RangePred>, dim3(nb), dim3(CP_THREADS), 0, s, pts, n, p, bs));
+    DCF_LAUNCH_B("compact_count", (double)n * 12.0, s, hipLaunchKernelGGL(k_compact_count<RangePred>, dim3(nb), dim3(CP_THREADS), 0, s, pts, n, p, bs));
     DCF_LAUNCH("compact_scan", s, hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(CP_THREADS), 0, s, bs, nb, count_dev));
-    DCF_LAUNCH("compact_scatter", s, hipLaunchKernelGGL((k_compact_scatter<RangePred, false>), dim3(nb), dim3(CP_THREADS), 0, s, pts, n, p, bs,
+    DCF_LAUNCH_B("compact_scatter", (double)n * (12.0 + 16.0), s, hipLaunchKernelGGL((k_compact_scatter<RangePred, false>), dim3(nb), dim3(CP_THREADS), 0, s, pts, n, p, bs,
                                                          (float *)nullptr, out_pts, out_src));
     return DCF_OK;
 }
@@ -855,9 +855,9 @@ extern "C" int dcf_project_filter(const float *pts, int n, const float *lim, con
     p.ulim = ulim; p.vlim = vlim; p.mode = mode;
     int nb = cdiv(n, CP_TILE);
     int *bs = (int *)ws;
-    DCF_LAUNCH("project_count", s, hipLaunchKernelGGL(k_compact_count<ProjPred>, dim3(nb), dim3(CP_THREADS), 0, s, pts, n, p, bs));
+    DCF_LAUNCH_B("project_count", (double)n * 12.0, s, hipLaunchKernelGGL(k_compact_count<ProjPred>, dim3(nb), dim3(CP_THREADS), 0, s, pts, n, p, bs));
     DCF_LAUNCH("compact_scan", s, hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(CP_THREADS), 0, s, bs, nb, count_dev));
-    DCF_LAUNCH("project_scatter", s, hipLaunchKernelGGL((k_compact_scatter<ProjPred, true>), dim3(nb), dim3(CP_THREADS), 0, s, pts, n, p, bs,
+    DCF_LAUNCH_B("project_scatter", (double)n * (12.0 + 20.0), s, hipLaunchKernelGGL((k_compact_scatter<ProjPred, true>), dim3(nb), dim3(CP_THREADS), 0, s, pts, n, p, bs,
                                                          uv_out, xyz_out, src_out));
     return DCF_OK;
 }
@@ -923,13 +923,13 @@ static int voxelize_batch_impl(const char *who, int dtype, bool nhwc, const floa
     memcpy(l.v, lim, sizeof(l.v));
     memcpy(a.v, aff, sizeof(a.v));
     const dim3 grid(cdiv(nmax, 256), B);
-    DCF_LAUNCH("voxel_cell_claim", s, hipLaunchKernelGGL(k_voxel_cell_claim, grid, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, 0));
+    DCF_LAUNCH_B("voxel_cell_claim", (double)nmax * B * 16.0, s, hipLaunchKernelGGL(k_voxel_cell_claim, grid, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, 0));
     if (!nhwc) {
-        DCF_LAUNCH("voxel_cell_gather", s, hipLaunchKernelGGL((k_voxel_cell_gather<float, false>), grid, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, (float *)grids, (const int *)owner_ws));
+        DCF_LAUNCH_B("voxel_cell_gather", (double)nmax * B * (12.0 + 27 * 4.0 + 8 * 4.0), s, hipLaunchKernelGGL((k_voxel_cell_gather<float, false>), grid, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, (float *)grids, (const int *)owner_ws));
     } else {
-        DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("voxel_cell_gather", s, hipLaunchKernelGGL((k_voxel_cell_gather<T, true>), grid, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, (T *)grids, (const int *)owner_ws)); })
+        DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("voxel_cell_gather", (double)nmax * B * (12.0 + 27 * 4.0 + 8.0 * sizeof(T)), s, hipLaunchKernelGGL((k_voxel_cell_gather<T, true>), grid, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, (T *)grids, (const int *)owner_ws)); })
     }
-    DCF_LAUNCH("voxel_cell_claim", s, hipLaunchKernelGGL(k_voxel_cell_claim, grid, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, 1));
+    DCF_LAUNCH_B("voxel_cell_claim", (double)nmax * B * 16.0, s, hipLaunchKernelGGL(k_voxel_cell_claim, grid, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, 1));
     return DCF_OK;
 }
 
@@ -983,7 +983,7 @@ extern "C" int dcf_knn_bev(const float *xyz, const int32_t *count_dev, int n_max
     DCF_HIP(hipMemsetAsync(cellcnt, 0, sizeof(int) * (size_t)nscan, s));
     if (n_max > 0) {
         const int nb = cdiv(n_max, 256);
-        DCF_LAUNCH("knn_hist", s, hipLaunchKernelGGL(k_knn_hist, dim3(nb), dim3(256), 0, s, xyz, count_dev, n_max, g, cellcnt, pkey));
+        DCF_LAUNCH_B("knn_hist", (double)n_max * 16.0, s, hipLaunchKernelGGL(k_knn_hist, dim3(nb), dim3(256), 0, s, xyz, count_dev, n_max, g, cellcnt, pkey));
     }
     int *total = blocksum + nsb;  // scratch int for the scan total
     DCF_LAUNCH("scan_blocksum", s, hipLaunchKernelGGL(k_scan_blocksum, dim3(nsb), dim3(CP_THREADS), 0, s, cellcnt, nscan, blocksum));
@@ -991,7 +991,7 @@ extern "C" int dcf_knn_bev(const float *xyz, const int32_t *count_dev, int n_max
     DCF_LAUNCH("scan_apply", s, hipLaunchKernelGGL(k_scan_apply, dim3(nsb), dim3(CP_THREADS), 0, s, cellcnt, nscan, blocksum, cellstart, cursor));
     if (n_max > 0) {
         const int nb = cdiv(n_max, 256);
-        DCF_LAUNCH("knn_fill", s, hipLaunchKernelGGL(k_knn_fill, dim3(nb), dim3(256), 0, s, xyz, count_dev, n_max, pkey, cursor, sorted));
+        DCF_LAUNCH_B("knn_fill", (double)n_max * (12.0 + 4.0 + 16.0), s, hipLaunchKernelGGL(k_knn_fill, dim3(nb), dim3(256), 0, s, xyz, count_dev, n_max, pkey, cursor, sorted));
     }
     const int nbp = cdiv(g.h8 * g.w8, 4);   // one wave per 8x8 pixel tile
     // coarse sites: one wave per pixel (lanes split the candidates).  DCF_KNN_KERNEL = wave | tile forces one of the two
@@ -1002,10 +1002,10 @@ extern "C" int dcf_knn_bev(const float *xyz, const int32_t *count_dev, int n_max
 #define KNN_CASE(KK)                                                                                                     \
     case KK:                                                                                                             \
         if (per_wave)                                                                                                    \
-            DCF_LAUNCH("knn_search_wave", s, hipLaunchKernelGGL(k_knn_search_wave<KK>, dim3(nbw), dim3(256), 0, s, count_dev, n_max, g, \
+            DCF_LAUNCH_B("knn_search_wave", (double)h * w * K * 4.0 + (double)n_max * 16.0, s, hipLaunchKernelGGL(k_knn_search_wave<KK>, dim3(nbw), dim3(256), 0, s, count_dev, n_max, g, \
                                                                 cellstart, sorted, rmax2, idx_out));                     \
         else                                                                                                             \
-            DCF_LAUNCH("knn_search", s, hipLaunchKernelGGL(k_knn_search<KK>, dim3(nbp), dim3(256), 0, s, count_dev, n_max, g, \
+            DCF_LAUNCH_B("knn_search", (double)h * w * K * 4.0 + (double)n_max * 16.0, s, hipLaunchKernelGGL(k_knn_search<KK>, dim3(nbp), dim3(256), 0, s, count_dev, n_max, g, \
                                                            cellstart, sorted, rmax2, idx_out));                          \
         break;
     switch (K) {
@@ -1045,10 +1045,10 @@ extern "C" int dcf_fusion_invert(const dcf_knn_map *maps, int nmaps, int K, int 
     const int total = (int)tot, nscan = nmaps * (n_max + 1), nsb = cdiv(nscan, CP_TILE);
     int *cnt = (int *)ws, *cursor = cnt + nscan, *blocksum = cursor + nscan, *totp = blocksum + nsb;
     DCF_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)nscan, s));
-    DCF_LAUNCH("inv_hist", s, hipLaunchKernelGGL(k_inv_hist, dim3(cdiv(total, 256)), dim3(256), 0, s, m, n_max, cnt));
+    DCF_LAUNCH_B("inv_hist", (double)total * 4.0, s, hipLaunchKernelGGL(k_inv_hist, dim3(cdiv(total, 256)), dim3(256), 0, s, m, n_max, cnt));
     DCF_LAUNCH("scan_blocksum", s, hipLaunchKernelGGL(k_scan_blocksum, dim3(nsb), dim3(CP_THREADS), 0, s, cnt, nscan, blocksum));
     DCF_LAUNCH("compact_scan", s, hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(CP_THREADS), 0, s, blocksum, nsb, totp));
     DCF_LAUNCH("scan_apply", s, hipLaunchKernelGGL(k_scan_apply, dim3(nsb), dim3(CP_THREADS), 0, s, cnt, nscan, blocksum, start, cursor));
-    DCF_LAUNCH("inv_fill", s, hipLaunchKernelGGL(k_inv_fill, dim3(cdiv(total, 256)), dim3(256), 0, s, m, n_max, cursor, ent_pix, ent_pt));
+    DCF_LAUNCH_B("inv_fill", (double)total * 12.0, s, hipLaunchKernelGGL(k_inv_fill, dim3(cdiv(total, 256)), dim3(256), 0, s, m, n_max, cursor, ent_pix, ent_pt));
     return DCF_OK;
 }

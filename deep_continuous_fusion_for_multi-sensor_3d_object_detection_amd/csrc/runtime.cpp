@@ -31,7 +31,7 @@ namespace {
 struct Rec {
     int name_id;
     hipEvent_t a, b;
-    double work;
+    double work, bytes;
 };
 std::mutex g_mu;
 std::vector<std::string> g_names;
@@ -40,7 +40,7 @@ std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t g_cur_a;
 int g_cur_name = -1;
-double g_cur_work = 0.0;
+double g_cur_work = 0.0, g_cur_bytes = 0.0;
 
 hipEvent_t get_event()
 {
@@ -55,7 +55,7 @@ hipEvent_t get_event()
 }
 }  // namespace
 
-void dcf_prof_begin(const char *name, hipStream_t s, double work)
+void dcf_prof_begin(const char *name, hipStream_t s, double work, double bytes)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_name_id.find(name);
@@ -69,6 +69,7 @@ void dcf_prof_begin(const char *name, hipStream_t s, double work)
     }
     g_cur_name = id;
     g_cur_work = work;
+    g_cur_bytes = bytes;
     g_cur_a = get_event();
     (void)hipEventRecord(g_cur_a, s);
 }
@@ -78,7 +79,7 @@ void dcf_prof_end(hipStream_t s)
     std::lock_guard<std::mutex> lk(g_mu);
     hipEvent_t b = get_event();
     (void)hipEventRecord(b, s);
-    g_recs.push_back(Rec{g_cur_name, g_cur_a, b, g_cur_work});
+    g_recs.push_back(Rec{g_cur_name, g_cur_a, b, g_cur_work, g_cur_bytes});
 }
 
 extern "C" int dcf_prof_enable(int on)
@@ -101,11 +102,16 @@ extern "C" int dcf_prof_reset(void)
 
 extern "C" int dcf_prof_read(char *names, double *total_ms, int64_t *calls, double *work, int cap)
 {
+    return dcf_prof_read2(names, total_ms, calls, work, nullptr, cap);
+}
+
+extern "C" int dcf_prof_read2(char *names, double *total_ms, int64_t *calls, double *work, double *bytes, int cap)
+{
     std::lock_guard<std::mutex> lk(g_mu);
     int n = (int)g_names.size();
     std::vector<double> tot(n, 0.0);
     std::vector<int64_t> cnt(n, 0);
-    std::vector<double> wk(n, 0.0);
+    std::vector<double> wk(n, 0.0), by(n, 0.0);
     for (auto &r : g_recs) {
         (void)hipEventSynchronize(r.b);
         float ms = 0.f;
@@ -113,6 +119,7 @@ extern "C" int dcf_prof_read(char *names, double *total_ms, int64_t *calls, doub
         tot[r.name_id] += ms;
         cnt[r.name_id] += 1;
         wk[r.name_id] += r.work;
+        by[r.name_id] += r.bytes;
     }
     int k = 0;
     for (int i = 0; i < n && k < cap; ++i) {
@@ -122,6 +129,7 @@ extern "C" int dcf_prof_read(char *names, double *total_ms, int64_t *calls, doub
         total_ms[k] = tot[i];
         calls[k] = cnt[i];
         if (work) work[k] = wk[i];
+        if (bytes) bytes[k] = by[i];
         ++k;
     }
     return k;
@@ -134,7 +142,7 @@ extern "C" int dcf_prof_calibrate(dcf_stream_t stream, int n)
     const int was = g_dcf_prof_on;
     g_dcf_prof_on = 1;
     for (int i = 0; i < n; ++i) {
-        dcf_prof_begin("__empty_bracket__", (hipStream_t)stream, 0.0);
+        dcf_prof_begin("__empty_bracket__", (hipStream_t)stream, 0.0, 0.0);
         dcf_prof_end((hipStream_t)stream);
     }
     g_dcf_prof_on = was;

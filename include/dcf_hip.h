@@ -49,6 +49,8 @@ int dcf_prof_calibrate(dcf_stream_t stream, int n);
  * ALGORITHMIC flops the launches declared (0 for kernels priced in bytes). Returns the number of
  * records. HOST pointers. */
 int dcf_prof_read(char *names /*[cap][64]*/, double *total_ms, int64_t *calls, double *work, int cap);
+/* Same, plus the algorithmic BYTES the launches declared (0 for launches that declare flops only). */
+int dcf_prof_read2(char *names, double *total_ms, int64_t *calls, double *work, double *bytes, int cap);
 
 /* ------------------------------------------------------------------ geometry
  * Replaces CarlaDataset.Voxelization_Projection / Projection
