@@ -402,7 +402,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if ws > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        # (a host tensor under gloo: DCF_DIST_BACKEND=gloo lets several ranks share one GPU for functional runs)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(trainer.loss_value.item())

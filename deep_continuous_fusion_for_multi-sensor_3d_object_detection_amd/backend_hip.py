@@ -160,10 +160,55 @@ class HipBackend(object):
         self.grads.zero_()
         self._wq = []                      # weight gradients collected by a backward that did not finish are dropped
 
+    # Gradient buckets (data parallel): the layer table is ordered LiDAR stream | camera stream | fusion layers, and so is
+    # the parameter arena.  With a hook installed (train.Train, world size > 1) the backward finalises the LiDAR + fusion
+    # layers as soon as their weight gradients are complete and hands the arena ranges to the hook, which starts their
+    # all-reduce while the camera stream's backward still runs; the camera bucket follows at the end.  Without a hook:
+    # one flush, one finalisation launch (the single-GPU path is unchanged).
+    bucket_hook = None
+
+    def _layer_split(self, layers):
+        img = [L.idx for L in layers if L.name.startswith("image_")]
+        fus = [L.idx for L in layers if L.name.startswith("fusion.")]
+        if not img or not fus or max(img) + 1 != min(fus) or max(fus) + 1 != len(layers):
+            return None
+        return min(img), min(fus)
+
+    def _finalize(self, lo, hi):
+        tab = self.table.data_ptr() + lo * ctypes.sizeof(H.ConvParam)
+        H.call("dcf_wgrad_finalize_rows", tab, hi - lo, ctypes.addressof(self._couts) + 4 * lo, self.params, self.buffers, self.ssarena,
+               self.slabs, self.gsum, self.grads, BN_EPS, H.stream_ptr())
+
+    def _param_ranges(self, layers, lo, hi):
+        """Arena range [a, b) holding every parameter of layers lo..hi-1 (weights, BN affine, fusion biases in between)."""
+        a = layers[lo].w_off
+        b = layers[hi].w_off if hi < len(layers) else self.params.numel()
+        return a, b
+
+    def bucket_ready(self, layers, which):
+        if self.bucket_hook is None:
+            return
+        sp = self._layer_split(layers)
+        if sp is None:
+            return
+        i0, f0 = sp
+        self._flush_wgrads()
+        self._finalize(0, i0)                       # LiDAR stream
+        self._finalize(f0, len(layers))             # fusion layers
+        self._done = (i0, f0)
+        self.bucket_hook([self._param_ranges(layers, 0, i0), self._param_ranges(layers, f0, len(layers))])
+
     def end_backward(self, layers):
         self._flush_wgrads()
-        H.call("dcf_wgrad_finalize_rows", self.table, self.nconv, ctypes.addressof(self._couts), self.params, self.buffers, self.ssarena,
-               self.slabs, self.gsum, self.grads, BN_EPS, H.stream_ptr())
+        done = self.__dict__.pop("_done", None)
+        if done is None:
+            self._finalize(0, self.nconv)
+            if self.bucket_hook is not None:
+                self.bucket_hook([(0, self.params.numel())])
+            return
+        i0, f0 = done
+        self._finalize(i0, f0)                      # camera stream
+        self.bucket_hook([self._param_ranges(layers, i0, f0)])
 
     # ------------------------------------------------------------------ convolutions
     def _amax(self, L):

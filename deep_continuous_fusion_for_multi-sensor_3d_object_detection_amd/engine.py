@@ -468,6 +468,10 @@ class Plan(object):
                 g = blocks[bi].backward(K, g, extra, need_gx=not first, g_masked=masked, prev=prev)
                 masked = prev is not None
         if c["fused"]:
+            # every gradient of the LiDAR stream and of the fusion layers is complete here; only the camera stream is left:
+            # the backend may finalise and hand over that bucket now (data-parallel runs all-reduce it under the camera
+            # stream's backward)
+            K.bucket_ready(self.layers, "lidar+fusion")
             self._image_backward(K, gF)
         K.end_backward(self.layers)
         self.ctx = {}

@@ -83,6 +83,9 @@ class Train(nn.Module):
         self.optimizer = FlatAdam(self.model, config["learning_rate"], (config["beta1"], 0.999))
         self.sync_replicas()
         self._side = None
+        # data parallel: all-reduce the LiDAR + fusion gradient bucket under the camera stream's backward
+        self.overlap_allreduce = bool(config.get("overlap_allreduce", True))
+        self._pending, self._reduced = [], 0
 
     def sync_replicas(self):
         """Identical replicas: rank 0's parameters, buffers and optimiser moments win (called at construction; call it
@@ -163,12 +166,46 @@ class Train(nn.Module):
         pred = self.model(lidar_voxel, camera_image, **extra)
         return torch.split(pred, [4, 14, 14], dim=1)
 
+    def _bucket_ready(self, ranges):
+        """Backend hook (world size > 1): arena ranges whose gradients are final.  Their all-reduce starts now -- RCCL runs it
+        on its own stream behind the finalisation launch, under whatever the backward still has to do -- and is waited for
+        before the optimiser step."""
+        g = self.model.flat_grads
+        for a, b in ranges:
+            if b <= a:
+                continue
+            seg = g[a:b]
+            if _through_host(seg):
+                h = seg.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                seg.copy_(h)
+            else:
+                self._pending.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
+            self._reduced += b - a
+
     def one_step(self, lidar_voxel, camera_image, object_data, num_ref_box, **extra):
         pred_cls, pred_reg, _ = self._predict(lidar_voxel, camera_image, extra)
         self.loss_value = self.loss_total(object_data, num_ref_box, pred_cls, pred_reg)
         self.optimizer.zero_grad()
-        self.loss_value.backward()
-        n = allreduce_grads(self.model.flat_grads)
+        n = world()
+        overlap = n > 1 and self.overlap_allreduce and not self.model.use_graphs and self.model._backend is not None
+        self._pending, self._reduced = [], 0
+        if overlap:
+            self.model._backend.bucket_hook = self._bucket_ready
+        try:
+            self.loss_value.backward()
+        finally:
+            if overlap:
+                self.model._backend.bucket_hook = None
+        if overlap and self._reduced == self.model.flat_grads.numel():
+            for w in self._pending:
+                w.wait()
+        else:                                      # single rank, captured graphs, or a backward that skipped the buckets
+            for w in self._pending:
+                w.wait()
+            if self._reduced:
+                raise RuntimeError("gradient buckets covered %d of %d elements" % (self._reduced, self.model.flat_grads.numel()))
+            allreduce_grads(self.model.flat_grads)
         self.optimizer.step(1.0 / n)
 
     def one_step_raw(self, frame_geometry, batch):

@@ -38,6 +38,17 @@ def pytest_sessionstart(session):
         log = open(os.path.join(outdir, name + ".log"), "w")
         procs.append((name, subprocess.Popen([sys.executable, child, str(world), str(rank), port, outdir], stdout=log, stderr=subprocess.STDOUT,
                                              cwd=ROOT)))
+    # ... and bench.py itself with two ranks on this one GPU (gloo instead of RCCL): the N > 1 code path of the benchmark
+    s2 = socket.socket()
+    s2.bind(("127.0.0.1", 0))
+    port2 = str(s2.getsockname()[1])
+    s2.close()
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port2, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", DCF_DIST_BACKEND="gloo")
+        out = open(os.path.join(outdir, "bench_r%d.out" % rank), "w")
+        log = open(os.path.join(outdir, "bench_r%d.log" % rank), "w")
+        procs.append(("bench_r%d" % rank, subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                                                            "--no-cpu-baseline"], stdout=out, stderr=log, cwd=ROOT, env=env)))
     config._dcf_dp_children = (outdir, procs)
 
 

@@ -12,12 +12,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_two_ranks_equal_one_rank_with_twice_the_batch(request):
+def _wait(request, prefix):
     kids = getattr(request.config, "_dcf_dp_children", None)
     if not kids:
         pytest.skip("data-parallel children were not started (no GPU at session start)")
     outdir, procs = kids
     for name, p in procs:
+        if not name.startswith(prefix):
+            continue
         try:
             rc = p.wait(timeout=900)
         except Exception:
@@ -25,6 +27,24 @@ def test_two_ranks_equal_one_rank_with_twice_the_batch(request):
             raise AssertionError("child %s did not finish" % name)
         log = open(os.path.join(outdir, name + ".log")).read()
         assert rc == 0, "child %s failed:\n%s" % (name, log[-3000:])
+    return outdir
+
+
+def test_bench_two_ranks_on_one_gpu(request):
+    """bench.py --gpus 2 (the driver's N > 1 launch contract: RANK / WORLD_SIZE from the environment, barrier-fenced timing,
+    MAX over ranks, one JSON line from rank 0) with both ranks on GPU 0 and gloo in place of RCCL: cfg2 steps including the
+    bucketed gradient all-reduce.  A functional check of the code path the 8-GPU scaling run takes."""
+    import json
+    outdir = _wait(request, "bench_r")
+    line = open(os.path.join(outdir, "bench_r0.out")).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["parallelism"] == "dp2" and d["roofline"] is not None
+    assert open(os.path.join(outdir, "bench_r1.out")).read().strip() == ""          # only rank 0 prints
+
+
+def test_two_ranks_equal_one_rank_with_twice_the_batch(request):
+    outdir = _wait(request, "w")
     one = torch.load(os.path.join(outdir, "w1_r0.pt"))
     r0 = torch.load(os.path.join(outdir, "w2_r0.pt"))
     r1 = torch.load(os.path.join(outdir, "w2_r1.pt"))
