@@ -84,7 +84,7 @@ class Train(nn.Module):
         self.sync_replicas()
         self._side = None
         # data parallel: all-reduce the LiDAR + fusion gradient bucket under the camera stream's backward
-        self.overlap_allreduce = bool(config.get("overlap_allreduce", True))
+        self.overlap_allreduce = bool(config.get("overlap_allreduce", os.environ.get("DCF_OVERLAP_ALLREDUCE", "1") != "0"))
         self._pending, self._reduced = [], 0
 
     def sync_replicas(self):

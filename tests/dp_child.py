@@ -51,7 +51,7 @@ def main():
     trainer.sync_replicas()                             # ... until rank 0's arenas are broadcast (Train does this at construction too)
     mine = list(range(2)) if world == 1 else [rank]
     H, W = cfg["voxel_length"] // 4, cfg["voxel_width"] // 4
-    outs = []
+    outs, grads = [], []
     for step in range(2):
         np.random.seed(100 + step)
         # the loss draws its negative samples from numpy's global generator, frame after frame: a rank that owns frame r
@@ -65,7 +65,9 @@ def main():
         trainer.one_step(x_lidar, img, boxes, nb, geom=geom)
         torch.cuda.synchronize()
         outs.append(trainer.model.flat_params.detach().cpu().clone())
-    torch.save({"params": outs, "loss": float(trainer.loss_value.item())}, os.path.join(outdir, "w%d_r%d.pt" % (world, rank)))
+        grads.append((trainer.model.flat_grads.detach() / world).cpu().clone())     # what Adam consumed (gscale = 1 / world)
+    torch.save({"params": outs, "grads": grads, "loss": float(trainer.loss_value.item()), "lr": cfg["learning_rate"]},
+               os.path.join(outdir, "w%d_r%d.pt" % (world, rank)))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
