@@ -57,6 +57,10 @@ SIGNATURES = {
     "dcf_stem7x7_wgrad": (c_int, [c_int, P, P, P, P, c_int] + [c_int] * 6 + [P]),
     "dcf_weight_prep": (c_int, [c_int, P, c_int, P, P, P, P, c_float, P]),
     "dcf_wgrad_finalize": (c_int, [P, c_int, c_int, P, P, P, P, P, P, c_float, P]),
+    "dcf_eval_score_filter": (c_int, [P, c_int, c_int, c_int, c_float, c_int, P, P, P]),
+    "dcf_eval_nms_workspace_bytes": (c_size_t, [c_int]),
+    "dcf_eval_nms": (c_int, [P, P, c_int, c_int, ctypes.c_double, P, P, P, P]),
+    "dcf_eval_match": (c_int, [P, c_int, P, c_int, P, c_int, P, P]),
     "dcf_wgrad_finalize_rows": (c_int, [P, c_int, P, P, P, P, P, P, P, c_float, P]),
     "dcf_bn_workspace_bytes": (c_size_t, [c_int]),
     "dcf_bn_train_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, c_i64, c_int, c_float, c_float, c_int, P, P]),

@@ -394,3 +394,45 @@ def rowscale_bias_fwd(dtype, y, cnt, b2):
 def rowscale_bias_bwd(dtype, gy, cnt, gb2):
     C = gy.shape[-1]
     H.call("dcf_rowscale_bias_bwd", dtype, gy, cnt, gb2, gy.numel() // C, C, H.stream_ptr())
+
+
+# ------------------------------------------------------------------ evaluation post-processing
+EVAL_NMS_CAP = 4096
+
+
+def eval_score_filter(pred, threshold, cap=EVAL_NMS_CAP):
+    """test.py:88-108 on the device: pred [B,32,h,w] fp32 -> (boxes [B,cap,7], count int32 [B]); per sample anchor 0's boxes
+    with score > threshold in raster order, then anchor 1's."""
+    B, C, h, w = pred.shape
+    if C != 32 or pred.dtype != torch.float32:
+        raise H.DcfError("eval_score_filter: pred must be the model output [B,32,h,w] fp32")
+    pred = _chk(pred.contiguous(), "pred")
+    boxes = torch.zeros((B, cap, 7), dtype=torch.float32, device=pred.device)
+    count = torch.zeros((B,), dtype=torch.int32, device=pred.device)
+    H.call("dcf_eval_score_filter", pred, B, h, w, float(threshold), cap, boxes, count, H.stream_ptr())
+    return boxes, count
+
+
+def eval_nms(boxes, mode, iou_threshold=0.01, count=None):
+    """Greedy suppression in input order (test.py:110-175): boxes [n,7] fp32 on the device -> keep flags int32 [n].
+    mode "sat" | "iou"; count: optional int32 [1] device tensor with the number of valid rows."""
+    n = boxes.shape[0]
+    if n > EVAL_NMS_CAP:
+        raise H.DcfError("eval_nms: at most %d boxes per call (got %d)" % (EVAL_NMS_CAP, n))
+    boxes = _chk(boxes.float().contiguous(), "boxes")
+    keep = torch.zeros((max(n, 1),), dtype=torch.int32, device=boxes.device)
+    nkeep = torch.zeros((1,), dtype=torch.int32, device=boxes.device)
+    ws = torch.empty((H.lib().dcf_eval_nms_workspace_bytes(max(n, 1)),), dtype=torch.uint8, device=boxes.device)
+    H.call("dcf_eval_nms", boxes, count, n, {"sat": 0, "iou": 1}[mode], float(iou_threshold), keep, nkeep, ws, H.stream_ptr())
+    return keep[:n], nkeep
+
+
+def eval_match(pred_boxes, ref_boxes, thresholds, tp):
+    """tp[t] += number of pred_boxes [n,7] whose bird's-eye IoU with a labelled row of ref_boxes [R,9] exceeds thresholds[t]
+    (fp64 device tensor); tp int32 [len(thresholds)] on the device (test.py:177-206)."""
+    n = pred_boxes.shape[0]
+    if n == 0:
+        return tp
+    H.call("dcf_eval_match", _chk(pred_boxes.float().contiguous(), "pred_boxes"), n, _chk(ref_boxes.float().contiguous(), "ref_boxes"),
+           ref_boxes.shape[0], thresholds, thresholds.shape[0], tp, H.stream_ptr())
+    return tp

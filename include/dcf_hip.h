@@ -319,6 +319,25 @@ int dcf_loss_fwd_bwd(const float *cls, int64_t cls_bstride, const float *reg, in
                      const int64_t *ints, const float *floats, int B, int HW, float reg_gain, int reduction,
                      float *loss, float *gcls, int64_t gcls_bstride, float *greg, int64_t greg_bstride, dcf_stream_t stream);
 
+/* ------------------------------------------------- evaluation post-processing
+ * What /root/reference/test.py:88-206 does on the host, box by box.
+ * dcf_eval_score_filter: test.py:88-108.  pred [B][32][h][w] fp32 (the model output: scores in channels 2a+1, decoded boxes in
+ *   18+7a..18+7a+6 for anchor a); boxes_out [B][cap][7] receives, per sample, anchor 0's boxes with score > threshold in raster
+ *   order, then anchor 1's; count_out[b] = how many passed (may exceed cap: rows past cap are dropped).
+ * dcf_eval_nms: test.py:110-175.  Greedy suppression in INPUT order: keep[i] = 1 iff box i overlaps no earlier kept box.
+ *   mode 0 = separating-axis test of the bird's-eye rectangles (NMS_SAT; touching counts), mode 1 = 3-D IoU > iou_threshold with the
+ *   kept box's centre nudged by 1e-4 (NMS_IOU).  boxes [n_max][7] fp32 (x, y, z, l, w, h, yaw); count_dev (may be NULL) = number of
+ *   valid rows on the device; n_max <= 4096.  ws: dcf_eval_nms_workspace_bytes(n_max).
+ * dcf_eval_match: test.py:177-206.  tp_counters[t] += number of predictions whose bird's-eye IoU with any labelled box
+ *   (ref row [9], last column == 1) exceeds thresholds_dev[t] (fp64, on the device). */
+int dcf_eval_score_filter(const float *pred, int B, int h, int w, float threshold, int cap, float *boxes_out, int32_t *count_out,
+                          dcf_stream_t stream);
+size_t dcf_eval_nms_workspace_bytes(int n_max);
+int dcf_eval_nms(const float *boxes, const int32_t *count_dev, int n_max, int mode, double iou_threshold, int32_t *keep, int32_t *nkeep,
+                 void *ws, dcf_stream_t stream);
+int dcf_eval_match(const float *pred_boxes, int npred, const float *ref_boxes, int nref_rows, const double *thresholds_dev, int nthr,
+                   int32_t *tp_counters, dcf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
