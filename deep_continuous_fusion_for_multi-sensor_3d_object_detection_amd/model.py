@@ -93,19 +93,24 @@ class _GraphSet(object):
     """Static buffers and the captured graphs of one input signature (tensor shapes + rows of the per-point fusion
     tensors): g_img = weight preparation + camera stream, g_lid = LiDAR stream with the fusion sites and the heads,
     g_bwd = the whole backward.  The three share one memory pool (activations saved by the forward graphs are read by
-    the backward graph)."""
+    the backward graph).  When the geometry arrives in the trainer's persistent buffer sets (geom["static"]), the graphs
+    are captured ON those buffers: a replay then needs no staging copy of the voxel image, the points or the KNN maps."""
 
     def __init__(self, model, x_lidar, x_image, geom, n_rows):
         m, K = model, model._backend
-        self.sx = x_lidar.clone()
+        self.static = bool(geom is not None and geom.get("static")) or (geom is None)
+        self.sx = x_lidar if (geom is not None and geom.get("static")) else x_lidar.clone()
         self.simg = None if x_image is None else x_image.clone()
         self.sgeom = None
-        if geom is not None:
-            self.sgeom = dict(xyz=geom["xyz"].clone(), uv=geom["uv"].clone(), cnt=geom["cnt"].clone(),
-                              idx=[t.clone() for t in geom["idx"]], aff=geom["aff"], n_rows=n_rows)
+        if geom is not None and geom.get("xyz") is not None:
+            keep = (lambda t: t) if geom.get("static") else (lambda t: t.clone())
+            self.sgeom = dict(xyz=keep(geom["xyz"]), uv=keep(geom["uv"]), cnt=keep(geom["cnt"]),
+                              idx=[keep(t) for t in geom["idx"]], aff=geom["aff"], n_rows=n_rows)
             if geom.get("inv") is not None:
-                self.sgeom["inv"] = tuple(t.clone() for t in geom["inv"])
+                self.sgeom["inv"] = tuple(keep(t) for t in geom["inv"])
                 self.sgeom["inv_nmax"] = geom["inv_nmax"]
+        self.copy_geom = self.sgeom is not None and not geom.get("static")
+        self.copy_x = not (geom is not None and geom.get("static"))
         split = m._plan.with_image and self.sgeom is not None
         # eager warm-up step on the static buffers: lazy allocations (slabs, anchors, workspaces) happen here
         K.prepare()
@@ -133,53 +138,67 @@ class _StepGraphs(object):
     """Captured-graph execution of the train step (config['hip_graphs']).  The geometry stays outside the graphs, on the
     caller's side stream (train.Train.geometry_async): the camera-stream graph is replayed first and overlaps it, the
     LiDAR-stream graph follows once the voxel grid and the KNN maps are there.  One set of graphs per input signature;
-    the signature includes the row count of the per-point fusion tensors (the valid-point count rounded up to 1024),
-    so the graphs keep the valid-count sizing of the eager path."""
-    MAX_SETS = 6
+    the signature includes the row count of the per-point fusion tensors -- the valid-point count rounded up to ROWS_STEP, a
+    coarse step so that real frames (whose in-frustum counts vary by a few per cent) share one or two sets -- and the
+    address of the geometry buffers.  Sets are evicted least-recently-used; a run whose signatures keep missing (more than
+    MAX_MISSES captures) falls back to eager launches for good instead of capturing for ever."""
+    MAX_SETS = 8
+    ROWS_STEP = 8192
+    MAX_MISSES = 24
 
     def __init__(self, model):
+        import collections
         self.model = model
-        self.sets = {}
+        self.sets = collections.OrderedDict()
         self.cur = None
+        self.misses = 0
+        self.disabled = False
 
-    @staticmethod
-    def _rows(geom):
-        if geom is None:
+    @classmethod
+    def _rows(cls, geom):
+        if geom is None or geom.get("xyz") is None:
             return 0
         n = geom["xyz"].shape[1]
         ch = geom.get("cnt_host")
         if ch is not None:
             geom["cnt_event"].synchronize()
-            n = min(n, max(1024, (int(ch.max()) + 1023) // 1024 * 1024))
+            n = min(n, max(cls.ROWS_STEP, (int(ch.max()) + cls.ROWS_STEP - 1) // cls.ROWS_STEP * cls.ROWS_STEP))
         return n
 
     def run_forward(self, x_lidar, x_image, geom):
         cur = torch.cuda.current_stream()
         n_rows = self._rows(geom)
-        sig = (tuple(x_lidar.shape), None if x_image is None else tuple(x_image.shape),
-               None if geom is None else (tuple(geom["xyz"].shape), tuple(geom["idx"][0].shape), geom.get("inv") is not None), n_rows)
+        has_geo = geom is not None and geom.get("xyz") is not None
+        sig = (tuple(x_lidar.shape), x_lidar.dtype, None if x_image is None else tuple(x_image.shape),
+               None if not has_geo else (tuple(geom["xyz"].shape), tuple(geom["idx"][0].shape), geom.get("inv") is not None), n_rows,
+               x_lidar.data_ptr() if (geom is not None and geom.get("static")) else 0)
         st = self.sets.get(sig)
         if st is None:
             if geom is not None:
                 for k in ("voxel_event", "event", "inv_event"):
                     if geom.get(k) is not None:
                         cur.wait_event(geom[k])
-            if len(self.sets) >= self.MAX_SETS:
-                self.sets.pop(next(iter(self.sets)))
-            st = self.sets[sig] = _GraphSet(self.model, x_lidar, x_image, geom, n_rows)
+            while len(self.sets) >= self.MAX_SETS:
+                self.sets.popitem(last=False)
+            self.misses += 1
+            st = self.sets[sig] = _GraphSet(self.model, x_lidar, x_image, geom if has_geo or geom is None else None, n_rows)
+        else:
+            self.sets.move_to_end(sig)
         self.cur = (st, geom)
         if st.simg is not None:
             st.simg.copy_(x_image)
         st.g_img.replay()                              # weight images + camera stream: overlaps the geometry side stream
         if geom is not None and geom.get("voxel_event") is not None:
             cur.wait_event(geom["voxel_event"])
-        st.sx.copy_(x_lidar)
+        if st.copy_x:
+            st.sx.copy_(x_lidar)
         if st.sgeom is not None:
             if geom.get("event") is not None:
                 cur.wait_event(geom["event"])
-            st.sgeom["xyz"].copy_(geom["xyz"]); st.sgeom["uv"].copy_(geom["uv"]); st.sgeom["cnt"].copy_(geom["cnt"])
-            for d, s_ in zip(st.sgeom["idx"], geom["idx"]):
-                d.copy_(s_)
+            if st.copy_geom:
+                st.sgeom["xyz"].copy_(geom["xyz"]); st.sgeom["uv"].copy_(geom["uv"]); st.sgeom["cnt"].copy_(geom["cnt"])
+                for d, s_ in zip(st.sgeom["idx"], geom["idx"]):
+                    d.copy_(s_)
         st.g_lid.replay()
         return st.spred
 
@@ -188,8 +207,9 @@ class _StepGraphs(object):
         if st.sgeom is not None and st.sgeom.get("inv") is not None:
             if geom.get("inv_event") is not None:
                 torch.cuda.current_stream().wait_event(geom["inv_event"])
-            for d, s_ in zip(st.sgeom["inv"], geom["inv"]):
-                d.copy_(s_)
+            if st.copy_geom:
+                for d, s_ in zip(st.sgeom["inv"], geom["inv"]):
+                    d.copy_(s_)
         st.sgpred.copy_(gpred)
         st.g_bwd.replay()
 
@@ -366,8 +386,9 @@ class ObjectDetection_DCF(_FlatParamModule):
                                        fp8_min_blocks=int(self.config.get("fp8_min_blocks", 512)))
         return self._backend
 
-    def fusion_geometry(self, points, uv, n_valid):
-        """KNN indices of every fusion site for a batch: points [B,n_max,3], uv [B,n_max,2], n_valid [B] (int)."""
+    def fusion_geometry(self, points, uv, n_valid, bufs=None):
+        """KNN indices of every fusion site for a batch: points [B,n_max,3], uv [B,n_max,2], n_valid [B] (int).
+        bufs: optional persistent buffers dict(idx=[4 x int32 [B,K,h,w]], ws=[4 x workspace]) to write into."""
         from . import ops
         B = points.shape[0]
         dev = points.device
@@ -377,11 +398,32 @@ class ObjectDetection_DCF(_FlatParamModule):
         idx = []
         for si in range(1, 5):
             s = 2 ** si
-            idx.append(torch.stack([ops.knn_bev(points[b].contiguous(), cnt[b:b + 1], self.K, L // s, W // s, s, self._grid.aff,
-                                                self.r_max) for b in range(B)], 0))
+            if bufs is not None:            # frames land side by side in the batch tensor: no per-frame allocation, no stack copy
+                site = bufs["idx"][si - 1]
+            else:
+                site = torch.empty((B, self.K, L // s, W // s), dtype=torch.int32, device=dev)
+            ws = None if bufs is None else bufs["ws"][si - 1]
+            for b in range(B):
+                ops.knn_bev(points[b], cnt[b:b + 1], self.K, L // s, W // s, s, self._grid.aff, self.r_max, ws=ws, out=site[b])
+            idx.append(site)
         return dict(xyz=points.contiguous(), uv=uv.contiguous(), cnt=cnt, idx=idx, aff=self._grid.aff)
 
-    def fusion_inverse(self, geom):
+    def fusion_buffers(self, B, n_max, device):
+        """Persistent buffers for fusion_geometry / fusion_inverse of batches of B frames with n_max point rows."""
+        from . import ops
+        L, W = self.config["voxel_length"], self.config["voxel_width"]
+        idx, ws = [], []
+        for si in range(1, 5):
+            s = 2 ** si
+            idx.append(torch.empty((B, self.K, L // s, W // s), dtype=torch.int32, device=device))
+            ws.append(torch.empty((H.lib().dcf_knn_workspace_bytes(n_max, L // s, W // s),), dtype=torch.uint8, device=device))
+        maps = [t[b] for t in idx for b in range(B)]
+        ns, ne, nw = ops.fusion_invert_sizes(maps, n_max)
+        inv = (torch.empty((ns,), dtype=torch.int32, device=device), torch.empty((2, ne), dtype=torch.int32, device=device),
+               torch.empty((nw,), dtype=torch.uint8, device=device))
+        return dict(idx=idx, ws=ws, inv=inv)
+
+    def fusion_inverse(self, geom, bufs=None):
         """The fusion backward gathers by POINT: invert every site's KNN map (pairs sorted by point id).  Only the
         backward needs it, so a caller with a side stream records its own event after this (train.geometry_async)."""
         from . import ops
@@ -390,7 +432,7 @@ class ObjectDetection_DCF(_FlatParamModule):
             return geom
         n_max = geom["xyz"].shape[1]
         maps = [t[b] for t in geom["idx"] for b in range(t.shape[0])]          # map index = site * B + frame
-        geom["inv"] = ops.fusion_invert(maps, n_max)
+        geom["inv"] = ops.fusion_invert(maps, n_max, out=None if bufs is None else bufs["inv"])
         geom["inv_nmax"] = n_max
         return geom
 
@@ -416,7 +458,13 @@ class ObjectDetection_DCF(_FlatParamModule):
         if self.use_graphs and need and not bn_train and not self._profiling():
             if self._graphs is None:
                 self._graphs = _StepGraphs(self)
-            return _RunGraphs.apply(self._param_list[0], self, x_lidar, x_image, geom)
+            if self._graphs.misses > self._graphs.MAX_MISSES and not self._graphs.disabled:
+                import warnings
+                warnings.warn("hip_graphs: more than %d input signatures captured -- falling back to eager launches" % self._graphs.MAX_MISSES)
+                self._graphs.disabled = True
+                self._graphs.sets.clear()
+            if not self._graphs.disabled:
+                return _RunGraphs.apply(self._param_list[0], self, x_lidar, x_image, geom)
         K.prepare()
         return _RunPlan.apply(self._param_list[0], self, x_lidar, x_image, geom, need)
 

@@ -314,10 +314,11 @@ def project_filter(pts, lim, crt, ulim, vlim, mode=H.PROJ_COMPAT, n_out=None, wa
     return uv, xyz, cnt, src
 
 
-def knn_bev(xyz, cnt, K, h, w, stride, aff, rmax=None, ws=None):
+def knn_bev(xyz, cnt, K, h, w, stride, aff, rmax=None, ws=None, out=None):
+    """out: optional int32 [K,h,w] tensor to write into (e.g. a frame's slice of a batch tensor)."""
     n_max = xyz.shape[0]
     dev = xyz.device
-    idx = torch.empty((K, h, w), dtype=torch.int32, device=dev)
+    idx = torch.empty((K, h, w), dtype=torch.int32, device=dev) if out is None else _chk(out, "out")
     if ws is None:
         ws = torch.empty((H.lib().dcf_knn_workspace_bytes(n_max, h, w),), dtype=torch.uint8, device=dev)
     r2 = -1.0 if rmax is None else float(np.float32(rmax) * np.float32(rmax))
@@ -357,9 +358,15 @@ def fusion_gather_bwd(dtype, P, xyz, idx, stride, aff, w1d, b1, ghsum, gP, gw1d,
            w1d, b1, Cb, ghsum, gP, gw1d, gb1, H.stream_ptr())
 
 
-def fusion_invert(maps, n_max):
+def fusion_invert_sizes(maps, n_max):
+    """(elements of start, pairs, workspace bytes) of fusion_invert for these maps."""
+    return len(maps) * (n_max + 1), sum(t.numel() for t in maps), H.lib().dcf_fusion_invert_workspace_bytes(n_max, len(maps))
+
+
+def fusion_invert(maps, n_max, out=None):
     """maps: list of KNN maps [K,h,w] (sites x frames of a step).  Returns (start [len(maps)*(n_max+1)], ent [2, pairs]):
-    the (pixel, point) pairs of all maps sorted by (map, point) -- see dcf_fusion_invert."""
+    the (pixel, point) pairs of all maps sorted by (map, point) -- see dcf_fusion_invert.
+    out: optional (start, ent, ws) buffers of fusion_invert_sizes() to write into."""
     K = maps[0].shape[0]
     dev = maps[0].device
     tab = (H.KnnMap * len(maps))()
@@ -368,9 +375,12 @@ def fusion_invert(maps, n_max):
         assert t.dtype == torch.int32 and t.is_contiguous() and t.shape[0] == K
         tab[i] = H.KnnMap(t.data_ptr(), t.shape[1], t.shape[2])
         total += t.numel()
-    start = torch.empty((len(maps) * (n_max + 1),), dtype=torch.int32, device=dev)
-    ent = torch.empty((2, total), dtype=torch.int32, device=dev)
-    ws = torch.empty((H.lib().dcf_fusion_invert_workspace_bytes(n_max, len(maps)),), dtype=torch.uint8, device=dev)
+    if out is not None:
+        start, ent, ws = out
+    else:
+        start = torch.empty((len(maps) * (n_max + 1),), dtype=torch.int32, device=dev)
+        ent = torch.empty((2, total), dtype=torch.int32, device=dev)
+        ws = torch.empty((H.lib().dcf_fusion_invert_workspace_bytes(n_max, len(maps)),), dtype=torch.uint8, device=dev)
     H.call("dcf_fusion_invert", ctypes.addressof(tab), len(maps), K, n_max, start, ent[0], ent[1], ws, H.stream_ptr())
     return start, ent
 

@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from . import ops
 from .loss import LossTotal
+from ._hip import torch_dtype as H_torch_dtype
 from .model import ObjectDetection_DCF
 
 
@@ -83,6 +84,8 @@ class Train(nn.Module):
         self.optimizer = FlatAdam(self.model, config["learning_rate"], (config["beta1"], 0.999))
         self.sync_replicas()
         self._side = None
+        self.static_geometry = bool(config.get("static_geometry", True))
+        self._geo_sets, self._geo_slot = {}, 0
         # data parallel: all-reduce the LiDAR + fusion gradient bucket under the camera stream's backward
         self.overlap_allreduce = bool(config.get("overlap_allreduce", os.environ.get("DCF_OVERLAP_ALLREDUCE", "1") != "0"))
         self._pending, self._reduced = [], 0
@@ -93,43 +96,88 @@ class Train(nn.Module):
         for t in (self.model.flat_params, self.model._bufflat, self.optimizer.m, self.optimizer.v):
             broadcast_from_rank0(t)
 
+    def _geo_set(self, B, mp, fast, dims):
+        """Persistent device buffers of the per-step geometry, two sets used in turn: a step's geometry is produced on the side
+        stream while the previous step's backward may still read its own set.  One zero-fill per step (the projection
+        outputs are dense-packed and zero-padded, data_import_carla.py:263-266) instead of a dozen allocations + fills, and
+        fixed addresses, so that captured graphs can read the geometry without staging copies."""
+        self._geo_slot ^= 1
+        key = (B, mp, fast, self._geo_slot)
+        st = self._geo_sets.get(key)
+        if st is None:
+            Cz, L, W = dims
+            dev = self.model.flat_params.device
+            st = {"slot": self._geo_slot, "free_event": None}
+            if fast:
+                from ._hip import torch_dtype
+                st["x_lidar"] = torch.empty((B, L, W, Cz), dtype=torch_dtype(self.model.dtype), device=dev)
+            else:
+                st["x_lidar"] = torch.empty((B, Cz, L, W), dtype=torch.float32, device=dev)
+            st["proj"] = torch.zeros((B * mp * 5 + 16,), dtype=torch.float32, device=dev)        # [xyz | uv | counts]
+            st["xyz"] = st["proj"][:B * mp * 3].view(B, mp, 3)
+            st["uv"] = st["proj"][B * mp * 3:B * mp * 5].view(B, mp, 2)
+            st["cnt"] = st["proj"][B * mp * 5:B * mp * 5 + B].view(torch.int32)
+            st["cnt_host"] = torch.empty(B, dtype=torch.int32).pin_memory()
+            if self.model.fusion_enabled:
+                st["fusion"] = self.model.fusion_buffers(B, mp, dev)
+            self._geo_sets[key] = st
+        return st
+
     def geometry_async(self, frame_geometry, points_list, crts=None, wait_event=None):
         """Per-frame geometry (voxelise, project, KNN of the fusion sites) on a side HIP stream, so that these
         small latency-bound kernels overlap the camera stream's convolutions on the compute stream.
         Returns (x_lidar [B,Cz,L,W], geom) where geom carries the events the engine waits on.
         crts: optional per-frame [4,3] projection matrices (KITTI calibrates every frame).
-        wait_event: event the side stream has to wait for before it reads the points (FrameLoader's H2D copies)."""
+        wait_event: event the side stream has to wait for before it reads the points (FrameLoader's H2D copies).
+        The returned tensors live in one of two persistent buffer sets (config static_geometry, default on): they stay
+        valid until the second-next call."""
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream()
         if wait_event is not None:
             self._side.wait_event(wait_event)
+        Cz, L, W = frame_geometry.grid.dims
+        Bn, mp = len(points_list), int(frame_geometry.config["max_num_pc"])
+        # 16-bit compute types: the voxeliser writes the engine's input image ([B,L,W,Cz] in that type) directly -- no fp32
+        # grid, no transpose (the model recognises it by its dtype); f32 keeps the reference's [B,Cz,L,W] grid
+        fast = self.model.dtype != 0 and frame_geometry.voxel_mode == 0 and Bn <= 8
+        direct = self.static_geometry and all(p.shape[0] <= mp for p in points_list)
+        st = None
+        if direct:
+            # (allocated under the side stream: memory handed out by the caching allocator is only safe to write on the stream
+            # it was requested on -- a block the compute stream has just released may still be in use by its queued kernels)
+            with torch.cuda.stream(self._side):
+                st = self._geo_set(Bn, mp, fast, (Cz, L, W))
+        if st is not None:
+            if st["free_event"] is not None:
+                self._side.wait_event(st["free_event"])        # the step that last read this set has finished with it
+                st["free_event"] = None
+            elif st.get("used"):
+                self._side.wait_stream(main)                   # handed out before, never consumed by one_step: be conservative
+            st["used"] = True
         with torch.cuda.stream(self._side):
             pcs, uvs, cnts = [], [], []
-            Cz, L, W = frame_geometry.grid.dims
-            # 16-bit compute types: the voxeliser writes the engine's input image ([B,L,W,Cz] in that type) directly -- no fp32
-            # grid, no transpose (the model recognises it by its dtype); f32 keeps the reference's [B,Cz,L,W] grid
-            fast = self.model.dtype != 0 and frame_geometry.voxel_mode == 0 and len(points_list) <= 8
-            if fast:
-                from ._hip import torch_dtype
-                x_lidar = torch.empty((len(points_list), L, W, Cz), dtype=torch_dtype(self.model.dtype), device="cuda")
+            if st is not None:
+                x_lidar = st["x_lidar"]
+                st["proj"].zero_()
+                xyz_all, uv_all, cnt_all = st["xyz"], st["uv"], st["cnt"]
             else:
-                x_lidar = torch.empty((len(points_list), Cz, L, W), dtype=torch.float32, device="cuda")
+                x_lidar = torch.empty((Bn, L, W, Cz), dtype=H_torch_dtype(self.model.dtype), device="cuda") if fast else \
+                    torch.empty((Bn, Cz, L, W), dtype=torch.float32, device="cuda")
+                xyz_all = torch.zeros((Bn, mp, 3), dtype=torch.float32, device="cuda")
+                uv_all = torch.zeros((Bn, mp, 2), dtype=torch.float32, device="cuda")
+                cnt_all = torch.zeros((Bn,), dtype=torch.int32, device="cuda")
             # projection first: its valid-point counts go to the host (pinned, asynchronous) while the voxeliser and the KNN
             # still run; the engine sizes the per-point fusion tensors by them instead of max_num_pc (Plan._fusion_rows)
             # the frames' projections land side by side in batch tensors (no per-frame allocations, no stack copies)
-            Bn, mp = len(points_list), int(frame_geometry.config["max_num_pc"])
-            xyz_all = torch.zeros((Bn, mp, 3), dtype=torch.float32, device="cuda")
-            uv_all = torch.zeros((Bn, mp, 2), dtype=torch.float32, device="cuda")
-            cnt_all = torch.zeros((Bn,), dtype=torch.int32, device="cuda")
-            direct = True
+            inplace = True
             for b, pts in enumerate(points_list):
                 pc, uv, cnt = frame_geometry.project(pts, crt=None if crts is None else crts[b],
                                                      out=(xyz_all[b], uv_all[b], cnt_all[b:b + 1]))
-                direct = direct and pc.data_ptr() == xyz_all[b].data_ptr()
+                inplace = inplace and pc.data_ptr() == xyz_all[b].data_ptr()
                 pcs.append(pc); uvs.append(uv); cnts.append(cnt)
-            cnt_dev = cnt_all if direct else torch.cat(cnts, 0)
-            cnt_host = torch.empty(len(points_list), dtype=torch.int32).pin_memory()
+            cnt_dev = cnt_all if inplace else torch.cat(cnts, 0)
+            cnt_host = st["cnt_host"] if st is not None else torch.empty(Bn, dtype=torch.int32).pin_memory()
             cnt_host.copy_(cnt_dev, non_blocking=True)
             ev_cnt = torch.cuda.Event()
             ev_cnt.record()
@@ -138,28 +186,33 @@ class Train(nn.Module):
             ev_vox.record()
             geom = None
             if self.model.fusion_enabled:
-                if direct:
-                    geom = self.model.fusion_geometry(xyz_all, uv_all, cnt_all)
+                fb = st.get("fusion") if st is not None else None
+                if inplace:
+                    geom = self.model.fusion_geometry(xyz_all, uv_all, cnt_all, bufs=fb)
                 else:                                   # a frame with more than max_num_pc points: the copying path
                     geom = self.model.fusion_geometry(torch.stack(pcs, 0), torch.stack(uvs, 0), cnt_dev)
                 ev = torch.cuda.Event()
                 ev.record()
                 geom["event"] = ev
                 geom["cnt_host"], geom["cnt_event"] = cnt_host, ev_cnt
-                self.model.fusion_inverse(geom)        # needed by the backward only: its own event
+                self.model.fusion_inverse(geom, bufs=fb if inplace else None)        # needed by the backward only: its own event
                 ev_inv = torch.cuda.Event()
                 ev_inv.record()
                 geom["inv_event"] = ev_inv
             else:
                 geom = {}
             geom["voxel_event"] = ev_vox
-        # tensors born on the side stream are consumed on the compute stream
-        x_lidar.record_stream(main)
-        born = [geom.get("xyz"), geom.get("uv"), geom.get("cnt")] + list(geom.get("idx") or [])
-        born += list(geom.get("inv") or [])
-        for t in born:
-            if t is not None:
-                t.record_stream(main)
+        if st is not None:
+            geom["_set"] = st                # one_step records the set's free event when the step has consumed it
+            geom["static"] = inplace
+        else:
+            # tensors born on the side stream are consumed on the compute stream
+            x_lidar.record_stream(main)
+            born = [geom.get("xyz"), geom.get("uv"), geom.get("cnt")] + list(geom.get("idx") or [])
+            born += list(geom.get("inv") or [])
+            for t in born:
+                if t is not None:
+                    t.record_stream(main)
         return x_lidar, geom
 
     def _predict(self, lidar_voxel, camera_image, extra):
@@ -207,6 +260,10 @@ class Train(nn.Module):
                 raise RuntimeError("gradient buckets covered %d of %d elements" % (self._reduced, self.model.flat_grads.numel()))
             allreduce_grads(self.model.flat_grads)
         self.optimizer.step(1.0 / n)
+        st = (extra.get("geom") or {}).get("_set")
+        if st is not None:                         # the geometry buffers of this step may be refilled from here on
+            st["free_event"] = torch.cuda.Event()
+            st["free_event"].record()
 
     def one_step_raw(self, frame_geometry, batch):
         """One train step from a FrameLoader batch (raw points + image in HBM): geometry on the side stream, then one_step."""

@@ -353,9 +353,9 @@ def test_graph_replay_with_side_stream_geometry_matches_eager():
         res[graphs] = out
         if graphs:
             assert trainer.model._graphs is not None and 1 <= len(trainer.model._graphs.sets) <= 3
-    for (p0, g0), (p1, g1) in zip(res[False], res[True]):
-        assert torch.allclose(p0, p1, rtol=1e-5, atol=1e-6)
-        assert float((g0 - g1).abs().max()) < 2e-5 * float(g0.abs().max())
+    for step, ((p0, g0), (p1, g1)) in enumerate(zip(res[False], res[True])):
+        assert torch.allclose(p0, p1, rtol=1e-5, atol=1e-6), "step %d: predictions differ by %g" % (step, float((p0 - p1).abs().max()))
+        assert float((g0 - g1).abs().max()) < 2e-5 * float(g0.abs().max()), "step %d" % step
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
