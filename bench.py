@@ -67,10 +67,19 @@ class FramePool(object):
             self.nb.append(nb)
         self.boxes_dev = [b.cuda() for b in self.boxes]
         self.n = n_frames
+        self._img_batches = {}
 
     def batch(self, step, B):
         ids = [(step * B + i) % self.n for i in range(B)]
         return ids
+
+    def image_batch(self, ids):
+        """[B,3,H,W] uint8 batch tensor, resident in HBM like the clouds (a loader collates frames into one tensor: FrameLoader
+        does it in pinned host memory; here the few distinct batches of the pool are stacked once)."""
+        key = tuple(ids)
+        if key not in self._img_batches:
+            self._img_batches[key] = torch.stack([self.img[i] for i in ids], 0)
+        return self._img_batches[key]
 
 
 class HostFrames(torch.utils.data.Dataset):
@@ -95,7 +104,7 @@ def train_step(trainer, pool, ids):
     """Whole hot path for one batch.  Geometry + KNN run on the trainer's side stream (overlapping the camera
     stream on the compute stream); everything else is enqueued on torch's current stream."""
     x_lidar, geom = trainer.geometry_async(pool.geometry, [pool.pts[i] for i in ids])
-    x_image = torch.stack([pool.img[i] for i in ids], 0)
+    x_image = pool.image_batch(ids)
     boxes = torch.stack([pool.boxes[i] for i in ids], 0)          # CPU, as a DataLoader would hand them over
     nb = torch.tensor([pool.nb[i] for i in ids])
     trainer.one_step(x_lidar, x_image, boxes, nb, geom=geom)

@@ -157,7 +157,16 @@ class HipBackend(object):
                     L.nsplit, L.slab_off, L.gsum_off = ns, so, go
             self._gsbase, self._slbase = self.gsum.data_ptr(), self.slabs.data_ptr()
             self._sig = sig
-        self.grads.zero_()
+        # Only the fusion layers' small parameters (fc1_geo, fc1 / fc2 biases) are ACCUMULATED into the gradient arena (float
+        # atomics of the gather backward); every other gradient is written whole by the finalisation launch (eval-mode BN) or by
+        # the BatchNorm backward.  They sit at the end of the arena, between the fusion layers' weights: one small fill.
+        fus = [L.w_off for L in layers if L.name.startswith("fusion.")]
+        if not fus:
+            pass
+        elif min(fus) > max(L.w_off for L in layers if not L.name.startswith("fusion.")):
+            self.grads[min(fus):].zero_()
+        else:
+            self.grads.zero_()
         self._wq = []                      # weight gradients collected by a backward that did not finish are dropped
 
     # Gradient buckets (data parallel): the layer table is ordered LiDAR stream | camera stream | fusion layers, and so is
@@ -379,7 +388,10 @@ class HipBackend(object):
     # ------------------------------------------------------------------ fusion
     def point_sample_fwd(self, fmap, uv, cnt, n_max):
         B = fmap.shape[0]
-        return torch.stack([ops.point_sample_fwd(self.dtype, fmap[b], uv[b], cnt[b:b + 1], n_max) for b in range(B)], 0)
+        fp = torch.zeros((B, max(n_max, 1), fmap.shape[-1]), dtype=fmap.dtype, device=fmap.device)      # frames side by side: one fill, no stack copy
+        for b in range(B):
+            ops.point_sample_fwd(self.dtype, fmap[b], uv[b], cnt[b:b + 1], n_max, out=fp[b])
+        return fp
 
     def point_sample_bwd(self, gfp, uv, cnt, n_max, fmap_shape, gF):
         if gF is None:
@@ -389,12 +401,12 @@ class HipBackend(object):
         return gF
 
     def fusion_gather_fwd(self, P, xyz, idx, stride, aff, w1d_off, b1_off):
-        hs, cs = [], []
-        for b in range(P.shape[0]):
-            h, c = ops.fusion_gather_fwd(self.dtype, P[b], xyz[b], idx[b], stride, aff, self.params[w1d_off:], self.params[b1_off:])
-            hs.append(h)
-            cs.append(c)
-        return torch.stack(hs, 0), torch.stack(cs, 0)
+        B, (K_, h, w) = P.shape[0], idx.shape[-3:]
+        hsum = torch.empty((B, h, w, P.shape[2]), dtype=P.dtype, device=P.device)
+        cnt = torch.empty((B, h * w), dtype=torch.float32, device=P.device)
+        for b in range(B):
+            ops.fusion_gather_fwd(self.dtype, P[b], xyz[b], idx[b], stride, aff, self.params[w1d_off:], self.params[b1_off:], out=(hsum[b], cnt[b]))
+        return hsum, cnt
 
     def fusion_gather_bwd(self, P, xyz, idx, stride, aff, w1d_off, b1_off, ghsum, inv=None, site=0, inv_nmax=None):
         """inv: inverse KNN maps of the step (ops.fusion_invert, map = site*B + frame) -> the point-sorted backward;

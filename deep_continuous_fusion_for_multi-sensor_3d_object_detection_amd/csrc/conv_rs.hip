@@ -353,8 +353,9 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
 // too short to hide the L2 latency behind two taps.  npt is picked so that the tile count fills the CUs in whole rounds
 // and the waves' shares are even.  (DCF_RS_KIND / DCF_RS_NPT force a choice: experiments.)
 struct RsPlan { int kind, npt; };
-struct RsKind { int BN, WM, TMMAX, ahead; };
-static const RsKind RS_KINDS[3] = {{128, 2, 5, 2}, {64, 4, 3, 2}, {64, 4, 1, 5}};
+struct RsKind { int BN, WM, TMMAX, ahead, nthreads, per_cu; };
+// kinds 3 / 4: 4-wave workgroups, two per CU (<= 80 KB of LDS each), so that one workgroup's prologue and epilogue overlap the other's taps
+static const RsKind RS_KINDS[5] = {{128, 2, 5, 2, 512, 1}, {64, 4, 3, 2, 512, 1}, {64, 4, 1, 5, 512, 1}, {64, 2, 2, 2, 256, 2}, {128, 2, 2, 1, 256, 2}};
 
 static RsPlan rs_plan(int64_t Q, int Cn)
 {
@@ -362,14 +363,15 @@ static RsPlan rs_plan(int64_t Q, int Cn)
     const int ncu = 256;
     RsPlan best = {-1, 0};
     double best_t = 1e30;
-    for (int kind = 0; kind < 3; ++kind) {
+    for (int kind = 0; kind < 5; ++kind) {
         const RsKind &k = RS_KINDS[kind];
+        if (kind >= 3 && !(ek && atoi(ek) == kind)) continue;      // experimental: only when forced
         if (Cn % k.BN) continue;
         if (ek && atoi(ek) != kind) continue;
         for (int npt = 1; npt <= k.WM * k.TMMAX; ++npt) {
             if (en && atoi(en) != npt) continue;
             const int64_t tiles = (Q + 32 * npt - 1) / (32 * npt) * (Cn / k.BN);
-            const int64_t rounds = (tiles + ncu - 1) / ncu;
+            const int64_t rounds = (tiles + ncu * k.per_cu - 1) / (ncu * k.per_cu);
             const int per_wave = (npt + k.WM - 1) / k.WM;
             // cycles per tap step on a CU: MFMAs of the busiest SIMD (2 waves), the L2 -> LDS transfer at ~28 B/clk, a fixed
             // cost of the wait + barrier + issue sequence, and the L2 latency spread over the taps the DMA runs ahead
@@ -411,7 +413,9 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
     do {                                                                                                                         \
         if (p.kind == 0) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1>), grid, dim3(512), 0, s, a)); \
         else if (p.kind == 1) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 3, 2, 4, 2, 1>), grid, dim3(512), 0, s, a)); \
-        else DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 5, 2>), grid, dim3(512), 0, s, a));          \
+        else if (p.kind == 2) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 5, 2>), grid, dim3(512), 0, s, a)); \
+        else if (p.kind == 3) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 2, 2, 2, 2, 1>), grid, dim3(256), 0, s, a)); \
+        else DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 2, 2, 2, 2, 1, 1>), grid, dim3(256), 0, s, a));          \
     } while (0)
     if (dtype == DCF_F16) DCF_RS(f16_t); else DCF_RS(bf16_t);
 #undef DCF_RS

@@ -379,31 +379,46 @@ class Plan(object):
         self._img_saved = self.ctx.get("img")
         return fmap
 
-    def forward(self, K, x_lidar, x_image=None, geom=None, save=True, fmap=None):
+    def forward(self, K, x_lidar, x_image=None, geom=None, save=True, fmap=None, phase=None, resume=None):
         """x_lidar [B,Cz,L,W] fp32 NCHW (model.py:194); returns pred [B,32,L/4,W/4] fp32 NCHW.
 
         geom (fusion only): dict(xyz [B,n_max,3], uv [B,n_max,2], cnt [B] int32 device, idx = list over
         sites of [B,K,h,w] int32, aff) -- produced once per frame by the geometry kernels.
         fmap: the camera feature map when forward_image() already ran for this step.
+        phase: None = the whole stream; 1 = only what does not need the KNN maps (input conversion, layer1, layer2's blocks:
+        returns that activation); 2 = the rest, from `resume` = what phase 1 returned.  The captured-graph path replays
+        phase 1 while the KNN still runs on the geometry side stream.
         """
-        self.ctx = {"save": save}
-        if fmap is not None:
-            if save:
-                self.ctx["img"] = self._img_saved
-        elif self.with_image and geom is not None:
-            fmap = self._image_forward(K, x_image, save)
-        if geom is not None and geom.get("voxel_event") is not None:
-            K.wait_event(geom["voxel_event"])          # voxel grid produced on the geometry side stream
-        # a 16-bit x_lidar is already the input image [B,L,W,Cz] (train.geometry_async: written by the voxeliser)
-        x = x_lidar if x_lidar.dtype != torch.float32 else K.nchw_to_nhwc(x_lidar)
+        if phase != 2:
+            self.ctx = {"save": save}
+            if fmap is not None:
+                if save:
+                    self.ctx["img"] = self._img_saved
+            elif self.with_image and geom is not None:
+                fmap = self._image_forward(K, x_image, save)
+                self.ctx["fmap_eager"] = fmap
+            if geom is not None and geom.get("voxel_event") is not None:
+                K.wait_event(geom["voxel_event"])          # voxel grid produced on the geometry side stream
+            # a 16-bit x_lidar is already the input image [B,L,W,Cz] (train.geometry_async: written by the voxeliser)
+            x = x_lidar if x_lidar.dtype != torch.float32 else K.nchw_to_nhwc(x_lidar)
+            for si in (0, 1):
+                for b in self.stages[si]:
+                    x = b.forward(K, x, save)
+            if phase == 1:
+                return x
+        else:
+            x = resume
+            if fmap is None:
+                fmap = self.ctx.pop("fmap_eager", None)
+        self.ctx.pop("fmap_eager", None)
         outs = []
-        for si, blocks in enumerate(self.stages):
-            for b in blocks:
-                x = b.forward(K, x, save)
-            if si >= 1:
-                if fmap is not None:
-                    x = self._fusion_forward(K, self.fusion[si - 1], x, fmap, geom, si - 1, save)
-                outs.append(x)
+        for si in range(1, 5):
+            if si > 1:
+                for b in self.stages[si]:
+                    x = b.forward(K, x, save)
+            if fmap is not None:
+                x = self._fusion_forward(K, self.fusion[si - 1], x, fmap, geom, si - 1, save)
+            outs.append(x)
         x1, x2, x3, x4 = outs
         l1 = K.conv_fwd(self.latconv1, x3, None, False)
         d1 = K.conv_fwd(self.downconv1, x4, None, False)

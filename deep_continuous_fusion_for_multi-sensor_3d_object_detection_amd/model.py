@@ -125,9 +125,14 @@ class _GraphSet(object):
         with torch.cuda.graph(self.g_img):
             K.prepare()
             self.sfmap = m._plan.forward_image(K, self.simg, save=True) if split else None
+        # the LiDAR stream in two graphs: what only needs the voxel image (layer1, layer2's blocks) ...
+        self.g_lid_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_lid_a, pool=self.g_img.pool()):
+            self.sxa = m._plan.forward(K, self.sx, self.simg, self.sgeom, save=True, fmap=self.sfmap, phase=1)
+        # ... and everything from the first fusion site on, which needs the KNN maps of the geometry side stream
         self.g_lid = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_lid, pool=self.g_img.pool()):
-            self.spred = m._plan.forward(K, self.sx, self.simg, self.sgeom, save=True, fmap=self.sfmap)
+            self.spred = m._plan.forward(K, self.sx, self.simg, self.sgeom, save=True, fmap=self.sfmap, phase=2, resume=self.sxa)
         self.sgpred = torch.zeros_like(self.spred)
         self.g_bwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_bwd, pool=self.g_img.pool()):
@@ -192,6 +197,7 @@ class _StepGraphs(object):
             cur.wait_event(geom["voxel_event"])
         if st.copy_x:
             st.sx.copy_(x_lidar)
+        st.g_lid_a.replay()                            # layer1 + layer2's blocks: the KNN may still be running
         if st.sgeom is not None:
             if geom.get("event") is not None:
                 cur.wait_event(geom["event"])

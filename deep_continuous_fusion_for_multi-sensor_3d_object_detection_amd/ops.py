@@ -328,9 +328,10 @@ def knn_bev(xyz, cnt, K, h, w, stride, aff, rmax=None, ws=None, out=None):
 
 
 # ------------------------------------------------------------------ fusion
-def point_sample_fwd(dtype, fmap, uv, cnt, n_max):
+def point_sample_fwd(dtype, fmap, uv, cnt, n_max, out=None):
+    """out: optional ZEROED [n_max, Cf] tensor to write into (a frame's slice of a batch tensor)."""
     Hf, Wf, Cf = fmap.shape
-    fp = torch.zeros((max(n_max, 1), Cf), dtype=fmap.dtype, device=fmap.device)
+    fp = torch.zeros((max(n_max, 1), Cf), dtype=fmap.dtype, device=fmap.device) if out is None else _chk(out, "out")
     H.call("dcf_point_sample_fwd", dtype, fmap, Hf, Wf, Cf, uv, cnt, n_max, fp, H.stream_ptr())
     return fp
 
@@ -341,11 +342,15 @@ def point_sample_bwd(dtype, gfp, uv, cnt, n_max, gfmap):
     return gfmap
 
 
-def fusion_gather_fwd(dtype, P, xyz, idx, stride, aff, w1d, b1):
+def fusion_gather_fwd(dtype, P, xyz, idx, stride, aff, w1d, b1, out=None):
+    """out: optional (hsum [h,w,Cb], cnt [h*w]) to write into (a frame's slices of batch tensors)."""
     K, h, w = idx.shape
     Cb = P.shape[1]
-    hsum = torch.empty((h, w, Cb), dtype=P.dtype, device=P.device)
-    cnt = torch.empty((h * w,), dtype=torch.float32, device=P.device)
+    if out is not None:
+        hsum, cnt = _chk(out[0], "hsum"), _chk(out[1], "cnt")
+    else:
+        hsum = torch.empty((h, w, Cb), dtype=P.dtype, device=P.device)
+        cnt = torch.empty((h * w,), dtype=torch.float32, device=P.device)
     H.call("dcf_fusion_gather_fwd", dtype, P, xyz, idx, K, h, w, stride, float(aff[0]), float(aff[1]), float(aff[2]), float(aff[3]),
            w1d, b1, Cb, hsum, cnt, H.stream_ptr())
     return hsum, cnt
