@@ -310,6 +310,9 @@ class HipBackend(object):
 
     _wq = []
     _group = os.environ.get("DCF_WGRAD_GROUP", "1") != "0"
+    # one-writer-per-point fusion backward (dcf_fusion_gather_bwd_pts: no zero-fill, no atomics on dP, no cast): correct, but a
+    # point that thousands of pixels chose is then one wave's serial work -- measured 1.07 vs 0.30 ms per step at cfg2, so off
+    _fusion_pts = os.environ.get("DCF_FUSION_PTS", "0") == "1"
 
     def conv_wgrad(self, L, x, gy, defer=True):
         """defer=False: gy (or x) is modified in place later in the backward (e.g. masked by a ReLU) -- launch now."""
@@ -411,8 +414,15 @@ class HipBackend(object):
     def fusion_gather_bwd(self, P, xyz, idx, stride, aff, w1d_off, b1_off, ghsum, inv=None, site=0, inv_nmax=None):
         """inv: inverse KNN maps of the step (ops.fusion_invert, map = site*B + frame) -> the point-sorted backward;
         else the pixel-run one."""
-        gP = torch.zeros(P.shape, dtype=torch.float32, device=self.dev)
         use_inv = inv is not None and P.shape[2] % 64 == 0 and 64 <= P.shape[2] <= 256
+        if use_inv and self._fusion_pts:
+            # one writer per point row: the gradient comes out whole, in the compute dtype (no zero-fill, no atomics on it, no cast)
+            gP = torch.empty(P.shape, dtype=P.dtype, device=self.dev)
+            for b in range(P.shape[0]):
+                ops.fusion_gather_bwd_pts(self.dtype, P[b], xyz[b], inv, inv_nmax or P.shape[1], site * P.shape[0] + b, tuple(idx.shape[-3:]), stride, aff,
+                                          self.params[w1d_off:], self.params[b1_off:], ghsum[b], gP[b], self.grads[w1d_off:], self.grads[b1_off:])
+            return gP
+        gP = torch.zeros(P.shape, dtype=torch.float32, device=self.dev)
         for b in range(P.shape[0]):
             if use_inv:
                 ops.fusion_gather_bwd_inv(self.dtype, P[b], xyz[b], inv, inv_nmax or P.shape[1], site * P.shape[0] + b, tuple(idx.shape[-3:]), stride, aff, self.params[w1d_off:],

@@ -297,21 +297,40 @@ __global__ void __launch_bounds__(256) k_fusion_gather_bwd_pipe(const T *__restr
 // 16 waves per workgroup: the number of workgroups is capped (each ends with C x 4 same-address atomics on dW1d / db1), so
 // the waves that hide the gather latency have to come from inside the workgroup
 constexpr int FGI_THREADS = 1024;
-template <typename T, int CJ>
+// EXCL: instead of slices of pairs, a wave owns a range of POINTS (all pairs of its points: start[p0] .. start[p1]), so every
+// row of gP has exactly one writer: it is stored whole in the compute type (zeros for points without pairs) -- no zero-fill
+// of an fp32 accumulator before, no float atomics, no cast kernel after.  e_begin then points at start[0] of the map, SL is
+// the number of point rows.
+template <typename T, int CJ, bool EXCL>
 __global__ void __launch_bounds__(FGI_THREADS) k_fusion_gather_bwd_inv(const T *__restrict__ P, const float *__restrict__ xyz, const int *__restrict__ e_begin, const int *__restrict__ e_end,
                                                                const int *__restrict__ ent_pix, const int *__restrict__ ent_pt, FuseGeom g,
                                                                const float *__restrict__ w1d, const float *__restrict__ b1, int C,
-                                                               const T *__restrict__ ghsum, float *gP, float *gw1d, float *gb1, int SL)
+                                                               const T *__restrict__ ghsum, void *gPv, float *gw1d, float *gb1, int SL)
 {
+    float *gP = reinterpret_cast<float *>(gPv);
+    T *gPt = reinterpret_cast<T *>(gPv);
     constexpr int U = 8;
     extern __shared__ float sm[];  // [C][4]: gw1d x3, gb1
     for (int i = threadIdx.x; i < C * 4; i += blockDim.x) sm[i] = 0.f;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (FGI_THREADS / 64) + (threadIdx.x >> 6));
-    const int E0 = *e_begin, E = *e_end;
     const int nwaves = gridDim.x * (FGI_THREADS / 64);   // the grid is capped: a wave takes slices wave, wave + nwaves, ...
-    if (E0 + wave * SL < E) {                             // (fewer workgroups = fewer same-address atomics on dW1d / db1)
+    const int PP = EXCL ? (SL + nwaves - 1) / nwaves : 0;       // points per wave
+    const int xp0 = wave * PP, xp1 = min(xp0 + PP, SL);
+    const int E0 = EXCL ? (xp0 < xp1 ? e_begin[xp0] : 0) : *e_begin, E = EXCL ? (xp0 < xp1 ? e_begin[xp1] : 0) : *e_end;
+    const int SLICE = EXCL ? max(E - E0, 1) : SL;             // EXCL: one "slice" = all pairs of the wave's points
+    int next_row = xp0;
+    auto store_row = [&](int pt, const float (&acc)[CJ]) {
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) DT<T>::st(gPt + (int64_t)pt * C + lane + 64 * j, acc[j]);
+    };
+    auto zero_rows = [&](int a, int b) {
+        for (int rr = a; rr < b; ++rr)
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) DT<T>::st(gPt + (int64_t)rr * C + lane + 64 * j, 0.f);
+    };
+    if (EXCL ? (xp0 < xp1) : (E0 + wave * SL < E)) {      // (fewer workgroups = fewer same-address atomics on dW1d / db1)
         float w0[CJ], w1[CJ], w2[CJ], bb[CJ], a0[CJ], a1[CJ], a2[CJ], ab[CJ], cur_acc[CJ];
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
@@ -319,8 +338,8 @@ __global__ void __launch_bounds__(FGI_THREADS) k_fusion_gather_bwd_inv(const T *
             w0[j] = w1d[c * 3]; w1[j] = w1d[c * 3 + 1]; w2[j] = w1d[c * 3 + 2]; bb[j] = b1[c];
             a0[j] = a1[j] = a2[j] = ab[j] = cur_acc[j] = 0.f;
         }
-      for (int sidx = wave; E0 + sidx * SL < E; sidx += nwaves) {
-        const int lo = E0 + sidx * SL, hi = min(E, lo + SL);
+      for (int sidx = EXCL ? 0 : wave; EXCL ? (sidx == 0) : (E0 + sidx * SL < E); sidx += nwaves) {
+        const int lo = E0 + sidx * SLICE, hi = EXCL ? E : min(E, lo + SLICE);
         int cur_pt = -1;
         auto bcast_i = [](int v, int i) { return __builtin_amdgcn_readlane(v, i); };
         auto bcast_f = [](float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); };
@@ -356,10 +375,16 @@ __global__ void __launch_bounds__(FGI_THREADS) k_fusion_gather_bwd_inv(const T *
                     if (i0 + u >= n) break;
                     if (pt[u] != cur_pt) {                   // wave-uniform
                         if (cur_pt >= 0) {
+                            if (EXCL) {
+                                store_row(cur_pt, cur_acc);
+                                next_row = cur_pt + 1;
+                            } else {
 #pragma unroll
-                            for (int j = 0; j < CJ; ++j)
-                                if (cur_acc[j] != 0.f) atomicAdd(gP + (int64_t)cur_pt * C + lane + 64 * j, cur_acc[j]);
+                                for (int j = 0; j < CJ; ++j)
+                                    if (cur_acc[j] != 0.f) atomicAdd(gP + (int64_t)cur_pt * C + lane + 64 * j, cur_acc[j]);
+                            }
                         }
+                        if (EXCL) zero_rows(next_row, pt[u]);       // points of this wave that no pixel chose
                         cur_pt = pt[u];
 #pragma unroll
                         for (int j = 0; j < CJ; ++j) cur_acc[j] = 0.f;
@@ -375,13 +400,19 @@ __global__ void __launch_bounds__(FGI_THREADS) k_fusion_gather_bwd_inv(const T *
             }
         }
         if (cur_pt >= 0) {
+            if (EXCL) {
+                store_row(cur_pt, cur_acc);
+                next_row = cur_pt + 1;
+            } else {
 #pragma unroll
-            for (int j = 0; j < CJ; ++j)
-                if (cur_acc[j] != 0.f) atomicAdd(gP + (int64_t)cur_pt * C + lane + 64 * j, cur_acc[j]);
+                for (int j = 0; j < CJ; ++j)
+                    if (cur_acc[j] != 0.f) atomicAdd(gP + (int64_t)cur_pt * C + lane + 64 * j, cur_acc[j]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < CJ; ++j) cur_acc[j] = 0.f;
       }
+      if (EXCL) zero_rows(next_row, xp1);
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
             const int c = lane + 64 * j;
@@ -489,7 +520,7 @@ extern "C" int dcf_fusion_gather_bwd_inv(int dtype, const void *P, const float *
     static const char *cap_env = getenv("DCF_FUSION_BWD_BLOCKS");
     const int cap = cap_env ? atoi(cap_env) : 256;     // swept: 128 / 256 / 512 / uncapped = 0.52 / 0.34 / 0.36 / 0.44 ms per step
     const int blocks = std::min(cdiv(waves, FGI_THREADS / 64), cap);
-#define DCF_FGI(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_inv", (double)max_entries * (8.0 + 2.0 * Cb * sizeof(T)), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_>), dim3(blocks), dim3(FGI_THREADS), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, sl))
+#define DCF_FGI(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_inv", (double)max_entries * (8.0 + 2.0 * Cb * sizeof(T)), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_, false>), dim3(blocks), dim3(FGI_THREADS), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, sl))
     DCF_DISPATCH_DTYPE(dtype, {
         if (Cb == 64) DCF_FGI(1);
         else if (Cb == 128) DCF_FGI(2);
@@ -497,5 +528,33 @@ extern "C" int dcf_fusion_gather_bwd_inv(int dtype, const void *P, const float *
         else DCF_FGI(4);
     })
 #undef DCF_FGI
+    return DCF_OK;
+}
+
+// Same sums with one writer per point row (see k_fusion_gather_bwd_inv<.., EXCL>): gP [n_rows][Cb] in the COMPUTE type, every row
+// written (zeros where no pixel chose the point), no zero-fill needed before and no cast after.  start = the map's
+// start[g*(n_max+1) ...] (n_rows + 1 entries are read: n_rows <= n_max).
+extern "C" int dcf_fusion_gather_bwd_pts(int dtype, const void *P, const float *xyz, const int32_t *start, int n_rows, const int32_t *ent_pix,
+                                         const int32_t *ent_pt, int max_entries, int h, int w, int stride, float xs, float xo, float ys, float yo,
+                                         const float *w1d, const float *b1, int Cb, const void *ghsum, void *gP, float *gw1d, float *gb1,
+                                         dcf_stream_t stream)
+{
+    DCF_REQUIRE(P && xyz && start && ent_pix && ent_pt && w1d && b1 && ghsum && gP && gw1d && gb1, "dcf_fusion_gather_bwd_pts: null pointer");
+    DCF_REQUIRE(Cb % 64 == 0 && Cb >= 64 && Cb <= 256, "dcf_fusion_gather_bwd_pts: Cb must be 64, 128, 192 or 256 (got %d)", Cb);
+    if (n_rows <= 0) return DCF_OK;
+    FuseGeom g;
+    g.h = h; g.w = w; g.stride = stride; g.K = 0; g.xs = xs; g.xo = xo; g.ys = ys; g.yo = yo;
+    hipStream_t s = S(stream);
+    static const char *cap_env = getenv("DCF_FUSION_BWD_BLOCKS");
+    const int cap = cap_env ? atoi(cap_env) : 256;
+    const int blocks = std::min(cdiv(n_rows, FGI_THREADS / 64), cap);
+#define DCF_FGP(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_pts", (double)max_entries * (8.0 + 2.0 * Cb * sizeof(T)) + (double)n_rows * Cb * sizeof(T), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_, true>), dim3(blocks), dim3(FGI_THREADS), sizeof(float) * Cb * 4, s, (const T *)P, xyz, start, start, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, n_rows))
+    DCF_DISPATCH_DTYPE(dtype, {
+        if (Cb == 64) DCF_FGP(1);
+        else if (Cb == 128) DCF_FGP(2);
+        else if (Cb == 192) DCF_FGP(3);
+        else DCF_FGP(4);
+    })
+#undef DCF_FGP
     return DCF_OK;
 }

@@ -411,6 +411,16 @@ def rowscale_bias_bwd(dtype, gy, cnt, gb2):
     H.call("dcf_rowscale_bias_bwd", dtype, gy, cnt, gb2, gy.numel() // C, C, H.stream_ptr())
 
 
+def fusion_gather_bwd_pts(dtype, P, xyz, inv, n_max, g, khw, stride, aff, w1d, b1, ghsum, gP, gw1d, gb1):
+    """fusion_gather_bwd_inv with one writer per point row: gP [n_rows, Cb] in the compute dtype, fully written (no zero-fill
+    before, no cast after).  Arguments as fusion_gather_bwd_inv."""
+    start, ent = inv
+    Cb = P.shape[1]
+    seg = start[g * (n_max + 1):]
+    H.call("dcf_fusion_gather_bwd_pts", dtype, P, xyz, seg, P.shape[0], ent[0], ent[1], khw[0] * khw[1] * khw[2], khw[1], khw[2], stride,
+           float(aff[0]), float(aff[1]), float(aff[2]), float(aff[3]), w1d, b1, Cb, ghsum, gP, gw1d, gb1, H.stream_ptr())
+
+
 # ------------------------------------------------------------------ evaluation post-processing (SURVEY.md 8(f) N2)
 EVAL_NMS_CAP = 4096
 

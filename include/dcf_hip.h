@@ -307,6 +307,14 @@ int dcf_fusion_gather_bwd_inv(int dtype, const void *P, const float *xyz, const 
                               float xo, float ys, float yo, const float *w1d, const float *b1, int Cb, const void *ghsum, float *gP,
                               float *gw1d, float *gb1, dcf_stream_t stream);
 
+/* The same sums with ONE writer per point row (a wave owns a range of points and all their pairs): gP [n_rows][Cb] in the compute
+ * dtype, every row written (zeros where no pixel chose the point) -- no zero-filled fp32 accumulator, no float atomics on gP, no
+ * cast afterwards.  start = the map's slice of dcf_fusion_invert's start array (n_rows + 1 entries are read, n_rows <= n_max). */
+int dcf_fusion_gather_bwd_pts(int dtype, const void *P, const float *xyz, const int32_t *start, int n_rows, const int32_t *ent_pix,
+                              const int32_t *ent_pt, int max_entries, int h, int w, int stride, float xs, float xo, float ys, float yo,
+                              const float *w1d, const float *b1, int Cb, const void *ghsum, void *gP, float *gw1d, float *gb1,
+                              dcf_stream_t stream);
+
 /* ------------------------------------------------------------- detection objective (loss.py:129-189)
  * Device half of LossTotal: 2-way cross-entropy at the sampled cells of both anchors + Smooth-L1 of the encoded box
  * offsets, and their gradients (fp32 atomics into ZEROED dense maps), in one launch; *loss (zeroed) receives the scalar.

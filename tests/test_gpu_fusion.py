@@ -224,6 +224,19 @@ def test_fusion_backward_by_point_matches_pixel_run_kernel(Cb, K, case):
         for a, b in zip(got, ref):
             scale = max(float(b.abs().max()), 1e-6)
             assert float((a - b).abs().max()) <= tol * scale * max(1.0, (h * w) ** 0.5), (case, Cb, float((a - b).abs().max()), scale)
+        # one-writer-per-point flavour (dcf_fusion_gather_bwd_pts): dP comes out whole in the compute dtype -- rows of points
+        # nobody chose are written as zeros (the buffer starts as NaN here), on fewer rows than n_max too
+        for rows in (n_max, 256):
+            gp = torch.full((rows, Cb), float("nan"), device="cuda").to(H.torch_dtype(dtype))
+            gw, gb = torch.zeros(Cb * 3, device="cuda"), torch.zeros(Cb, device="cuda")
+            ops.fusion_gather_bwd_pts(dtype, Pd[:rows].contiguous(), xyz, inv, n_max, 0, (K, h, w), stride, aff, w1d, b1, gd, gp, gw, gb)
+            want = ref[0][:rows].to(H.torch_dtype(dtype)).float() if dtype != H.F32 else ref[0][:rows]
+            assert torch.isfinite(gp.float()).all()
+            rtol = tol if dtype == H.F32 else 2.0 ** -7
+            assert float((gp.float() - want).abs().max()) <= rtol * max(float(want.abs().max()), 1e-6) * max(1.0, (h * w) ** 0.5 if dtype == H.F32 else 1.0)
+            for a, b in ((gw, ref[1]), (gb, ref[2])):
+                scale = max(float(b.abs().max()), 1e-6)
+                assert float((a - b).abs().max()) <= tol * scale * max(1.0, (h * w) ** 0.5)
 
 
 def test_cfg4_shape_model_step_fp16():
