@@ -110,8 +110,9 @@ __global__ void __launch_bounds__(CP_THREADS) k_compact_count(const float *pts, 
 }
 
 // single block: exclusive scan of nb block sums in place; total -> *count
-__global__ void __launch_bounds__(CP_THREADS) k_compact_scan(int *blocksum, int nb, int *count)
+__global__ void __launch_bounds__(CP_THREADS) k_compact_scan(int *blocksum, int nb, int *count, int fstride = 0)
 {
+    blocksum += (size_t)blockIdx.y * fstride; count += (size_t)blockIdx.y * fstride;
     int carry = 0;
     for (int b0 = 0; b0 < nb; b0 += CP_THREADS) {
         int i = b0 + threadIdx.x;
@@ -352,6 +353,9 @@ __global__ void __launch_bounds__(256) k_voxel_occupancy(const float *pts, int n
 struct KnnGrid {
     int h, w, h8, w8, stride;
     float xs, xo, ys, yo;
+    // batched launches (grid.y = frame): per-frame strides of the point rows (floats), the valid counts (ints), the workspace
+    // (ints) and the index maps (ints); all 0 for a single frame
+    int fs_xyz, fs_cnt, fs_ws, fs_out;
 };
 
 __device__ __forceinline__ int cell_key(int ci, int cj, const KnnGrid &g)
@@ -372,6 +376,7 @@ __global__ void __launch_bounds__(256) k_knn_hist(const float *xyz, const int *c
                                                   int *pkey)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    xyz += (size_t)blockIdx.y * g.fs_xyz; count += blockIdx.y * g.fs_cnt; cellcnt += (size_t)blockIdx.y * g.fs_ws; pkey += (size_t)blockIdx.y * g.fs_ws;
     const int n = min(*count, n_max);
     if (i >= n) return;
     int ci, cj;
@@ -382,8 +387,9 @@ __global__ void __launch_bounds__(256) k_knn_hist(const float *xyz, const int *c
 }
 
 // generic multi-block exclusive scan over ints (count -> start), 3 phases
-__global__ void __launch_bounds__(CP_THREADS) k_scan_blocksum(const int *in, int n, int *blocksum)
+__global__ void __launch_bounds__(CP_THREADS) k_scan_blocksum(const int *in, int n, int *blocksum, int fstride = 0)
 {
+    in += (size_t)blockIdx.y * fstride; blocksum += (size_t)blockIdx.y * fstride;
     const int base = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS;
     int c = 0;
 #pragma unroll
@@ -394,8 +400,9 @@ __global__ void __launch_bounds__(CP_THREADS) k_scan_blocksum(const int *in, int
     if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
 }
 
-__global__ void __launch_bounds__(CP_THREADS) k_scan_apply(const int *in, int n, const int *blockoff, int *out, int *cursor)
+__global__ void __launch_bounds__(CP_THREADS) k_scan_apply(const int *in, int n, const int *blockoff, int *out, int *cursor, int fstride = 0)
 {
+    in += (size_t)blockIdx.y * fstride; blockoff += (size_t)blockIdx.y * fstride; out += (size_t)blockIdx.y * fstride; cursor += (size_t)blockIdx.y * fstride;
     const int base = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS;
     int v[CP_ITEMS];
     int c = 0;
@@ -417,8 +424,10 @@ __global__ void __launch_bounds__(CP_THREADS) k_scan_apply(const int *in, int n,
 }
 
 __global__ void __launch_bounds__(256) k_knn_fill(const float *xyz, const int *count, int n_max, const int *pkey, int *cursor,
-                                                  float4 *sorted)
+                                                  float4 *sorted, int fs_xyz = 0, int fs_cnt = 0, int fs_ws = 0)
 {
+    xyz += (size_t)blockIdx.y * fs_xyz; count += blockIdx.y * fs_cnt; pkey += (size_t)blockIdx.y * fs_ws; cursor += (size_t)blockIdx.y * fs_ws;
+    sorted = reinterpret_cast<float4 *>(reinterpret_cast<int *>(sorted) + (size_t)blockIdx.y * fs_ws);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = min(*count, n_max);
     if (i >= n) return;
@@ -467,6 +476,8 @@ template <int K>
 __global__ void __launch_bounds__(256) k_knn_search(const int *count, int n_max, KnnGrid g, const int *cellstart,
                                                     const float4 *sorted, float rmax2, int *out)
 {
+    count += blockIdx.y * g.fs_cnt; cellstart += (size_t)blockIdx.y * g.fs_ws; out += (size_t)blockIdx.y * g.fs_out;
+    sorted = reinterpret_cast<const float4 *>(reinterpret_cast<const int *>(sorted) + (size_t)blockIdx.y * g.fs_ws);
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (tile >= g.h8 * g.w8) return;
@@ -638,6 +649,8 @@ template <int K>
 __global__ void __launch_bounds__(256) k_knn_search_wave(const int *count, int n_max, KnnGrid g, const int *cellstart,
                                                          const float4 *sorted, float rmax2, int *out)
 {
+    count += blockIdx.y * g.fs_cnt; cellstart += (size_t)blockIdx.y * g.fs_ws; out += (size_t)blockIdx.y * g.fs_out;
+    sorted = reinterpret_cast<const float4 *>(reinterpret_cast<const int *>(sorted) + (size_t)blockIdx.y * g.fs_ws);
     const int lane = threadIdx.x & 63;
     const int pix = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int hw = g.h * g.w;
@@ -958,16 +971,17 @@ extern "C" size_t dcf_knn_workspace_bytes(int n_max, int h, int w)
     return ints * sizeof(int) + sizeof(float4) * (size_t)n_max + 64;
 }
 
-extern "C" int dcf_knn_bev(const float *xyz, const int32_t *count_dev, int n_max, int K, int h, int w, int stride,
-                           float xs, float xo, float ys, float yo, float rmax2, int32_t *idx_out, void *ws,
-                           dcf_stream_t stream)
+static int knn_bev_impl(const char *who, const float *xyz, const int32_t *count_dev, int B, int n_max, int K, int h, int w, int stride,
+                        float xs, float xo, float ys, float yo, float rmax2, int32_t *idx_out, void *ws, size_t ws_stride_bytes, hipStream_t s)
 {
-    DCF_REQUIRE(xyz && count_dev && idx_out && ws, "dcf_knn_bev: null pointer");
-    DCF_REQUIRE(K >= 1 && K <= 8, "dcf_knn_bev: K must be 1..8 (got %d)", K);
-    DCF_REQUIRE(h > 0 && w > 0 && stride > 0 && n_max >= 0, "dcf_knn_bev: bad dims");
-    hipStream_t s = S(stream);
+    DCF_REQUIRE(xyz && count_dev && idx_out && ws, "%s: null pointer", who);
+    DCF_REQUIRE(K >= 1 && K <= 8, "%s: K must be 1..8 (got %d)", who, K);
+    DCF_REQUIRE(h > 0 && w > 0 && stride > 0 && n_max >= 0 && B >= 1 && B <= 65535, "%s: bad dims", who);
+    DCF_REQUIRE(B == 1 || (ws_stride_bytes % 16 == 0 && ws_stride_bytes >= dcf_knn_workspace_bytes(n_max, h, w) && ws_stride_bytes / 4 < (1ull << 31)),
+                "%s: workspace stride must be a multiple of 16 bytes and hold one frame's workspace", who);
     KnnGrid g;
     g.h = h; g.w = w; g.stride = stride; g.xs = xs; g.xo = xo; g.ys = ys; g.yo = yo;
+    g.fs_xyz = B > 1 ? n_max * 3 : 0; g.fs_cnt = B > 1 ? 1 : 0; g.fs_ws = B > 1 ? (int)(ws_stride_bytes / 4) : 0; g.fs_out = B > 1 ? K * h * w : 0;
     int ncell;
     knn_dims(h, w, g.h8, g.w8, ncell);
     const int nscan = ncell + 1;
@@ -980,18 +994,20 @@ extern "C" int dcf_knn_bev(const float *xyz, const int32_t *count_dev, int n_max
     size_t ints = 3 * (size_t)nscan + (size_t)nsb + 8 + (size_t)n_max;
     ints = (ints + 3) & ~(size_t)3;
     float4 *sorted = (float4 *)((char *)ws + ints * sizeof(int));
-    DCF_HIP(hipMemsetAsync(cellcnt, 0, sizeof(int) * (size_t)nscan, s));
+    if (B == 1) DCF_HIP(hipMemsetAsync(cellcnt, 0, sizeof(int) * (size_t)nscan, s));
+    else DCF_HIP(hipMemset2DAsync(cellcnt, ws_stride_bytes, 0, sizeof(int) * (size_t)nscan, B, s));
+    const double fB = (double)B;
     if (n_max > 0) {
         const int nb = cdiv(n_max, 256);
-        DCF_LAUNCH_B("knn_hist", (double)n_max * 16.0, s, hipLaunchKernelGGL(k_knn_hist, dim3(nb), dim3(256), 0, s, xyz, count_dev, n_max, g, cellcnt, pkey));
+        DCF_LAUNCH_B("knn_hist", fB * n_max * 16.0, s, hipLaunchKernelGGL(k_knn_hist, dim3(nb, B), dim3(256), 0, s, xyz, count_dev, n_max, g, cellcnt, pkey));
     }
     int *total = blocksum + nsb;  // scratch int for the scan total
-    DCF_LAUNCH("scan_blocksum", s, hipLaunchKernelGGL(k_scan_blocksum, dim3(nsb), dim3(CP_THREADS), 0, s, cellcnt, nscan, blocksum));
-    DCF_LAUNCH("compact_scan", s, hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(CP_THREADS), 0, s, blocksum, nsb, total));
-    DCF_LAUNCH("scan_apply", s, hipLaunchKernelGGL(k_scan_apply, dim3(nsb), dim3(CP_THREADS), 0, s, cellcnt, nscan, blocksum, cellstart, cursor));
+    DCF_LAUNCH("scan_blocksum", s, hipLaunchKernelGGL(k_scan_blocksum, dim3(nsb, B), dim3(CP_THREADS), 0, s, cellcnt, nscan, blocksum, g.fs_ws));
+    DCF_LAUNCH("compact_scan", s, hipLaunchKernelGGL(k_compact_scan, dim3(1, B), dim3(CP_THREADS), 0, s, blocksum, nsb, total, g.fs_ws));
+    DCF_LAUNCH("scan_apply", s, hipLaunchKernelGGL(k_scan_apply, dim3(nsb, B), dim3(CP_THREADS), 0, s, cellcnt, nscan, blocksum, cellstart, cursor, g.fs_ws));
     if (n_max > 0) {
         const int nb = cdiv(n_max, 256);
-        DCF_LAUNCH_B("knn_fill", (double)n_max * (12.0 + 4.0 + 16.0), s, hipLaunchKernelGGL(k_knn_fill, dim3(nb), dim3(256), 0, s, xyz, count_dev, n_max, pkey, cursor, sorted));
+        DCF_LAUNCH_B("knn_fill", fB * n_max * (12.0 + 4.0 + 16.0), s, hipLaunchKernelGGL(k_knn_fill, dim3(nb, B), dim3(256), 0, s, xyz, count_dev, n_max, pkey, cursor, sorted, g.fs_xyz, g.fs_cnt, g.fs_ws));
     }
     const int nbp = cdiv(g.h8 * g.w8, 4);   // one wave per 8x8 pixel tile
     // coarse sites: one wave per pixel (lanes split the candidates).  DCF_KNN_KERNEL = wave | tile forces one of the two
@@ -1002,10 +1018,10 @@ extern "C" int dcf_knn_bev(const float *xyz, const int32_t *count_dev, int n_max
 #define KNN_CASE(KK)                                                                                                     \
     case KK:                                                                                                             \
         if (per_wave)                                                                                                    \
-            DCF_LAUNCH_B("knn_search_wave", (double)h * w * K * 4.0 + (double)n_max * 16.0, s, hipLaunchKernelGGL(k_knn_search_wave<KK>, dim3(nbw), dim3(256), 0, s, count_dev, n_max, g, \
+            DCF_LAUNCH_B("knn_search_wave", fB * ((double)h * w * K * 4.0 + (double)n_max * 16.0), s, hipLaunchKernelGGL(k_knn_search_wave<KK>, dim3(nbw, B), dim3(256), 0, s, count_dev, n_max, g, \
                                                                 cellstart, sorted, rmax2, idx_out));                     \
         else                                                                                                             \
-            DCF_LAUNCH_B("knn_search", (double)h * w * K * 4.0 + (double)n_max * 16.0, s, hipLaunchKernelGGL(k_knn_search<KK>, dim3(nbp), dim3(256), 0, s, count_dev, n_max, g, \
+            DCF_LAUNCH_B("knn_search", fB * ((double)h * w * K * 4.0 + (double)n_max * 16.0), s, hipLaunchKernelGGL(k_knn_search<KK>, dim3(nbp, B), dim3(256), 0, s, count_dev, n_max, g, \
                                                            cellstart, sorted, rmax2, idx_out));                          \
         break;
     switch (K) {
@@ -1013,6 +1029,22 @@ extern "C" int dcf_knn_bev(const float *xyz, const int32_t *count_dev, int n_max
     }
 #undef KNN_CASE
     return DCF_OK;
+}
+
+extern "C" int dcf_knn_bev(const float *xyz, const int32_t *count_dev, int n_max, int K, int h, int w, int stride,
+                           float xs, float xo, float ys, float yo, float rmax2, int32_t *idx_out, void *ws,
+                           dcf_stream_t stream)
+{
+    return knn_bev_impl("dcf_knn_bev", xyz, count_dev, 1, n_max, K, h, w, stride, xs, xo, ys, yo, rmax2, idx_out, ws, 0, S(stream));
+}
+
+// B frames of a batch in one launch per phase (grid.y = frame): xyz [B][n_max][3], count_dev [B], idx_out [B][K][h][w], ws = B
+// workspaces ws_stride_bytes apart.  Same results as B calls of dcf_knn_bev; a coarse site's search then fills the chip.
+extern "C" int dcf_knn_bev_batch(const float *xyz, const int32_t *count_dev, int B, int n_max, int K, int h, int w, int stride,
+                                 float xs, float xo, float ys, float yo, float rmax2, int32_t *idx_out, void *ws, size_t ws_stride_bytes,
+                                 dcf_stream_t stream)
+{
+    return knn_bev_impl("dcf_knn_bev_batch", xyz, count_dev, B, n_max, K, h, w, stride, xs, xo, ys, yo, rmax2, idx_out, ws, ws_stride_bytes, S(stream));
 }
 
 extern "C" size_t dcf_fusion_invert_workspace_bytes(int n_max, int nmaps)

@@ -409,8 +409,12 @@ class ObjectDetection_DCF(_FlatParamModule):
             else:
                 site = torch.empty((B, self.K, L // s, W // s), dtype=torch.int32, device=dev)
             ws = None if bufs is None else bufs["ws"][si - 1]
-            for b in range(B):
-                ops.knn_bev(points[b], cnt[b:b + 1], self.K, L // s, W // s, s, self._grid.aff, self.r_max, ws=ws, out=site[b])
+            if B > 1 and points.is_contiguous() and cnt.is_contiguous():
+                # every phase once for the whole batch (grid.y = frame): half the launches, and the coarse sites' searches fill the chip
+                ops.knn_bev_batch(points, cnt, self.K, L // s, W // s, s, self._grid.aff, self.r_max, ws=ws, out=site)
+            else:
+                for b in range(B):
+                    ops.knn_bev(points[b], cnt[b:b + 1], self.K, L // s, W // s, s, self._grid.aff, self.r_max, ws=None if ws is None else ws[0], out=site[b])
             idx.append(site)
         return dict(xyz=points.contiguous(), uv=uv.contiguous(), cnt=cnt, idx=idx, aff=self._grid.aff)
 
@@ -422,7 +426,7 @@ class ObjectDetection_DCF(_FlatParamModule):
         for si in range(1, 5):
             s = 2 ** si
             idx.append(torch.empty((B, self.K, L // s, W // s), dtype=torch.int32, device=device))
-            ws.append(torch.empty((H.lib().dcf_knn_workspace_bytes(n_max, L // s, W // s),), dtype=torch.uint8, device=device))
+            ws.append(torch.empty((B, ops.knn_ws_stride(n_max, L // s, W // s)), dtype=torch.uint8, device=device))
         maps = [t[b] for t in idx for b in range(B)]
         ns, ne, nw = ops.fusion_invert_sizes(maps, n_max)
         inv = (torch.empty((ns,), dtype=torch.int32, device=device), torch.empty((2, ne), dtype=torch.int32, device=device),

@@ -327,6 +327,28 @@ def knn_bev(xyz, cnt, K, h, w, stride, aff, rmax=None, ws=None, out=None):
     return idx
 
 
+def knn_ws_stride(n_max, h, w):
+    """Bytes between the per-frame workspaces of knn_bev_batch."""
+    return (H.lib().dcf_knn_workspace_bytes(n_max, h, w) + 255) // 256 * 256
+
+
+def knn_bev_batch(xyz, cnt, K, h, w, stride, aff, rmax=None, ws=None, out=None):
+    """All frames of a batch in one launch per phase: xyz [B,n_max,3], cnt int32 [B] -> idx int32 [B,K,h,w]
+    (= knn_bev frame by frame).  ws: uint8 [B, knn_ws_stride(...)]."""
+    B, n_max = xyz.shape[0], xyz.shape[1]
+    dev = xyz.device
+    st = knn_ws_stride(n_max, h, w)
+    idx = torch.empty((B, K, h, w), dtype=torch.int32, device=dev) if out is None else _chk(out, "out")
+    if ws is None:
+        ws = torch.empty((B, st), dtype=torch.uint8, device=dev)
+    if ws.shape[0] < B or ws.stride(0) != st:
+        raise H.DcfError("knn_bev_batch: workspace must be [B, %d] bytes" % st)
+    r2 = -1.0 if rmax is None else float(np.float32(rmax) * np.float32(rmax))
+    H.call("dcf_knn_bev_batch", _chk(xyz, "xyz"), _chk(cnt, "cnt"), B, n_max, K, h, w, stride, float(aff[0]), float(aff[1]), float(aff[2]), float(aff[3]),
+           r2, idx, ws, st, H.stream_ptr())
+    return idx
+
+
 # ------------------------------------------------------------------ fusion
 def point_sample_fwd(dtype, fmap, uv, cnt, n_max, out=None):
     """out: optional ZEROED [n_max, Cf] tensor to write into (a frame's slice of a batch tensor)."""

@@ -97,6 +97,11 @@ size_t dcf_knn_workspace_bytes(int n_max, int h, int w);
 int dcf_knn_bev(const float *xyz, const int32_t *count_dev, int n_max, int K, int h, int w, int stride,
                 float xs, float xo, float ys, float yo, float rmax2, int32_t *idx_out, void *ws,
                 dcf_stream_t stream);
+/* The B frames of a batch in one launch per phase: xyz [B][n_max][3], count_dev [B], idx_out [B][K][h][w]; ws = B workspaces of
+ * dcf_knn_workspace_bytes(n_max, h, w), ws_stride_bytes apart (a multiple of 16).  Same indices as B calls of dcf_knn_bev. */
+int dcf_knn_bev_batch(const float *xyz, const int32_t *count_dev, int B, int n_max, int K, int h, int w, int stride,
+                      float xs, float xo, float ys, float yo, float rmax2, int32_t *idx_out, void *ws, size_t ws_stride_bytes,
+                      dcf_stream_t stream);
 
 /* Inverse of the KNN maps of a step (sites x frames) for the fusion backward: the (pixel, point) pairs of every
  * idx [K][h][w] counting-sorted by (map, point).  start int32 [nmaps*(n_max+1)]: pairs of point q of map g are

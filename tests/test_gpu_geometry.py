@@ -362,3 +362,28 @@ def test_knn_tile_kernel_far_cluster_full_site(where):
     assert np.array_equal(got, geometry_ref.knn_bev(xyz, K, h, w, stride, g.aff))
     got = ops.knn_bev(d, cnt, K, h, w, stride, g.aff, rmax=30.0).cpu().numpy()
     assert np.array_equal(got, geometry_ref.knn_bev(xyz, K, h, w, stride, g.aff, rmax=30.0))
+
+
+@pytest.mark.parametrize("stride,K", [(2, 3), (8, 5), (16, 3)])
+def test_knn_batch_equals_per_frame(stride, K):
+    """dcf_knn_bev_batch (every phase once for the batch, grid.y = frame) == dcf_knn_bev frame by frame, bit for bit: frames with
+    different valid counts (one of them empty), tile kernel and wave kernel sites."""
+    ops, det = pkg("ops"), pkg("detfill")
+    g, xyz = _cfg2_cloud(seed=13)
+    n_max = 40960
+    h, w = 704 // stride, 800 // stride
+    B = 3
+    pts = torch.zeros((B, n_max, 3), device="cuda")
+    counts = [xyz.shape[0], 0, 1234]
+    _, xyz2 = _cfg2_cloud(seed=14)
+    pts[0, :counts[0]] = torch.from_numpy(xyz).cuda()
+    pts[2, :counts[2]] = torch.from_numpy(xyz2[:counts[2]]).cuda()
+    cnt = torch.tensor(counts, dtype=torch.int32, device="cuda")
+    got = ops.knn_bev_batch(pts, cnt, K, h, w, stride, g.aff)
+    for b in range(B):
+        ref = ops.knn_bev(pts[b], cnt[b:b + 1], K, h, w, stride, g.aff)
+        assert torch.equal(got[b], ref), "frame %d" % b
+    assert int((got[1] != -1).sum()) == 0
+    got2 = ops.knn_bev_batch(pts, cnt, K, h, w, stride, g.aff, rmax=2.0)
+    for b in range(B):
+        assert torch.equal(got2[b], ops.knn_bev(pts[b], cnt[b:b + 1], K, h, w, stride, g.aff, rmax=2.0))
