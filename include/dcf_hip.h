@@ -108,7 +108,7 @@ int dcf_knn_bev_batch(const float *xyz, const int32_t *count_dev, int B, int n_m
  * [start[g*(n_max+1)+q], start[g*(n_max+1)+q+1]); ent_pix / ent_pt int32 [sum K*h*w] (pixel packed (i<<16)|j).
  * maps is a HOST array.  ws: dcf_fusion_invert_workspace_bytes(n_max, nmaps).  Pair order inside a point is not
  * deterministic (atomic cursor). */
-#define DCF_MAX_KNN_MAPS 16
+#define DCF_MAX_KNN_MAPS 32
 typedef struct { const int32_t *idx; int32_t h, w; } dcf_knn_map;
 size_t dcf_fusion_invert_workspace_bytes(int n_max, int nmaps);
 int dcf_fusion_invert(const dcf_knn_map *maps, int nmaps, int K, int n_max, int32_t *start, int32_t *ent_pix, int32_t *ent_pt,
