@@ -59,6 +59,7 @@ class _RunPlan(torch.autograd.Function):
         ctx.model = model
         pred = model._plan.forward(model._backend, x_lidar, x_image, geom, save=need)
         ctx.saved_graph = need
+        model._fwd_serial = ctx.serial = getattr(model, "_fwd_serial", 0) + 1
         return pred
 
     @staticmethod
@@ -66,6 +67,12 @@ class _RunPlan(torch.autograd.Function):
         model = ctx.model
         if not ctx.saved_graph:
             raise RuntimeError("backward through a forward that ran without saving activations")
+        if ctx.serial != model._fwd_serial:
+            # the plan keeps ONE set of saved activations (and one gradient arena that every backward overwrites): unlike an
+            # nn.Module tree under autograd, forward(a); forward(b); loss_a.backward() cannot work -- say so instead of silently
+            # differentiating b's activations
+            raise RuntimeError("backward of a stale forward: this module keeps the activations of its LAST forward only "
+                               "(call backward before the next forward; gradients are overwritten, not accumulated)")
         model._plan.backward(model._backend, gpred.contiguous())
         model._bind_grads()
         return None, None, None, None, None, None
@@ -79,11 +86,14 @@ class _RunGraphs(torch.autograd.Function):
     @staticmethod
     def forward(ctx, token, model, x_lidar, x_image, geom):
         ctx.model = model
+        model._fwd_serial = ctx.serial = getattr(model, "_fwd_serial", 0) + 1
         return model._graphs.run_forward(x_lidar, x_image, geom)
 
     @staticmethod
     def backward(ctx, gpred):
         model = ctx.model
+        if ctx.serial != model._fwd_serial:
+            raise RuntimeError("backward of a stale forward: this module keeps the activations of its LAST forward only")
         model._graphs.run_backward(gpred)
         model._bind_grads()
         return None, None, None, None, None

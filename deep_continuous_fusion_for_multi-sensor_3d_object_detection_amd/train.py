@@ -329,28 +329,60 @@ def make_dataset(config, mode="train"):
     return SyntheticDataset(config, length=64, raw=True)
 
 
+def evaluate(training, tester, dataset, loader, max_batches=None):
+    """The reference's evaluation pass (train.py:87-100 every 500 batches, :105-122 at the end of an epoch): loss, the
+    score-threshold / NMS / precision-recall counters of test.Test over the test loader.  Returns (mean loss, cumulative
+    loss, number of positives, number of labelled boxes, TP counters per IoU threshold)."""
+    tester.initialize_ap()
+    cum = 0.0
+    n = 0
+    for n, batch in enumerate(loader, 1):
+        batch.wait()
+        x_lidar, geom = training.geometry_async(dataset.geometry, batch["points"], crts=batch.get("crt"), wait_event=batch.event)
+        value, _ = tester.get_eval_value_onestep(x_lidar, batch["image"], batch["bboxes"], batch["num_bboxes"], geom=geom)
+        cum += value
+        if max_batches is not None and n >= max_batches:
+            break
+    tester.display_average_precision()
+    return cum / max(n, 1), cum, tester.get_num_P(), tester.get_num_T(), tester.get_num_TP_set()
+
+
 def main():
     import yaml
     from .frame_loader import FrameLoader
+    from .test import Test
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "config", "config_carla.yaml")) as f:
         config = yaml.safe_load(f)
     init_distributed()
+    rank0 = not dist.is_initialized() or dist.get_rank() == 0
     dataset = make_dataset(config)
     sampler = torch.utils.data.distributed.DistributedSampler(dataset, shuffle=True) if world() > 1 else None
     loader = FrameLoader(dataset, config["batch_size"], sampler=sampler, shuffle=True, num_workers=int(config.get("num_workers", 4)),
                          drop_last=True)
     training = Train(config)
+    # the reference builds Test(training.model) before the loop (train.py:76), which is what puts the trained module in eval
+    # mode (SURVEY.md F4): bn_mode "eval" is the default here, and with bn_mode "module" this constructor has the same effect
+    tester = Test(training.model, config)
+    test_dataset = make_dataset(config, "test") if rank0 else None
+    test_loader = FrameLoader(test_dataset, config["batch_size"], shuffle=False, num_workers=int(config.get("num_workers", 4)),
+                              drop_last=True) if rank0 else None
     os.makedirs("./saved_model", exist_ok=True)
     for epoch in range(config["num_epoch"]):
         if sampler is not None:
             sampler.set_epoch(epoch)
-        if not dist.is_initialized() or dist.get_rank() == 0:
+        if rank0:
             torch.save(training.model.state_dict(), "./saved_model/" + config["saved_model_name"])
         for batch_ndx, batch in enumerate(loader):
             training.one_step_raw(dataset.geometry, batch)
             if batch_ndx % 100 == 0:
                 print("training at ", batch_ndx, "is processed, loss %.4f" % training.loss_value.item())
+            if rank0 and batch_ndx % 500 == 0 and batch_ndx != 0:          # train.py:87-100
+                mean, cum, npos, nt, tp = evaluate(training, tester, test_dataset, test_loader, max_batches=int(config.get("eval_batches", 7)))           # `batch_ndx_ > 5`
+                print("batch %d: validation loss %.4f, positives %d, labelled %d, TP@0.5 %d" % (batch_ndx, mean, npos, nt, tp[0.5]))
+        if rank0:                                                          # train.py:105-122
+            mean, cum, npos, nt, tp = evaluate(training, tester, test_dataset, test_loader, max_batches=int(config.get("eval_batches_epoch", 12)))   # `batch_ndx > 10`
+            print("epoch %d: validation loss %.4f (cumulative %.2f), positives %d, labelled %d, TP %s" % (epoch, mean, cum, npos, nt, dict(tp)))
 
 
 if __name__ == "__main__":

@@ -545,3 +545,19 @@ def test_residual_block_and_module_surfaces():
     with pytest.raises(Exception) as e:
         M.ResidualBlock(32, 32)(x)
     assert "no CPU fallback" in str(e.value)
+
+
+def test_stale_forward_backward_fails_loudly():
+    """The plan keeps the activations of the LAST forward only: forward(a); forward(b); loss_a.backward() must raise instead of
+    silently differentiating b's activations (an nn.Module tree under autograd would have handled it)."""
+    z = load_golden("model_tiny.npz")
+    net, cfg = build(golden_cfg(z), "f32")
+    x = tiny_input()[:1].cuda()
+    img = torch.zeros(1, 3, 8, 8, dtype=torch.uint8, device="cuda")
+    a = net(x, img)
+    b = net(x * 0.5, img)
+    with pytest.raises(RuntimeError) as e:
+        a.sum().backward()
+    assert "stale forward" in str(e.value)
+    b.sum().backward()                       # the last forward is fine
+    assert float(net.flat_grads.abs().sum()) > 0
