@@ -141,8 +141,8 @@ class HipBackend(object):
                         continue
                     B, Ho, Wo = L.out_shape
                     L.nsplit = ops.conv2d_wgrad_splits(B, Ho, Wo, L.cin, L.cout_pad, L.kh, L.kw, L.stride)
-                    L.slab_off = off
-                    off += L.nsplit * L.cout_pad * L.taps * L.cin
+                    L.slab_off = off                        # 256-byte aligned: the 3x3 kernels store 16-byte vectors
+                    off += -(-(L.nsplit * L.cout_pad * L.taps * L.cin) // 64) * 64
                     L.gsum_off = goff                       # [4*nsplit][cout_pad] per-wave sums of g (dbeta)
                     goff += 4 * L.nsplit * L.cout_pad
                 self.slabs = torch.empty(max(off, 4), dtype=torch.float32, device=self.dev)

@@ -1514,6 +1514,16 @@ static bool use_rs(int dtype, int kh, int kw, int stride, int pad)
     return !(e && atoi(e) == 0) && dtype != DCF_F32 && kh == 3 && kw == 3 && stride == 1 && pad == 1;
 }
 
+// shared-staging weight gradient of the 3x3 / stride-1 layers with 128- or 192-channel tiles (conv_wgs.hip)
+struct dcf_wgs_item {
+    const void *x, *gy;
+    float *slabs, *gsum;
+    int B, H, W, Cin, Cout, nsplit;
+};
+int dcf_wgrad3s_kind(int dtype, int B, int H, int W, int Cin, int Cout);
+int dcf_wgrad3s_splits(int kind, int B, int H, int W, int Cin, int Cout);
+int dcf_wgrad3s_launch(int dtype, int kind, const dcf_wgs_item *items, int n, double flops, double bytes, hipStream_t s);
+
 // ================================================================== C ABI
 static int check_conv(const char *who, int dtype, int Cin, int Cout, int kh, int kw, int stride)
 {
@@ -1619,6 +1629,10 @@ extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout,
 {
     int TM, TN, KR;
     int tiles;
+    if (kh == 3 && kw == 3 && stride == 1) {      // (the 16-bit kernel's choice also for fp32 launches of the shape: any count works there)
+        const int kind = dcf_wgrad3s_kind(DCF_BF16, B, Ho, Wo, Cin, Cout);
+        if (kind) return dcf_wgrad3s_splits(kind, B, Ho, Wo, Cin, Cout);
+    }
     static const char *gb = getenv("DCF_WGRAD_BLOCKS");
     // Workgroups per layer.  The backward issues the weight gradients in grouped launches (dcf_conv2d_wgrad_group), where
     // the layers overlap each other: a layer does not have to fill the chip on its own, and fewer pixel ranges mean fewer
@@ -1675,6 +1689,14 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
     const double flops = 2.0 * a.M * Cout * (double)Cin * kh * kw;
     const double wbytes_ = (double)a.xbytes + (double)a.gbytes + (double)nsplit * Cout * kh * kw * Cin * 4.0;
     int TM, TN, KR;
+    if (pad == 1 && H == Ho && W == Wo && kh == 3 && kw == 3 && stride == 1) {
+        const int kind = dcf_wgrad3s_kind(dtype, B, H, W, Cin, Cout);
+        if (kind) {
+            const dcf_wgs_item it = {x, gy, slabs, gsum, B, H, W, Cin, Cout, nsplit};
+            const double wb = (double)a.xbytes + (double)a.gbytes + (double)nsplit * Cout * 9 * Cin * 4.0;
+            return dcf_wgrad3s_launch(dtype, kind, &it, 1, flops, wb, s);
+        }
+    }
     if (pad == 1 && H == Ho && W == Wo && wgrad3_tiles(Cin, Cout, kh, kw, stride, TM, TN, KR)) {
         const bool dma = dtype != DCF_F32 && wgrad3_dma(Wo, TM, TN) && (int64_t)B * H * W * a.pixbytes < (1ll << 31) && (int64_t)a.M * Cout * 2 < (1ll << 31);
         if (dtype == DCF_F32 && TM == 2 && TN == 2) TN = 1;   // fp32 accumulators + fragments of 2x2x3 do not fit 256 VGPRs
@@ -1764,6 +1786,8 @@ extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_st
         const int Ho = (it.H + 2 * it.pad - it.kh) / it.stride + 1, Wo = (it.W + 2 * it.pad - it.kw) / it.stride + 1;
         int TM, TN, KR;
         if (it.dtype == DCF_F32) bucket[i] = -1;
+        else if (it.pad == 1 && it.kh == 3 && it.kw == 3 && it.stride == 1 && dcf_wgrad3s_kind(it.dtype, it.B, it.H, it.W, it.Cin, it.Cout))
+            bucket[i] = 4 + dcf_wgrad3s_kind(it.dtype, it.B, it.H, it.W, it.Cin, it.Cout);       // 5 / 6: shared-staging kernel, quadrants 2 x 2 / 3 x 1
         else if (dcf_conv2d_wgrad_groupable(it.dtype, it.B, it.H, it.W, it.Cin, it.Cout, it.kh, it.kw, it.stride, it.pad)) bucket[i] = 0;
         else if (it.pad == 1 && Ho == it.H && Wo == it.W && wgrad3_tiles(it.Cin, it.Cout, it.kh, it.kw, it.stride, TM, TN, KR)) bucket[i] = -1;
         else {
@@ -1776,6 +1800,22 @@ extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_st
             if (rc) return rc;
         }
     }
+    for (int bk = 5; bk <= 6; ++bk)
+        for (int dt = DCF_BF16; dt <= DCF_F16; ++dt) {
+            std::vector<dcf_wgs_item> ws;
+            double flops = 0.0, bytes = 0.0;
+            for (int i = 0; i < n; ++i) {
+                const dcf_wgrad_item &it = items[i];
+                if (bucket[i] != bk || it.dtype != dt) continue;
+                ws.push_back({it.x, it.gy, it.slabs, it.gsum, it.B, it.H, it.W, it.Cin, it.Cout, it.nsplit});
+                flops += 2.0 * it.B * it.H * it.W * (double)it.Cout * it.Cin * 9;
+                bytes += (double)it.B * it.H * it.W * (it.Cin + it.Cout) * 2.0 + (double)it.nsplit * it.Cout * 9 * it.Cin * 4.0;
+            }
+            if (!ws.empty()) {
+                int rc = dcf_wgrad3s_launch(dt, bk - 4, ws.data(), (int)ws.size(), flops, bytes, s);
+                if (rc) return rc;
+            }
+        }
     static const char *gen_env = getenv("DCF_WGRAD_GROUP_GENERIC");
     const bool group_generic = !(gen_env && atoi(gen_env) == 0);
     for (int bk = 0; bk <= 4; ++bk) {

@@ -29,6 +29,11 @@ SHAPES = [
     (1, 20, 46, 32, 64, 3, 1),       # 64 x 32 tile
     (2, 5, 61, 64, 32, 3, 1),        # 32 x 64 tile
     (3, 33, 75, 64, 64, 3, 1),       # many stages per wave, ranges crossing image boundaries
+    # shared-staging weight-gradient kernel: 128-multiple channels (2 x 2 quadrants) and 192 x 192 (3 x 1)
+    (2, 9, 44, 128, 128, 3, 1),
+    (3, 21, 41, 256, 128, 3, 1),     # two input-channel tiles; pixel ranges crossing frames
+    (1, 13, 50, 192, 192, 3, 1),
+    (2, 30, 38, 192, 192, 3, 1),
 ]
 
 
@@ -179,7 +184,8 @@ def test_wgrad_group_equals_single_launches(dtype):
     import ctypes
     ops, H = pkg("ops"), pkg("_hip")
     shapes = [(2, 12, 40, 64, 64, 3, 1), (1, 9, 47, 128, 64, 3, 1), (2, 7, 50, 64, 128, 3, 1), (2, 17, 13, 64, 64, 3, 2),
-              (1, 24, 16, 256, 192, 1, 1), (2, 10, 10, 128, 192, 3, 2), (1, 40, 52, 32, 32, 3, 1), (1, 8, 8, 192, 256, 1, 1)]
+              (1, 24, 16, 256, 192, 1, 1), (2, 10, 10, 128, 192, 3, 2), (1, 40, 52, 32, 32, 3, 1), (1, 8, 8, 192, 256, 1, 1),
+              (2, 9, 44, 128, 128, 3, 1), (1, 30, 60, 128, 256, 3, 1), (1, 13, 50, 192, 192, 3, 1), (2, 30, 38, 192, 192, 3, 1)]
     keep, items, want = [], [], []
     for i, (B, Hh, W, Cin, Cout, k, s) in enumerate(shapes):
         pad = k // 2

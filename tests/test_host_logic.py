@@ -183,3 +183,4 @@ def test_batched_negative_sampling_consumes_the_generator_like_scalar_calls():
                 if (x, y) not in taken:
                     got.append((x, y))
         assert got == ref and np.random.randint(1 << 30) == tail_ref
+
