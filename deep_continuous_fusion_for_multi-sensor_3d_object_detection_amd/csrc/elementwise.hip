@@ -574,7 +574,7 @@ __global__ void __launch_bounds__(256) k_weight_prep(const dcf_conv_param *table
 }
 
 // Gradient finalisation, one block per (conv, output channel): fixed-order reduction of the
-// wgrad slabs (16 B per lane, 4 independent partial sums), then the folded-BN chain rule
+// wgrad slabs (16 B per lane, slab order, 8 loads in flight per lane), then the folded-BN chain rule
 //   dW = scale*G ; dbeta = sum g ; dgamma = (<W,G> - mean*dbeta) * rsqrt(var+eps).
 // rows = kernel-argument copy of the layers' first rows (prefix sums of cout): the grid is exactly one block per (conv, output
 // channel) instead of max_cout x nconv blocks of which three quarters exit at once
@@ -613,49 +613,123 @@ __global__ void __launch_bounds__(256) k_wgrad_finalize(const dcf_conv_param *ta
     __shared__ float4 gpart[256];
     const int K4 = K >> 2;
     const int G = (K4 >= 256 || !grouped) ? 1 : 256 / K4;
-    const int grp = G == 1 ? 0 : threadIdx.x / K4;
-    const int kbeg = G == 1 ? threadIdx.x * 4 : (threadIdx.x - grp * K4) * 4;
-    const int kstep = G == 1 ? blockDim.x * 4 : K;             // grouped rows: one pass
-    for (int k = kbeg; k < K; k += kstep) {
+    const float sc = d.gamma_off >= 0 ? scale : 1.f;
+    // one finished column: stem zeros, <W, G> for dgamma, scaled store
+    auto finish = [&](int k, float4 g4) {
         const int64_t e = (int64_t)co * K + k;
-        const float *sp = slabs + d.slab_off + e;
         const float4 w = ld4(params + d.w_off + e);
-        float4 part[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) part[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (grp < G) {
-            int sidx = grp;
-            for (; sidx + 3 * G < d.nsplit; sidx += 4 * G) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 v = ld4(sp + (int64_t)(sidx + u * G) * slab_elems);
-                    part[u].x += v.x; part[u].y += v.y; part[u].z += v.z; part[u].w += v.w;
-                }
-            }
-            for (int u = 0; sidx < d.nsplit; sidx += G, ++u) {
-                const float4 v = ld4(sp + (int64_t)sidx * slab_elems);
-                part[u].x += v.x; part[u].y += v.y; part[u].z += v.z; part[u].w += v.w;
-            }
-        }
-        float G4[4] = {(part[0].x + part[1].x) + (part[2].x + part[3].x), (part[0].y + part[1].y) + (part[2].y + part[3].y),
-                       (part[0].z + part[1].z) + (part[2].z + part[3].z), (part[0].w + part[1].w) + (part[2].w + part[3].w)};
-        if (G > 1) {
-            if (grp < G) gpart[threadIdx.x] = make_float4(G4[0], G4[1], G4[2], G4[3]);
-            __syncthreads();
-            if (grp != 0) break;
-            for (int g2 = 1; g2 < G; ++g2) {
-                const float4 v = gpart[g2 * K4 + threadIdx.x];
-                G4[0] += v.x; G4[1] += v.y; G4[2] += v.z; G4[3] += v.w;
-            }
-        }
         // stem weights are stored [Cout][7][8][4]: tap kw=7 and channel 3 are structural zeros
         if (d.flags & 1) {
-            if (((k & 31) >> 2) == 7) G4[0] = G4[1] = G4[2] = 0.f;
-            G4[3] = 0.f;
+            if (((k & 31) >> 2) == 7) g4.x = g4.y = g4.z = 0.f;
+            g4.w = 0.f;
         }
-        dot += (w.x * G4[0] + w.y * G4[1]) + (w.z * G4[2] + w.w * G4[3]);
-        const float sc = d.gamma_off >= 0 ? scale : 1.f;
-        st4(grads + d.w_off + e, make_float4(sc * G4[0], sc * G4[1], sc * G4[2], sc * G4[3]));
+        dot += (w.x * g4.x + w.y * g4.y) + (w.z * g4.z + w.w * g4.w);
+        st4(grads + d.w_off + e, make_float4(sc * g4.x, sc * g4.y, sc * g4.z, sc * g4.w));
+    };
+    if (G > 1) {
+        // short rows: group grp sums the slabs grp, grp + G, ... (8 loads in flight), the group sums are added in group order
+        const int grp = threadIdx.x / K4;
+        const int k = (threadIdx.x - grp * K4) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grp < G) {
+            const float *sp = slabs + d.slab_off + (int64_t)co * K + k;
+            int sidx = grp;
+            for (; sidx + 7 * G < d.nsplit; sidx += 8 * G) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = ld4(sp + (int64_t)(sidx + u * G) * slab_elems);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+            for (; sidx < d.nsplit; sidx += G) {
+                const float4 v = ld4(sp + (int64_t)sidx * slab_elems);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            gpart[threadIdx.x] = acc;
+        }
+        __syncthreads();
+        if (grp == 0) {
+            for (int g2 = 1; g2 < G; ++g2) {
+                const float4 v = gpart[g2 * K4 + threadIdx.x];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            finish(k, acc);
+        }
+    } else {
+        // long rows: a thread owns the columns tid, tid + 256, ... and walks the slabs of up to FOUR of them together, in
+        // slab order, with 8 loads in flight (a row of 288 or 576 vectors is then one or two dependent chains, not two or three)
+        for (int kb = 0; kb < K4; kb += 1024) {
+            const int ncol = min(4, (K4 - kb + 255) >> 8);
+            float4 acc[4];
+            const float *sp[4];
+            bool on[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int k4 = kb + c * 256 + (int)threadIdx.x;
+                on[c] = k4 < K4;
+                sp[c] = slabs + d.slab_off + (int64_t)co * K + (on[c] ? k4 : 0) * 4;
+            }
+            if (ncol == 1) {
+                if (on[0]) {
+                    int sidx = 0;
+                    for (; sidx + 7 < d.nsplit; sidx += 8) {
+                        float4 v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = ld4(sp[0] + (int64_t)(sidx + u) * slab_elems);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { acc[0].x += v[u].x; acc[0].y += v[u].y; acc[0].z += v[u].z; acc[0].w += v[u].w; }
+                    }
+                    for (; sidx < d.nsplit; ++sidx) {
+                        const float4 v = ld4(sp[0] + (int64_t)sidx * slab_elems);
+                        acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+                    }
+                }
+            } else if (ncol == 2) {
+                int sidx = 0;
+                for (; sidx + 3 < d.nsplit; sidx += 4) {
+                    float4 v[2][4];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[c][u] = on[c] ? ld4(sp[c] + (int64_t)(sidx + u) * slab_elems) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { acc[c].x += v[c][u].x; acc[c].y += v[c][u].y; acc[c].z += v[c][u].z; acc[c].w += v[c][u].w; }
+                }
+                for (; sidx < d.nsplit; ++sidx)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        if (on[c]) {
+                            const float4 v = ld4(sp[c] + (int64_t)sidx * slab_elems);
+                            acc[c].x += v.x; acc[c].y += v.y; acc[c].z += v.z; acc[c].w += v.w;
+                        }
+            } else {
+                int sidx = 0;
+                for (; sidx + 1 < d.nsplit; sidx += 2) {
+                    float4 v[4][2];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) v[c][u] = on[c] ? ld4(sp[c] + (int64_t)(sidx + u) * slab_elems) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) { acc[c].x += v[c][u].x; acc[c].y += v[c][u].y; acc[c].z += v[c][u].z; acc[c].w += v[c][u].w; }
+                }
+                for (; sidx < d.nsplit; ++sidx)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (on[c]) {
+                            const float4 v = ld4(sp[c] + (int64_t)sidx * slab_elems);
+                            acc[c].x += v.x; acc[c].y += v.y; acc[c].z += v.z; acc[c].w += v.w;
+                        }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (on[c]) finish((kb + c * 256 + (int)threadIdx.x) * 4, acc[c]);
+        }
     }
     if (d.gamma_off < 0) return;
     __shared__ float red[8];
