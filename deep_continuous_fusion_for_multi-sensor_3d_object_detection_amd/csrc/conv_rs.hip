@@ -30,6 +30,10 @@
 #include "dcf_common.h"
 #include "conv_common.h"
 
+#ifndef DCF_RS_SPREAD
+#define DCF_RS_SPREAD 1
+#endif
+
 namespace {
 
 struct RsArgs {
@@ -241,9 +245,31 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
                 __builtin_amdgcn_s_barrier();
                 // (issuing the second half-workgroup's DMA after its MFMAs instead -- waves w and w + 4 share a SIMD -- was
                 // measured: no gain, 26.7 -> 27.3 us on the 128-channel stage)
-                issue_w((kj + DW) / 3, (kj + DW) % 3, wsi);
-                if (kj == 0) issue_x(DX, xsi, 0, PXA);
-                if (kj == 1) issue_x(DX, xsi, PXA, CX);
+                // The group's pieces go out one per K-quarter, between the MFMAs (DCF_RS_SPREAD): a burst of every wave's
+                // pieces right after the barrier holds the waves at their issue (~60-180 cycles per piece) while the
+                // matrix pipes idle.  Waves without tiles (C == 0) issue theirs at once.
+                const int xj0 = kj == 0 ? 0 : PXA, xj1 = kj == 0 ? PXA : (kj == 1 ? CX : PXA);       // kj == 2: none
+                auto issue_part = [&](int part) {
+                    const int dw = (kj + DW) / 3, kw = (kj + DW) % 3;
+                    const unsigned dstw = __builtin_amdgcn_readfirstlane(ldsW0 + wsi * WSLOT + wid * PWW * 1024);
+                    const bool okw = kis[dw] < 3 && !(a.dbg & 16);
+                    const unsigned koff = (unsigned)(wst[dw] + kw * tapstep);
+#pragma unroll
+                    for (int j = 0; j < PWW; ++j)
+                        if ((j & 3) == part) glds16(srcW, okw ? wbase[j] + koff : OOB, dstw + j * 1024);
+                    const int kix = kis[DX];
+#pragma unroll
+                    for (int j = 0; j < PXW; ++j)
+                        if (j >= xj0 && j < xj1 && ((PWW + j - xj0) & 3) == part) {
+                            const unsigned dst = __builtin_amdgcn_readfirstlane(ldsX0 + xsi * XSLOT + (wid + j * NW) * 1024);
+                            glds16(srcX, (((xok[j] >> kix) & 1) && !(a.dbg & 2)) ? (unsigned)(xbase[j] + xst[DX]) : OOB, dst);
+                        }
+                };
+                if (!DCF_RS_SPREAD || C == 0 || (a.dbg & 1)) {
+                    issue_w((kj + DW) / 3, (kj + DW) % 3, wsi);
+                    if (kj == 0) issue_x(DX, xsi, 0, PXA);
+                    if (kj == 1) issue_x(DX, xsi, PXA, CX);
+                }
                 if constexpr (C > 0) if (!(a.dbg & 1)) {
                     const char *pw = lds + wsr * WSLOT + rdA;
                     const char *px = lds + NSW * WSLOT + xsr * XSLOT + rdX + kj * 128;
@@ -259,6 +285,7 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
                         for (int j = 0; j < C; ++j)
 #pragma unroll
                             for (int i = 0; i < TN; ++i) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+                        if (DCF_RS_SPREAD) issue_part(ks);
                     }
                 }
                 wsr = wsr + 1 == NSW ? 0 : wsr + 1;
