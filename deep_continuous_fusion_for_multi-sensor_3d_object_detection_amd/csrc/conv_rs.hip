@@ -114,16 +114,19 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
     const int wm = (wid & 4) ? WM - 1 - wid % WM : wid % WM;
     const int r = lane & 31, h = lane >> 5;
 
-    // XCD-aware tile order (speed only; same scheme as k_conv_igemm): XCD x takes the x-th contiguous chunk of the
-    // (position tile, channel tile) list, channel tiles fastest
+    // PERSISTENT workgroups, XCD-aware tile order (speed only): XCD x = blockIdx & 7 owns the x-th contiguous chunk of the
+    // (position tile, channel tile) list, channel tiles fastest; its workgroups take the chunk's tiles round-robin.  A
+    // workgroup issues the first DMA groups of its NEXT tile before it stores the current one, so the L2 latency of a
+    // tile's first taps (2-3 us, a third of a 64-channel tile's whole K loop) hides under the previous tile's epilogue.
     const int nt = a.Cn / BN;
     const int nblk = a.mtiles * nt;
     const int chunk = (nblk + 7) >> 3;
-    const int gidx = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if (gidx >= nblk) return;
-    const int n0 = (gidx % nt) * BN;
+    const int wpx = gridDim.x >> 3;                   // workgroups per XCD
+    const int chunk_lo = (blockIdx.x & 7) * chunk, chunk_hi = min(chunk_lo + chunk, nblk);
+    int gidx = chunk_lo + (blockIdx.x >> 3);
+    if (gidx >= chunk_hi) return;
+    int n0 = 0, q0 = 0;
     const int BM = a.npt * 32;
-    const int q0 = (gidx / nt) * BM;                  // first padded position of this tile
     const int Wp = a.W + 2, BH = a.B * a.H;
     const int rowbytes = a.Ck * 2;
     const int cchunks = rowbytes / 128;
@@ -144,11 +147,6 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
     // 1 and 2, i.e. for all three taps).
     const int l8 = lane >> 3, lc = lane & 7;
     unsigned wbase[PWW];
-#pragma unroll
-    for (int j = 0; j < PWW; ++j) {
-        const int row = (wid * PWW + j) * 8 + l8;
-        wbase[j] = (unsigned)(n0 + row) * (unsigned)(9 * rowbytes) + (unsigned)((lc ^ ((row >> 1) & 7)) * 16);
-    }
     // pixel pieces of this wave: piece index wid + j*NW (interleaved: the waves' counts differ by at most one);
     // LDS row i of the slot = padded position q0 - 1 + i
     const int npieces = (BM + 2 + 7) >> 3;
@@ -156,17 +154,27 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
     const int pxa = (cntx + 1) >> 1, pxb = cntx >> 1;      // issued with tap 0 / tap 1 of an earlier stage
     int xbase[PXW], xok[PXW];
     const int rowpitch = a.W * rowbytes;
+    auto setup_tile = [&](int gi) __attribute__((always_inline)) {                        // DMA source offsets of tile gi
+        n0 = (gi % nt) * BN;
+        q0 = (gi / nt) * BM;                               // first padded position of this tile
 #pragma unroll
-    for (int j = 0; j < PXW; ++j) {
-        const int i = (wid + j * NW) * 8 + l8;
-        const int p = q0 - 1 + i;
-        const int R = p >= 0 ? p / Wp : 0;
-        const int c = p - R * Wp;
-        const int oh = R % a.H;
-        const bool live = (i < BM + 2) && (p >= 0) && (R < BH) && (c >= 1) && (c <= a.W);
-        xbase[j] = (R * a.W + c - 1) * rowbytes + ((lc ^ ((i >> 1) & 7)) * 16);
-        xok[j] = live ? ((oh >= 1 ? 1 : 0) | 2 | (oh + 1 < a.H ? 4 : 0)) : 0;
-    }
+        for (int j = 0; j < PWW; ++j) {
+            const int row = (wid * PWW + j) * 8 + l8;
+            wbase[j] = (unsigned)(n0 + row) * (unsigned)(9 * rowbytes) + (unsigned)((lc ^ ((row >> 1) & 7)) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < PXW; ++j) {
+            const int i = (wid + j * NW) * 8 + l8;
+            const int p = q0 - 1 + i;
+            const int R = p >= 0 ? p / Wp : 0;
+            const int c = p - R * Wp;
+            const int oh = R % a.H;
+            const bool live = (i < BM + 2) && (p >= 0) && (R < BH) && (c >= 1) && (c <= a.W);
+            xbase[j] = (R * a.W + c - 1) * rowbytes + ((lc ^ ((i >> 1) & 7)) * 16);
+            xok[j] = live ? ((oh >= 1 ? 1 : 0) | 2 | (oh + 1 < a.H ? 4 : 0)) : 0;
+        }
+    };
+    setup_tile(gidx);
     f32x16 acc[TN][TMMAX];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
@@ -182,6 +190,60 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
     const int rdA = (wn * TN * 32 + r) * 128;
     const int rdX = (pt0 * 32 + r) * 128;
     const int tapstep = a.flip ? -rowbytes : rowbytes;
+
+    // ---- epilogue of one tile (as k_conv_igemm): v = acc + shift + res ; relu ; v *= (mask > 0) ; 8 consecutive channels per access
+    T *y = reinterpret_cast<T *>(a.y);
+    const T *res = reinterpret_cast<const T *>(a.res);
+    const T *mask = reinterpret_cast<const T *>(a.mask);
+    auto store_tile = [&](int q0c, int n0c) __attribute__((always_inline)) {
+        if (a.dbg & 4) return;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TMMAX; ++j) acc_rows8(acc[i][j]);
+#pragma unroll
+        for (int j = 0; j < TMMAX; ++j) {
+            if (j >= cnt) continue;
+            const int p = q0c + (pt0 + j) * 32 + r;
+            const int R = p / Wp, c = p - R * Wp;
+            if (p >= a.Q || c < 1 || c > a.W) continue;      // padding position: no output
+            const int m = R * a.W + c - 1;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    const int ch = n0c + (wn * TN + i) * 32 + 16 * pp + 8 * h;
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = acc[i][j][8 * pp + k];
+                    if (a.shift) {
+                        float sh[8];
+                        ld8(a.shift + ch, sh);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] += sh[k];
+                    }
+                    const size_t o = (size_t)m * a.Cn + ch;
+                    if (res) {
+                        float rr[8];
+                        ld8(res + o, rr);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] += rr[k];
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+                    }
+                    if (mask) {
+                        float mm[8];
+                        ld8(mask + o, mm);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = mm[k] > 0.f ? v[k] : 0.f;
+                    }
+                    st8(y + o, v);
+                }
+            }
+        }
+    };
 
     // Main loop, specialised on the wave's tile count C and on its pixel-piece count CX (both wave-uniform: one dispatch, no
     // branches between the MFMAs, every wait an immediate).  Step t = 3 s + kj issues "group t": the weights of tap t + DW
@@ -201,22 +263,20 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
         // stage coordinates of stages s .. s + DS: weight offset of the stage's tap 0, pixel offset, kernel row (3 = past the end)
         int wst[DS + 1], xst[DS + 1], kis[DS + 1];
         int lki = 0, lcc = 0;
-        auto stage_entry = [&](int d) {
+        auto stage_entry = [&](int d) __attribute__((always_inline)) {
             kis[d] = lki > 2 ? 3 : lki;
             wst[d] = (a.flip ? (2 - lki) * 3 + 2 : lki * 3) * rowbytes + lcc * 128;
             xst[d] = (lki - 1) * rowpitch + lcc * 128;
             if (++lcc == cchunks) { lcc = 0; ++lki; }
         };
-#pragma unroll
-        for (int d = 0; d <= DS; ++d) stage_entry(d);
-        auto issue_w = [&](int d, int kj, int slot) {                  // weights of tap kj of stage s + d
+        auto issue_w = [&](int d, int kj, int slot) __attribute__((always_inline)) {                  // weights of tap kj of stage s + d
             const unsigned dst = __builtin_amdgcn_readfirstlane(ldsW0 + slot * WSLOT + wid * PWW * 1024);
             const bool ok = kis[d] < 3 && !(a.dbg & 16);
             const unsigned koff = (unsigned)(wst[d] + kj * tapstep);
 #pragma unroll
             for (int j = 0; j < PWW; ++j) glds16(srcW, ok ? wbase[j] + koff : OOB, dst + j * 1024);
         };
-        auto issue_x = [&](int d, int slot, int j0, int j1) {          // pieces j0 .. j1-1 of the pixel tile of stage s + d
+        auto issue_x = [&](int d, int slot, int j0, int j1) __attribute__((always_inline)) {          // pieces j0 .. j1-1 of the pixel tile of stage s + d
             const int ki = kis[d];
 #pragma unroll
             for (int j = 0; j < PXW; ++j)
@@ -225,18 +285,25 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
                     glds16(srcX, (((xok[j] >> ki) & 1) && !(a.dbg & 2)) ? (unsigned)(xbase[j] + xst[d]) : OOB, dst);
                 }
         };
-        // prologue: groups -3 DX .. -1, then everything landed (the first taps need their data at once anyway)
-        {
-            int wsl = 0, xsl = 0;
+        auto begin_tile = [&]() __attribute__((always_inline)) {                                      // stage bookkeeping of a fresh tile + its first groups
+            lki = 0; lcc = 0;
 #pragma unroll
-            for (int u = -3 * DX; u < 0; ++u) {
-                const int v = u + 3 * DX, sv = v / 3, kj = v - 3 * sv;                 // pixel tile of stage sv < DX
-                if (kj == 0) issue_x(sv, xsl, 0, PXA);
-                if (kj == 1) { issue_x(sv, xsl, PXA, CX); ++xsl; }
-                if (u + DW >= 0) { issue_w((u + DW) / 3, (u + DW) % 3, wsl); ++wsl; }
+            for (int d = 0; d <= DS; ++d) stage_entry(d);
+        // prologue: groups -3 DX .. -1, then everything landed (the first taps need their data at once anyway)
+            {
+                int wsl = 0, xsl = 0;
+#pragma unroll
+                for (int u = -3 * DX; u < 0; ++u) {
+                    const int v = u + 3 * DX, sv = v / 3, kj = v - 3 * sv;                 // pixel tile of stage sv < DX
+                    if (kj == 0) issue_x(sv, xsl, 0, PXA);
+                    if (kj == 1) { issue_x(sv, xsl, PXA, CX); ++xsl; }
+                    if (u + DW >= 0) { issue_w((u + DW) / 3, (u + DW) % 3, wsl); ++wsl; }
+                }
             }
-        }
-        wait_vmcnt<0>();
+        };
+        begin_tile();
+        for (;;) {
+        wait_vmcnt<0>();              // the tile's first groups have landed (and the previous tile's stores are out)
         int wsr = 0, wsi = DW % NSW, xsr = 0, xsi = DX % NSX;         // ring slots: read / issue
         for (int s = 0; s < nstage; ++s) {
 #pragma unroll
@@ -298,6 +365,23 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
             stage_entry(DS);
         }
         wait_vmcnt<0>();              // the trailing dummy pieces still target this workgroup's LDS
+        const int q0c = q0, n0c = n0;
+        gidx += wpx;
+        const bool more = gidx < chunk_hi;
+        if (more) {
+            __builtin_amdgcn_s_barrier();                              // every wave is done with the rings
+            setup_tile(gidx);
+            begin_tile();                                              // in flight under the epilogue below
+        }
+        store_tile(q0c, n0c);
+        if (!more) break;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TMMAX; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+        }
     };
     // dispatch on (tiles, pixel pieces) of this wave; the host's plan keeps both inside the instantiated ranges
 #define DCF_RS_CX(C_)                                                                                               \
@@ -321,57 +405,6 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
     }
 #undef DCF_RS_CX
 
-    if (a.dbg & 4) return;
-    // ---- epilogue (as k_conv_igemm): v = acc + shift + res ; relu ; v *= (mask > 0) ; 8 consecutive channels per access
-    T *y = reinterpret_cast<T *>(a.y);
-    const T *res = reinterpret_cast<const T *>(a.res);
-    const T *mask = reinterpret_cast<const T *>(a.mask);
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TMMAX; ++j) acc_rows8(acc[i][j]);
-#pragma unroll
-    for (int j = 0; j < TMMAX; ++j) {
-        if (j >= cnt) continue;
-        const int p = q0 + (pt0 + j) * 32 + r;
-        const int R = p / Wp, c = p - R * Wp;
-        if (p >= a.Q || c < 1 || c > a.W) continue;      // padding position: no output
-        const int m = R * a.W + c - 1;
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-#pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
-                const int ch = n0 + (wn * TN + i) * 32 + 16 * pp + 8 * h;
-                float v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = acc[i][j][8 * pp + k];
-                if (a.shift) {
-                    float s[8];
-                    ld8(a.shift + ch, s);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += s[k];
-                }
-                const size_t o = (size_t)m * a.Cn + ch;
-                if (res) {
-                    float rr[8];
-                    ld8(res + o, rr);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += rr[k];
-                }
-                if (a.relu) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-                }
-                if (mask) {
-                    float mm[8];
-                    ld8(mask + o, mm);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = mm[k] > 0.f ? v[k] : 0.f;
-                }
-                st8(y + o, v);
-            }
-        }
-    }
 }
 
 // Tile shape of a launch.  kind 0: 128 channels x up to 320 positions (waves 4 x 2, up to 5 position tiles per wave);
@@ -381,8 +414,9 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
 // and the waves' shares are even.  (DCF_RS_KIND / DCF_RS_NPT force a choice: experiments.)
 struct RsPlan { int kind, npt; };
 struct RsKind { int BN, WM, TMMAX, ahead, nthreads, per_cu; };
-// kinds 3 / 4: 4-wave workgroups, two per CU (<= 80 KB of LDS each), so that one workgroup's prologue and epilogue overlap the other's taps
-static const RsKind RS_KINDS[5] = {{128, 2, 5, 2, 512, 1}, {64, 4, 3, 2, 512, 1}, {64, 4, 1, 5, 512, 1}, {64, 2, 2, 2, 256, 2}, {128, 2, 2, 1, 256, 2}};
+// (4-wave workgroups, two per CU with <= 80 KB of LDS each so that one's prologue and epilogue overlap the other's taps, were
+// measured as kinds {64, 2, 2, 2, 256, 2} and {128, 2, 2, 1, 256, 2}: never ahead of these three, removed)
+static const RsKind RS_KINDS[3] = {{128, 2, 5, 2, 512, 1}, {64, 4, 3, 2, 512, 1}, {64, 4, 1, 5, 512, 1}};
 
 static RsPlan rs_plan(int64_t Q, int Cn)
 {
@@ -390,9 +424,8 @@ static RsPlan rs_plan(int64_t Q, int Cn)
     const int ncu = 256;
     RsPlan best = {-1, 0};
     double best_t = 1e30;
-    for (int kind = 0; kind < 5; ++kind) {
+    for (int kind = 0; kind < 3; ++kind) {
         const RsKind &k = RS_KINDS[kind];
-        if (kind >= 3 && !(ek && atoi(ek) == kind)) continue;      // experimental: only when forced
         if (Cn % k.BN) continue;
         if (ek && atoi(ek) != kind) continue;
         for (int npt = 1; npt <= k.WM * k.TMMAX; ++npt) {
@@ -432,7 +465,11 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
     a.xbytes = (unsigned)((int64_t)B * H * W * Ck * 2);
     a.wbytes = (unsigned)((int64_t)Cn * 9 * Ck * 2);
     const int BN = RS_KINDS[p.kind].BN;
-    const dim3 grid((((int64_t)a.mtiles * (Cn / BN) + 7) / 8) * 8);
+    // persistent workgroups: at most one per CU, each walking its XCD's share of the tile list
+    static const char *pe = getenv("DCF_RS_PERSIST");
+    int64_t nwg = (((int64_t)a.mtiles * (Cn / BN) + 7) / 8) * 8;
+    if (!(pe && atoi(pe) == 0)) nwg = std::min<int64_t>(nwg, 256 * RS_KINDS[p.kind].per_cu);
+    const dim3 grid((unsigned)nwg);
     char name[96];
     snprintf(name, sizeof(name), "%s<rs%d,%d>", name_base, p.kind, p.npt);
     const double bytes = (double)a.xbytes + (double)a.wbytes + (double)B * H * W * Cn * 2.0 * (1 + (res ? 1 : 0) + (mask ? 1 : 0));
@@ -440,9 +477,7 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
     do {                                                                                                                         \
         if (p.kind == 0) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1>), grid, dim3(512), 0, s, a)); \
         else if (p.kind == 1) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 3, 2, 4, 2, 1>), grid, dim3(512), 0, s, a)); \
-        else if (p.kind == 2) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 5, 2>), grid, dim3(512), 0, s, a)); \
-        else if (p.kind == 3) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 2, 2, 2, 2, 1>), grid, dim3(256), 0, s, a)); \
-        else DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 2, 2, 2, 2, 1, 1>), grid, dim3(256), 0, s, a));          \
+        else DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 5, 2>), grid, dim3(512), 0, s, a)); \
     } while (0)
     if (dtype == DCF_F16) DCF_RS(f16_t); else DCF_RS(bf16_t);
 #undef DCF_RS

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from conv_bench import LIDAR, IMAGE, timeit
 ops = importlib.import_module("deep_continuous_fusion_for_multi-sensor_3d_object_detection_amd.ops")
-KINDS = {0: (128, 10), 1: (64, 12), 2: (64, 4), 3: (64, 4), 4: (128, 4)}
+KINDS = {0: (128, 10), 1: (64, 12), 2: (64, 4)}
 
 
 def main():
