@@ -90,7 +90,10 @@ constexpr int rs_allowed(int kj, int dw, int dx, int pww, int pxa, int pxb)
 // Block = WN x WM waves.  Wave (wn, wm) owns channel tiles wn*TN .. +TN-1 (32 channels each) and its even share of the
 // workgroup's npt position tiles (at most TMMAX).  K order: kernel row ki, 64-channel chunk cc, then the three taps.
 // DW = taps the weight DMA runs ahead (ring of DW + 1 slots), DX = stages the pixel DMA runs ahead (DX + 1 slots).
-template <typename T, int TN, int TMMAX, int WN, int WM, int DW, int DX>
+// S3: one wait + barrier per STAGE (three taps) instead of per tap -- the small-M layers' tap steps are four MFMAs per wave,
+// shorter than the wait / barrier / issue sequence around them.  The weights then run DW = 3 DX taps ahead in a ring of
+// DW + 3 tap slots (a stage's three slots are refilled together), the pixel tile DX stages ahead as before.
+template <typename T, int TN, int TMMAX, int WN, int WM, int DW, int DX, bool S3 = false>
 __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
 {
     static_assert(DT<T>::size == 2, "16-bit element types only");
@@ -102,8 +105,10 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
     constexpr int PXW = (BMMAX + 2 + 8 * NW - 1) / (8 * NW);  // most pixel pieces a wave issues per stage
     constexpr int XROWS = NW * PXW * 8;
     constexpr int WSLOT = BN * 128, XSLOT = XROWS * 128;
-    constexpr int NSW = DW + 1, NSX = DX + 1;
+    constexpr int NSW = S3 ? DW + 3 : DW + 1, NSX = DX + 1;
     static_assert(DW >= 1 && DX >= 1 && (DW - 1) * PWW + 2 * PXW <= 48, "vmcnt range");
+    static_assert(!S3 || DW == 3 * DX, "stage-granular sync: weights and pixels run the same number of stages ahead");
+    static_assert(NSW * WSLOT + NSX * XSLOT <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(1024))) char lds[NSW * WSLOT + NSX * XSLOT];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -260,6 +265,8 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
         constexpr int DS = (2 + DW) / 3 > DX ? (2 + DW) / 3 : DX;          // stages the bookkeeping looks ahead
         constexpr int A0 = rs_allowed(0, DW, DX, PWW, PXA, PXB), A1 = rs_allowed(1, DW, DX, PWW, PXA, PXB), A2 = rs_allowed(2, DW, DX, PWW, PXA, PXB);
         static_assert(A0 < 64 && A1 < 64 && A2 < 64, "vmcnt range");
+        constexpr int AS = (DX - 1) * (3 * PWW + CX);                      // S3: pieces issued after the stage's own group
+        static_assert(AS < 64, "vmcnt range");
         // stage coordinates of stages s .. s + DS: weight offset of the stage's tap 0, pixel offset, kernel row (3 = past the end)
         int wst[DS + 1], xst[DS + 1], kis[DS + 1];
         int lki = 0, lcc = 0;
@@ -292,6 +299,14 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
         // prologue: groups -3 DX .. -1, then everything landed (the first taps need their data at once anyway)
             {
                 int wsl = 0, xsl = 0;
+                if constexpr (S3) {
+#pragma unroll
+                    for (int sv = 0; sv < DX; ++sv) {
+                        issue_x(sv, sv, 0, CX);
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) issue_w(sv, kw, sv * 3 + kw);
+                    }
+                } else
 #pragma unroll
                 for (int u = -3 * DX; u < 0; ++u) {
                     const int v = u + 3 * DX, sv = v / 3, kj = v - 3 * sv;                 // pixel tile of stage sv < DX
@@ -308,8 +323,12 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
         for (int s = 0; s < nstage; ++s) {
 #pragma unroll
             for (int kj = 0; kj < 3; ++kj) {
-                if (kj == 0) wait_vmcnt<A0>(); else if (kj == 1) wait_vmcnt<A1>(); else wait_vmcnt<A2>();
-                __builtin_amdgcn_s_barrier();
+                if constexpr (S3) {
+                    if (kj == 0) { wait_vmcnt<AS>(); __builtin_amdgcn_s_barrier(); }
+                } else {
+                    if (kj == 0) wait_vmcnt<A0>(); else if (kj == 1) wait_vmcnt<A1>(); else wait_vmcnt<A2>();
+                    __builtin_amdgcn_s_barrier();
+                }
                 // (issuing the second half-workgroup's DMA after its MFMAs instead -- waves w and w + 4 share a SIMD -- was
                 // measured: no gain, 26.7 -> 27.3 us on the 128-channel stage)
                 // The group's pieces go out one per K-quarter, between the MFMAs (DCF_RS_SPREAD): a burst of every wave's
@@ -317,6 +336,26 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
                 // matrix pipes idle.  Waves without tiles (C == 0) issue theirs at once.
                 const int xj0 = kj == 0 ? 0 : PXA, xj1 = kj == 0 ? PXA : (kj == 1 ? CX : PXA);       // kj == 2: none
                 auto issue_part = [&](int part) {
+                    if constexpr (S3) {                    // the stage's group (3 PWW weight + CX pixel pieces) over its 12 K-quarters
+                        const int q12 = kj * 4 + part;
+                        const bool okw = kis[DX] < 3 && !(a.dbg & 16);
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                            for (int j = 0; j < PWW; ++j)
+                                if ((kw * PWW + j) % 12 == q12) {
+                                    const unsigned dstw = __builtin_amdgcn_readfirstlane(ldsW0 + (wsi - kj + kw) * WSLOT + (wid * PWW + j) * 1024);
+                                    glds16(srcW, okw ? wbase[j] + (unsigned)(wst[DX] + kw * tapstep) : OOB, dstw);
+                                }
+                        const int kix = kis[DX];
+#pragma unroll
+                        for (int j = 0; j < PXW; ++j)
+                            if (j < CX && (3 * PWW + j) % 12 == q12) {
+                                const unsigned dst = __builtin_amdgcn_readfirstlane(ldsX0 + xsi * XSLOT + (wid + j * NW) * 1024);
+                                glds16(srcX, (((xok[j] >> kix) & 1) && !(a.dbg & 2)) ? (unsigned)(xbase[j] + xst[DX]) : OOB, dst);
+                            }
+                        return;
+                    }
                     const int dw = (kj + DW) / 3, kw = (kj + DW) % 3;
                     const unsigned dstw = __builtin_amdgcn_readfirstlane(ldsW0 + wsi * WSLOT + wid * PWW * 1024);
                     const bool okw = kis[dw] < 3 && !(a.dbg & 16);
@@ -333,9 +372,17 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
                         }
                 };
                 if (!DCF_RS_SPREAD || C == 0 || (a.dbg & 1)) {
-                    issue_w((kj + DW) / 3, (kj + DW) % 3, wsi);
-                    if (kj == 0) issue_x(DX, xsi, 0, PXA);
-                    if (kj == 1) issue_x(DX, xsi, PXA, CX);
+                    if constexpr (S3) {
+                        if (kj == 0) {
+                            issue_x(DX, xsi, 0, CX);
+#pragma unroll
+                            for (int kw = 0; kw < 3; ++kw) issue_w(DX, kw, wsi + kw);
+                        }
+                    } else {
+                        issue_w((kj + DW) / 3, (kj + DW) % 3, wsi);
+                        if (kj == 0) issue_x(DX, xsi, 0, PXA);
+                        if (kj == 1) issue_x(DX, xsi, PXA, CX);
+                    }
                 }
                 if constexpr (C > 0) if (!(a.dbg & 1)) {
                     const char *pw = lds + wsr * WSLOT + rdA;
@@ -473,11 +520,14 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
     char name[96];
     snprintf(name, sizeof(name), "%s<rs%d,%d>", name_base, p.kind, p.npt);
     const double bytes = (double)a.xbytes + (double)a.wbytes + (double)B * H * W * Cn * 2.0 * (1 + (res ? 1 : 0) + (mask ? 1 : 0));
+    static const char *s3e = getenv("DCF_RS_S3");
+    const bool s3 = !(s3e && atoi(s3e) == 0);
 #define DCF_RS(T_)                                                                                                               \
     do {                                                                                                                         \
         if (p.kind == 0) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1>), grid, dim3(512), 0, s, a)); \
         else if (p.kind == 1) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 3, 2, 4, 2, 1>), grid, dim3(512), 0, s, a)); \
-        else DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 5, 2>), grid, dim3(512), 0, s, a)); \
+        else if (!s3) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 5, 2>), grid, dim3(512), 0, s, a)); \
+        else DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 6, 2, true>), grid, dim3(512), 0, s, a)); \
     } while (0)
     if (dtype == DCF_F16) DCF_RS(f16_t); else DCF_RS(bf16_t);
 #undef DCF_RS

@@ -436,17 +436,9 @@ int dcf_wgrad3s_launch(int dtype, int kind, const dcf_wgs_item *items_in, int n,
             DCF_LAUNCH_WB("conv_wgrad3s_grp_bf16<" #A_ "," #B_ "," #G_ "," #NS_ ">", f, by, s,                                                    \
                           hipLaunchKernelGGL((k_conv_wgrad3s_grp<bf16_t, A_, B_, G_, NS_>), dim3(blocks), dim3(A_ * B_ * G_ * 64), 0, s, g));      \
     } while (0)
-        static const char *ve = getenv("DCF_WGS_VARIANT");       // 0: two pixel-half groups, ring of 3; 1: ring of 4; 2: one group, ring of 4
-        const int var = ve ? atoi(ve) : 0;
-        if (kind == 1) {
-            if (var == 1) DCF_WGS_GO(2, 2, 2, 4);
-            else if (var == 2) DCF_WGS_GO(2, 2, 1, 4);
-            else DCF_WGS_GO(2, 2, 2, 3);
-        } else {
-            if (var == 1) DCF_WGS_GO(3, 1, 2, 4);
-            else if (var == 2) DCF_WGS_GO(3, 1, 1, 4);
-            else DCF_WGS_GO(3, 1, 2, 3);
-        }
+        // (a ring of 4 slots, and one pixel group per workgroup with two workgroups per CU, were measured: no faster)
+        if (kind == 1) DCF_WGS_GO(2, 2, 2, 3);
+        else DCF_WGS_GO(3, 1, 2, 3);
 #undef DCF_WGS_GO
     }
     return DCF_OK;
