@@ -209,6 +209,10 @@ def rocprof_kernel(name):
     kind, _, tmpl = name.partition("<")
     t = tmpl.rstrip(">").split(",") if tmpl else []
     dt = "unsignedshort" if "bf16" in kind else ("f16_t" if "f16" in kind else "float")
+    if kind.startswith("conv_wgrad3s_grp"):
+        return "k_conv_wgrad3s_grp", [dt] + t
+    if kind.startswith("fusion_gather_bwd_inv"):
+        return None          # (the profile name carries no element type: no PMC row is matched for it)
     if kind.startswith("conv_wgrad3g_grp"):
         return "k_conv_wgrad3g_grp", [dt] + t
     if kind.startswith("conv_wgrad3g"):
@@ -218,7 +222,8 @@ def rocprof_kernel(name):
     if kind.startswith("conv_wgrad") or kind.startswith("stem_wgrad"):
         return ("k_conv_wgrad", [dt] + t) if t else None
     if t and t[0].startswith("rs"):                          # row-sharing kernel: 'conv_fwd_bf16<rs0,9>' = tile kind 0, 9 position tiles
-        return "k_conv3x3_rs", [dt] + {0: ["1", "5", "4", "2", "2", "1"], 1: ["1", "3", "2", "4", "2", "1"], 2: ["1", "1", "2", "4", "5", "2"]}[int(t[0][2:])]
+        return "k_conv3x3_rs", [dt] + {0: ["1", "5", "4", "2", "2", "1", "false"], 1: ["1", "3", "2", "4", "2", "1", "false"],
+                                       2: ["1", "1", "2", "4", "6", "2", "true"]}[int(t[0][2:])]
     if kind.startswith("conv_fwd") or kind.startswith("conv_dgrad") or kind.startswith("stem_fwd"):
         tr = "true" if "dgrad" in kind else "false"
         if t and t[-1].startswith("dma"):

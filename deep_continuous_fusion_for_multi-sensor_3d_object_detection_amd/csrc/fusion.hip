@@ -520,7 +520,8 @@ extern "C" int dcf_fusion_gather_bwd_inv(int dtype, const void *P, const float *
     static const char *cap_env = getenv("DCF_FUSION_BWD_BLOCKS");
     const int cap = cap_env ? atoi(cap_env) : 256;     // swept: 128 / 256 / 512 / uncapped = 0.52 / 0.34 / 0.36 / 0.44 ms per step
     const int blocks = std::min(cdiv(waves, FGI_THREADS / 64), cap);
-#define DCF_FGI(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_inv", (double)max_entries * (8.0 + 2.0 * Cb * sizeof(T)), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_, false>), dim3(blocks), dim3(FGI_THREADS), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, sl))
+    // (one profile name per instantiation, as rocprofv3 lists them: the four sites run four different kernels)
+#define DCF_FGI(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_inv<" #CJ_ ">", (double)max_entries * (8.0 + 2.0 * Cb * sizeof(T)), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_, false>), dim3(blocks), dim3(FGI_THREADS), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, sl))
     DCF_DISPATCH_DTYPE(dtype, {
         if (Cb == 64) DCF_FGI(1);
         else if (Cb == 128) DCF_FGI(2);
