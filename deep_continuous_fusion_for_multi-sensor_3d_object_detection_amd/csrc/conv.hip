@@ -1787,7 +1787,7 @@ extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_st
         int TM, TN, KR;
         if (it.dtype == DCF_F32) bucket[i] = -1;
         else if (it.pad == 1 && it.kh == 3 && it.kw == 3 && it.stride == 1 && dcf_wgrad3s_kind(it.dtype, it.B, it.H, it.W, it.Cin, it.Cout))
-            bucket[i] = 4 + dcf_wgrad3s_kind(it.dtype, it.B, it.H, it.W, it.Cin, it.Cout);       // 5 / 6: shared-staging kernel, quadrants 2 x 2 / 3 x 1
+            bucket[i] = 4 + dcf_wgrad3s_kind(it.dtype, it.B, it.H, it.W, it.Cin, it.Cout);       // 5: shared-staging kernel
         else if (dcf_conv2d_wgrad_groupable(it.dtype, it.B, it.H, it.W, it.Cin, it.Cout, it.kh, it.kw, it.stride, it.pad)) bucket[i] = 0;
         else if (it.pad == 1 && Ho == it.H && Wo == it.W && wgrad3_tiles(it.Cin, it.Cout, it.kh, it.kw, it.stride, TM, TN, KR)) bucket[i] = -1;
         else {
@@ -1800,7 +1800,7 @@ extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_st
             if (rc) return rc;
         }
     }
-    for (int bk = 5; bk <= 6; ++bk)
+    for (int bk = 5; bk <= 5; ++bk)
         for (int dt = DCF_BF16; dt <= DCF_F16; ++dt) {
             std::vector<dcf_wgs_item> ws;
             double flops = 0.0, bytes = 0.0;

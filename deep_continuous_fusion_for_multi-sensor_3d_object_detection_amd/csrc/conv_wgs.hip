@@ -3,8 +3,8 @@
 // The row-sharing LDS-DMA kernel of conv.hip (k_conv_wgrad3g) gives every wave its own pixel range and its own ring: a wave
 // stages a 32-pixel gy tile (4 KB) and a 34-pixel x tile (4.25 KB) for 24 MFMAs -- 93 flop per staged byte, and with the
 // ~21 B/clk a CU pulls out of its L2 into LDS its loop is half idle (0.28-0.31 of the MFMA peak).  Here the waves of a
-// workgroup are the 64 x 64 QUADRANTS of one (64 A) x (64 BC) output tile (A = BC = 2: 128 x 128 channels; A = 3, BC = 1: 192 x 64)
-// walking the SAME pixels: a stage of A gy sub-tiles + BC x sub-tiles (16.5 KB for 2 x 2, 17 KB for 3 x 1) feeds
+// workgroup are the 64 x 64 QUADRANTS of one (64 A) x (64 BC) output tile (instantiated: A = BC = 2, 128 x 128 channels)
+// walking the SAME pixels: a stage of A gy sub-tiles + BC x sub-tiles (16.5 KB for 2 x 2) feeds
 // 24 A BC MFMAs -- 190 resp. 139 flop per staged byte.  Two such groups per workgroup take the two halves of the
 // workgroup's pixel range (two waves per SIMD hide each other's waits) and meet in LDS at the end, so a workgroup still
 // writes ONE fp32 slab tile; with the layers of a backward pass issued in grouped launches a layer does not have to fill
@@ -353,17 +353,16 @@ __global__ void __launch_bounds__(A * BC * G * 64) k_conv_wgrad3s_grp(WsGroup g)
 }  // namespace
 
 // ---- host side (called from conv.hip)
-// kind: 0 = not this kernel's; 1 = quadrants 2 x 2 (128 x 128 output tiles: channel counts multiples of 128); 2 = quadrants 3 x 1
-// (192 x 64 tiles, 192-channel layers: nine quadrant waves in one workgroup would be three per SIMD, i.e. 170 registers each)
+// kind: 0 = not this kernel's; 1 = quadrants 2 x 2 (128 x 128 output tiles: channel counts multiples of 128)
 int dcf_wgrad3s_kind(int dtype, int B, int H, int W, int Cin, int Cout)
 {
     static const char *e = getenv("DCF_WGRAD3S");
     if (e && atoi(e) == 0) return 0;
     if (dtype == DCF_F32 || W + 2 < 40) return 0;
     if ((int64_t)B * H * W * Cin * 2 >= (1ll << 31) || (int64_t)B * H * W * Cout * 2 >= (1ll << 31)) return 0;
-    if (Cin % 128 == 0 && Cout % 128 == 0) return 1;
-    if (Cin == 192 && Cout == 192) return 2;
-    return 0;
+    // (a 192 x 64 tile of 3 x 1 quadrants for the 192-channel layers was built and measured: six waves on four SIMDs, 560-700
+    // TFLOP/s in the grouped launch against 680-750 for k_conv_wgrad3g on the same layers -- removed)
+    return (Cin % 128 == 0 && Cout % 128 == 0) ? 1 : 0;
 }
 
 // pixel ranges (= slabs) of a layer: a workgroup should walk >= ~2048 padded positions (64 stages shared by its two groups), and a
@@ -437,8 +436,7 @@ int dcf_wgrad3s_launch(int dtype, int kind, const dcf_wgs_item *items_in, int n,
                           hipLaunchKernelGGL((k_conv_wgrad3s_grp<bf16_t, A_, B_, G_, NS_>), dim3(blocks), dim3(A_ * B_ * G_ * 64), 0, s, g));      \
     } while (0)
         // (a ring of 4 slots, and one pixel group per workgroup with two workgroups per CU, were measured: no faster)
-        if (kind == 1) DCF_WGS_GO(2, 2, 2, 3);
-        else DCF_WGS_GO(3, 1, 2, 3);
+        DCF_WGS_GO(2, 2, 2, 3);
 #undef DCF_WGS_GO
     }
     return DCF_OK;
