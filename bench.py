@@ -171,7 +171,16 @@ def roofline_leg(trainer, pool, B, steps):
         return tf, gb, bound, (fm if bound == "mfma" else fh)
 
     table = sorted(((n, v[0], v[1], v[2], v[3]) for n, v in prof.items()), key=lambda t: -t[1])
-    name, ms, calls, work, byts = table[0]                 # dominant kernel by GPU time
+    # The dominant kernel is the GPU FUNCTION with the most time, as rocprofv3's kernel stats count it: launch names that
+    # differ only in run-time arguments (the row-sharing convolution's position tiles per workgroup; forward / input
+    # gradient = the same function on two weight images) are one row there, so they are summed here too.
+    groups = {}
+    for n, m, c, w, by in table:
+        rk = rocprof_kernel(n)
+        key = "%s<%s>" % (rk[0], ",".join(rk[1])) if rk else n
+        g = groups.setdefault(key, [n, 0.0, 0, 0.0, 0.0, []])
+        g[1] += m; g[2] += c; g[3] += w; g[4] += by; g[5].append(n)
+    symbol, (name, ms, calls, work, byts, members) = max(groups.items(), key=lambda kv: kv[1][1])
     tf, gb, bound, frac = rates(name, ms, work, byts)
     if bound == "hbm":
         roof = {"kernel": name, "bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac, 4), "traffic": None}
@@ -183,6 +192,8 @@ def roofline_leg(trainer, pool, B, steps):
                  "algorithmic_bytes_per_launch": round(byts / max(calls, 1)) if byts else None,
                  "gpu_ms_per_step_all_kernels": round(total_ms / steps, 3), "event_bracket_us_subtracted": round(bracket_ms * 1e3, 2)})
     roof["traffic"], roof["traffic_source"], roof["traffic_stale"] = pmc_traffic(name)
+    roof["kernel"] = symbol
+    roof["launch_names"] = members
     breakdown = []
     for n, m, c, w, by in table[:48]:
         tf, gb, bound, frac = rates(n, m, w, by)
