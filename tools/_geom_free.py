@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Upper bound of what faster geometry kernels could buy: the cfg2 step with the side-stream geometry computed every step
+(as shipped) against the same step re-using a cached geometry (experiment only)."""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+train = bench.pkg("train")
+cfg = bench.kitti_config(2, "bf16", 100000, 3, "resnet18", (1242, 375))
+cfg["bn_mode"] = "eval"
+torch.cuda.set_device(0)
+trainer = train.Train(cfg)
+bench.pkg("detfill").fill_state_dict(trainer.model)
+pool = bench.FramePool(cfg, n_frames=4, n_points=100000, seed0=0)
+cache = {}
+def step(s, cached):
+    ids = pool.batch(s, 2)
+    if cached:
+        key = tuple(ids)
+        if key not in cache:
+            cache[key] = trainer.geometry_async(pool.geometry, [pool.pts[i] for i in ids])
+            cache[key][1].pop("_set", None)
+        x_lidar, geom = cache[key]
+    else:
+        x_lidar, geom = trainer.geometry_async(pool.geometry, [pool.pts[i] for i in ids])
+    boxes = torch.stack([pool.boxes[i] for i in ids], 0)
+    nb = torch.tensor([pool.nb[i] for i in ids])
+    trainer.one_step(x_lidar, pool.image_batch(ids), boxes, nb, geom=geom)
+for cached in (False, True, False, True):
+    for s in range(8):
+        step(s, cached)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for s in range(40):
+        step(8 + s, cached)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 40
+    print("cached geometry" if cached else "geometry per step", "%.3f ms/step" % (dt * 1e3), flush=True)
