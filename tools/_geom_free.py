@@ -27,6 +27,24 @@ def step(s, cached):
     boxes = torch.stack([pool.boxes[i] for i in ids], 0)
     nb = torch.tensor([pool.nb[i] for i in ids])
     trainer.one_step(x_lidar, pool.image_batch(ids), boxes, nb, geom=geom)
+def run_prefetch(n0, n):
+    """geometry of step s + 1 issued before step s is enqueued (runs beside step s on the side stream)"""
+    ids = pool.batch(n0, 2)
+    cur = trainer.geometry_async(pool.geometry, [pool.pts[i] for i in ids])
+    for s in range(n0, n0 + n):
+        ids = pool.batch(s, 2)
+        nxt_ids = pool.batch(s + 1, 2)
+        nxt = trainer.geometry_async(pool.geometry, [pool.pts[i] for i in nxt_ids])
+        boxes = torch.stack([pool.boxes[i] for i in ids], 0)
+        nb = torch.tensor([pool.nb[i] for i in ids])
+        trainer.one_step(cur[0], pool.image_batch(ids), boxes, nb, geom=cur[1])
+        cur = nxt
+for rep in range(2):
+    run_prefetch(0, 8)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    run_prefetch(8, 40)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 40
+    print("geometry one step ahead %.3f ms/step" % (dt * 1e3), flush=True)
 for cached in (False, True, False, True):
     for s in range(8):
         step(s, cached)
