@@ -48,9 +48,42 @@ struct RsArgs {
     int npt;              // 32-position tiles per workgroup
     int mtiles;           // position tiles of the launch
     int Q;                // padded positions B*H*(W+2)
-    unsigned xbytes, wbytes;
+    unsigned xbytes, wbytes, ybytes;
     int dbg;              // experiments (DCF_RS_DBG, tools/rs_ablate.py): 1 no MFMAs, 2 pixel DMA reads nothing, 4 no epilogue, 16 weight DMA reads nothing
 };
+
+// One output store: 64 lanes x 16 B through a buffer descriptor; a lane whose offset is out of range stores nothing.
+// UNCONDITIONAL (padding lanes get an out-of-range offset instead of a branch): the number of store instructions a wave
+// issues per tile is then a compile-time constant, which the counted vmcnt waits of the next tile's first steps need -- stores
+// count in vmcnt, in issue order, with the DMA pieces (MI355X_MICROARCH.md), and they are left in flight under those steps.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gst16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, uint4 data)
+{
+    // the compiler's own buffer-store intrinsic, not inline asm: its hazard recogniser then keeps later writes of the data
+    // registers away from the store (an asm store followed by `s_nop` was not enough once ten of them went out back to back)
+    const u32x4 d = {data.x, data.y, data.z, data.w};
+    __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, (int)voff, 0, 0);
+}
+// A stand-in for a store where a tile has none to issue (the first tile of a workgroup, debug runs): out of range, so nothing is
+// written, but it counts in vmcnt like a real one.  Inline asm: ten identical intrinsic stores would be merged into one.
+__device__ __forceinline__ void gst16_dummy(__amdgpu_buffer_rsrc_t rsrc)
+{
+    const u32x4 d = {0u, 0u, 0u, 0u};
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(d), "v"(0xFFFFFF00u), "s"(rsrc) : "memory");
+}
+template <typename T> __device__ __forceinline__ uint4 pack8(const float (&v)[8]);
+template <> __device__ __forceinline__ uint4 pack8<bf16_t>(const float (&v)[8])
+{
+    return make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+}
+template <> __device__ __forceinline__ uint4 pack8<f16_t>(const float (&v)[8])
+{
+    typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+    h16x8 h;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) h[k] = (_Float16)v[k];
+    return __builtin_bit_cast(uint4, h);
+}
 
 // s_waitcnt vmcnt(n) for a wave-uniform runtime n (the immediate must be a constant: one scalar branch)
 __device__ __forceinline__ void wait_vmcnt_dyn(int n)
@@ -144,6 +177,7 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
 
     const __amdgpu_buffer_rsrc_t srcX = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t srcW = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dstY = __builtin_amdgcn_make_buffer_rsrc((void *)a.y, 0, a.ybytes, 0x00020000);
     constexpr unsigned OOB = 0xFFFFFF00u;
     const unsigned ldsW0 = lds_addr(lds), ldsX0 = ldsW0 + NSW * WSLOT;
 
@@ -197,56 +231,117 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
     const int tapstep = a.flip ? -rowbytes : rowbytes;
 
     // ---- epilogue of one tile (as k_conv_igemm): v = acc + shift + res ; relu ; v *= (mask > 0) ; 8 consecutive channels per access
-    T *y = reinterpret_cast<T *>(a.y);
     const T *res = reinterpret_cast<const T *>(a.res);
     const T *mask = reinterpret_cast<const T *>(a.mask);
     auto store_tile = [&](int q0c, int n0c) __attribute__((always_inline)) {
-        if (a.dbg & 4) return;
+        // exactly cnt x TN x 2 store instructions per wave, whatever the tile (see gst16)
+        if (a.dbg & 4) {
+#pragma unroll
+            for (int j = 0; j < TMMAX; ++j)
+                if (j < cnt)
+#pragma unroll
+                    for (int k = 0; k < TN * 2; ++k) gst16_dummy(dstY);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int j = 0; j < TMMAX; ++j) acc_rows8(acc[i][j]);
+        // Two rounds of independent loads instead of one dependent load per store (behind an asm store -- a compiler barrier --
+        // each would pay its own latency): every residual vector of the wave's tiles, folded into the accumulators with the
+        // shift and the ReLU; then every mask vector; then the stores.
+        int mrow[TMMAX];
+        bool valid[TMMAX];
+#pragma unroll
+        for (int j = 0; j < TMMAX; ++j) {
+            const int p = q0c + (pt0 + j) * 32 + r;
+            const int R = p / Wp, c = p - R * Wp;
+            valid[j] = (j < cnt) && !(p >= a.Q || c < 1 || c > a.W);      // padding position: no output
+            mrow[j] = R * a.W + c - 1;
+        }
+        auto voff = [&](int j, int i, int pp) { return (size_t)mrow[j] * a.Cn + n0c + (wn * TN + i) * 32 + 16 * pp + 8 * h; };
+        if (res) {
+            uint4 rr[TMMAX][TN][2];
+#pragma unroll
+            for (int j = 0; j < TMMAX; ++j)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
+                        rr[j][i][pp] = valid[j] ? *reinterpret_cast<const uint4 *>(res + voff(j, i, pp)) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TMMAX; ++j)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        const unsigned rw[4] = {rr[j][i][pp].x, rr[j][i][pp].y, rr[j][i][pp].z, rr[j][i][pp].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float lo, hi;
+                            unpack2<T>(rw[e], lo, hi);
+                            acc[i][j][8 * pp + 2 * e] += lo; acc[i][j][8 * pp + 2 * e + 1] += hi;
+                        }
+                    }
+        }
+        if (a.shift) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    float sh[8];
+                    ld8(a.shift + n0c + (wn * TN + i) * 32 + 16 * pp + 8 * h, sh);
+#pragma unroll
+                    for (int j = 0; j < TMMAX; ++j)
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) acc[i][j][8 * pp + k] += sh[k];
+                }
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TMMAX; ++j)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[i][j][k] = fmaxf(acc[i][j][k], 0.f);
+        }
+        if (mask) {
+            uint4 mm[TMMAX][TN][2];
+#pragma unroll
+            for (int j = 0; j < TMMAX; ++j)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
+                        mm[j][i][pp] = valid[j] ? *reinterpret_cast<const uint4 *>(mask + voff(j, i, pp)) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TMMAX; ++j)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        const unsigned mw[4] = {mm[j][i][pp].x, mm[j][i][pp].y, mm[j][i][pp].z, mm[j][i][pp].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float lo, hi;
+                            unpack2<T>(mw[e], lo, hi);
+                            if (!(lo > 0.f)) acc[i][j][8 * pp + 2 * e] = 0.f;
+                            if (!(hi > 0.f)) acc[i][j][8 * pp + 2 * e + 1] = 0.f;
+                        }
+                    }
+        }
 #pragma unroll
         for (int j = 0; j < TMMAX; ++j) {
             if (j >= cnt) continue;
-            const int p = q0c + (pt0 + j) * 32 + r;
-            const int R = p / Wp, c = p - R * Wp;
-            if (p >= a.Q || c < 1 || c > a.W) continue;      // padding position: no output
-            const int m = R * a.W + c - 1;
 #pragma unroll
-            for (int i = 0; i < TN; ++i) {
+            for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int pp = 0; pp < 2; ++pp) {
-                    const int ch = n0c + (wn * TN + i) * 32 + 16 * pp + 8 * h;
                     float v[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = acc[i][j][8 * pp + k];
-                    if (a.shift) {
-                        float sh[8];
-                        ld8(a.shift + ch, sh);
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) v[k] += sh[k];
-                    }
-                    const size_t o = (size_t)m * a.Cn + ch;
-                    if (res) {
-                        float rr[8];
-                        ld8(res + o, rr);
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) v[k] += rr[k];
-                    }
-                    if (a.relu) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-                    }
-                    if (mask) {
-                        float mm[8];
-                        ld8(mask + o, mm);
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) v[k] = mm[k] > 0.f ? v[k] : 0.f;
-                    }
-                    st8(y + o, v);
+                    gst16(dstY, valid[j] ? (unsigned)(voff(j, i, pp) * sizeof(T)) : OOB, pack8<T>(v));
                 }
-            }
         }
     };
 
@@ -266,7 +361,11 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
         constexpr int A0 = rs_allowed(0, DW, DX, PWW, PXA, PXB), A1 = rs_allowed(1, DW, DX, PWW, PXA, PXB), A2 = rs_allowed(2, DW, DX, PWW, PXA, PXB);
         static_assert(A0 < 64 && A1 < 64 && A2 < 64, "vmcnt range");
         constexpr int AS = (DX - 1) * (3 * PWW + CX);                      // S3: pieces issued after the stage's own group
-        static_assert(AS < 64, "vmcnt range");
+        // The previous tile's stores (the first tile: as many dummy ones) are issued after the tile's first groups and are left in
+        // flight: a step that depends on one of those first groups may leave them outstanding too.
+        constexpr int ST = C * TN * 2;
+        constexpr int BK0 = (3 * DX - 1 < DW) ? 3 * DX - 1 : DW;            // groups back a tap-0 step depends on (rs_allowed)
+        static_assert(AS + ST < 64 && A0 + ST < 64 && A1 + ST < 64 && A2 + ST < 64, "vmcnt range");
         // stage coordinates of stages s .. s + DS: weight offset of the stage's tap 0, pixel offset, kernel row (3 = past the end)
         int wst[DS + 1], xst[DS + 1], kis[DS + 1];
         int lki = 0, lcc = 0;
@@ -317,16 +416,23 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
             }
         };
         begin_tile();
+#pragma unroll
+        for (int k = 0; k < ST; ++k) gst16_dummy(dstY);      // stand-ins for a previous tile's stores
         for (;;) {
-        wait_vmcnt<0>();              // the tile's first groups have landed (and the previous tile's stores are out)
         int wsr = 0, wsi = DW % NSW, xsr = 0, xsi = DX % NSX;         // ring slots: read / issue
         for (int s = 0; s < nstage; ++s) {
 #pragma unroll
             for (int kj = 0; kj < 3; ++kj) {
                 if constexpr (S3) {
-                    if (kj == 0) { wait_vmcnt<AS>(); __builtin_amdgcn_s_barrier(); }
+                    if (kj == 0) {
+                        if (s < DX) wait_vmcnt<AS + ST>(); else wait_vmcnt<AS>();
+                        __builtin_amdgcn_s_barrier();
+                    }
                 } else {
-                    if (kj == 0) wait_vmcnt<A0>(); else if (kj == 1) wait_vmcnt<A1>(); else wait_vmcnt<A2>();
+                    const bool early = 3 * s + kj < (kj == 0 ? BK0 : DW);       // the group this step needs went out before the stores
+                    if (kj == 0) { if (early) wait_vmcnt<A0 + ST>(); else wait_vmcnt<A0>(); }
+                    else if (kj == 1) { if (early) wait_vmcnt<A1 + ST>(); else wait_vmcnt<A1>(); }
+                    else { if (early) wait_vmcnt<A2 + ST>(); else wait_vmcnt<A2>(); }
                     __builtin_amdgcn_s_barrier();
                 }
                 // (issuing the second half-workgroup's DMA after its MFMAs instead -- waves w and w + 4 share a SIMD -- was
@@ -511,6 +617,7 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
     a.mtiles = (int)((Q + 32 * p.npt - 1) / (32 * p.npt));
     a.xbytes = (unsigned)((int64_t)B * H * W * Ck * 2);
     a.wbytes = (unsigned)((int64_t)Cn * 9 * Ck * 2);
+    a.ybytes = (unsigned)((int64_t)B * H * W * Cn * 2);
     const int BN = RS_KINDS[p.kind].BN;
     // persistent workgroups: at most one per CU, each walking its XCD's share of the tile list
     static const char *pe = getenv("DCF_RS_PERSIST");

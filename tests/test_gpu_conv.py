@@ -29,6 +29,11 @@ SHAPES = [
     (1, 20, 46, 32, 64, 3, 1),       # 64 x 32 tile
     (2, 5, 61, 64, 32, 3, 1),        # 32 x 64 tile
     (3, 33, 75, 64, 64, 3, 1),       # many stages per wave, ranges crossing image boundaries
+    # row-sharing forward / dgrad kernel at awkward sizes: tail tiles with whole waves out of range (their stores are issued
+    # all the same: the next tile's counted waits rely on the count), odd widths, three frames
+    (2, 37, 61, 64, 64, 3, 1),
+    (1, 75, 83, 128, 128, 3, 1),
+    (3, 41, 43, 192, 128, 3, 1),
     # shared-staging weight-gradient kernel: 128-multiple channels (2 x 2 quadrants) and 192 x 192 (3 x 1)
     (2, 9, 44, 128, 128, 3, 1),
     (3, 21, 41, 256, 128, 3, 1),     # two input-channel tiles; pixel ranges crossing frames
@@ -219,6 +224,8 @@ BIG_SHAPES = [
     (1, 353, 399, 128, 192, 3, 2),   # stride 2, odd sizes: unequal parity classes; 192 = 64-channel tiles
     (2, 176, 200, 192, 192, 3, 1),   # conv3 / FPN shape: 192 channels -> 64 ch x 128 px tiles, batch boundary inside tiles
     (1, 352, 400, 128, 192, 1, 1),   # 1x1 (latconv2 shape), 128 -> 192
+    (1, 301, 397, 64, 64, 3, 1),     # row-sharing kernel, persistent workgroups over three rounds of tiles, odd sizes
+    (2, 203, 199, 128, 128, 3, 1),   # same on the 128-channel kind (five / four position tiles per wave)
 ]
 
 
