@@ -286,45 +286,10 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
     for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc_rows8(acc[i][j]);
+    int mpix[TM];
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int m = out_pixel(m0 + (wm * TM + j) * 32 + r);
-        if (m < 0) continue;
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int c = n0 + (wn * TN + i) * 32 + 16 * p + 8 * h;
-                float v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = acc[i][j][8 * p + k];
-                if (a.shift) {
-                    float s[8];
-                    ld8(a.shift + c, s);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += s[k];
-                }
-                const size_t o = (size_t)m * a.Cn + c;
-                if (res) {
-                    float rr[8];
-                    ld8(res + o, rr);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += rr[k];
-                }
-                if (a.relu) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-                }
-                if (mask) {
-                    float mm[8];
-                    ld8(mask + o, mm);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = mm[k] > 0.f ? v[k] : 0.f;
-                }
-                st8(y + o, v);
-            }
-        }
-    }
+    for (int j = 0; j < TM; ++j) mpix[j] = out_pixel(m0 + (wm * TM + j) * 32 + r);
+    conv_epilogue_phases<T, TN, TM>(acc, mpix, n0 + wn * TN * 32 + 8 * h, a.Cn, a.shift, res, mask, a.relu, y);
     DCF_STAMP(4);
     DCF_WEND();
 }
@@ -523,45 +488,10 @@ __global__ void __launch_bounds__(256) k_conv_igemm_dma(ConvArgs a)
     for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc_rows8(acc[i][j]);
+    int mpix[TM];
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int m = out_pixel(m0 + (wm * TM + j) * 32 + r);
-        if (m < 0) continue;
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int c = n0 + (wn * TN + i) * 32 + 16 * p + 8 * h;
-                float v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = acc[i][j][8 * p + k];
-                if (a.shift) {
-                    float s[8];
-                    ld8(a.shift + c, s);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += s[k];
-                }
-                const size_t o = (size_t)m * a.Cn + c;
-                if (res) {
-                    float rr[8];
-                    ld8(res + o, rr);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += rr[k];
-                }
-                if (a.relu) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-                }
-                if (mask) {
-                    float mm[8];
-                    ld8(mask + o, mm);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = mm[k] > 0.f ? v[k] : 0.f;
-                }
-                st8(y + o, v);
-            }
-        }
-    }
+    for (int j = 0; j < TM; ++j) mpix[j] = out_pixel(m0 + (wm * TM + j) * 32 + r);
+    conv_epilogue_phases<T, TN, TM>(acc, mpix, n0 + wn * TN * 32 + 8 * h, a.Cn, a.shift, res, mask, a.relu, y);
     DCF_STAMP(4);
     DCF_WEND();
 }

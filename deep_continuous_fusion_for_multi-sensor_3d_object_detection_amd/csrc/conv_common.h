@@ -60,4 +60,76 @@ template <> struct Mma<float> {
     }
 };
 
+// Epilogue of the implicit-GEMM kernels: v = acc + shift + res ; relu ; v *= (mask > 0), 8 consecutive channels per access
+// (after acc_rows8).  Phases instead of one load-compute-store chain per vector: every residual vector of the wave's tiles
+// is folded into the accumulators first, then the shift and the ReLU, then every mask vector, then the stores -- loads of a
+// phase are independent of each other (behind a store that may alias them, each used to pay its own latency).
+// m[j] = output pixel of this lane in position tile j, or < 0; channel of (i, p) = c0 + 32 i + 16 p.
+template <typename T, int TN, int TM>
+__device__ __forceinline__ void conv_epilogue_phases(f32x16 (&acc)[TN][TM], const int (&m)[TM], int c0, int Cn, const float *shift,
+                                                     const T *res, const T *mask, int relu, T *y)
+{
+    if (res) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    if (m[j] >= 0) {
+                        float rr[8];
+                        ld8(res + (size_t)m[j] * Cn + c0 + i * 32 + 16 * p, rr);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) acc[i][j][8 * p + k] += rr[k];
+                    }
+    }
+    if (shift) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float sh[8];
+                ld8(shift + c0 + i * 32 + 16 * p, sh);
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[i][j][8 * p + k] += sh[k];
+            }
+    }
+    if (relu) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[i][j][k] = fmaxf(acc[i][j][k], 0.f);
+    }
+    if (mask) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    if (m[j] >= 0) {
+                        float mm[8];
+                        ld8(mask + (size_t)m[j] * Cn + c0 + i * 32 + 16 * p, mm);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) acc[i][j][8 * p + k] = mm[k] > 0.f ? acc[i][j][8 * p + k] : 0.f;
+                    }
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                if (m[j] >= 0) {
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = acc[i][j][8 * p + k];
+                    st8(y + (size_t)m[j] * Cn + c0 + i * 32 + 16 * p, v);
+                }
+}
+
 }  // namespace
