@@ -6,6 +6,6 @@ for f in "$@"; do
     touch $CS/conv_rs.hip
     make -s -C $CS "CXXFLAGS=--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function $f" > /dev/null 2>&1 || { echo build failed; exit 1; }
     echo "== $f"
-    python tools/conv_bench.py 2>&1 | grep -E "^(l3|l4|l5|conv3|l2|i1|i2|i3|i4) |totals"
-    python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-from-host --no-roofline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+    for r in 1 2 3; do python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-from-host --no-roofline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; done
+    python bench.py --batch 8 --steps 20 --warmup 5 --no-cpu-baseline --no-from-host --no-roofline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('b8', d['value'], d['ms_per_step'])"
 done
