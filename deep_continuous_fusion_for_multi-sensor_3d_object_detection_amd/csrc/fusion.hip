@@ -302,7 +302,7 @@ constexpr int FGI_THREADS = 1024;
 // of an fp32 accumulator before, no float atomics, no cast kernel after.  e_begin then points at start[0] of the map, SL is
 // the number of point rows.
 template <typename T, int CJ, bool EXCL>
-__global__ void __launch_bounds__(FGI_THREADS) k_fusion_gather_bwd_inv(const T *__restrict__ P, const float *__restrict__ xyz, const int *__restrict__ e_begin, const int *__restrict__ e_end,
+__global__ void __launch_bounds__(CJ >= 4 ? FGI_THREADS / 2 : FGI_THREADS) k_fusion_gather_bwd_inv(const T *__restrict__ P, const float *__restrict__ xyz, const int *__restrict__ e_begin, const int *__restrict__ e_end,
                                                                const int *__restrict__ ent_pix, const int *__restrict__ ent_pt, FuseGeom g,
                                                                const float *__restrict__ w1d, const float *__restrict__ b1, int C,
                                                                const T *__restrict__ ghsum, void *gPv, float *gw1d, float *gb1, int SL)
@@ -314,8 +314,8 @@ __global__ void __launch_bounds__(FGI_THREADS) k_fusion_gather_bwd_inv(const T *
     for (int i = threadIdx.x; i < C * 4; i += blockDim.x) sm[i] = 0.f;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (FGI_THREADS / 64) + (threadIdx.x >> 6));
-    const int nwaves = gridDim.x * (FGI_THREADS / 64);   // the grid is capped: a wave takes slices wave, wave + nwaves, ...
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int nwaves = gridDim.x * (blockDim.x >> 6);   // the grid is capped: a wave takes slices wave, wave + nwaves, ...
     const int PP = EXCL ? (SL + nwaves - 1) / nwaves : 0;       // points per wave
     const int xp0 = wave * PP, xp1 = min(xp0 + PP, SL);
     const int E0 = EXCL ? (xp0 < xp1 ? e_begin[xp0] : 0) : *e_begin, E = EXCL ? (xp0 < xp1 ? e_begin[xp1] : 0) : *e_end;
@@ -519,9 +519,11 @@ extern "C" int dcf_fusion_gather_bwd_inv(int dtype, const void *P, const float *
     const int waves = cdiv(max_entries, sl);
     static const char *cap_env = getenv("DCF_FUSION_BWD_BLOCKS");
     const int cap = cap_env ? atoi(cap_env) : 256;     // swept: 128 / 256 / 512 / uncapped = 0.52 / 0.34 / 0.36 / 0.44 ms per step
-    const int blocks = std::min(cdiv(waves, FGI_THREADS / 64), cap);
+    // (256 channels: 4 accumulator sets per lane do not fit the 128 registers of a 1024-thread block -- 512 threads there)
+    const int thr = Cb >= 256 ? FGI_THREADS / 2 : FGI_THREADS;
+    const int blocks = std::min(cdiv(waves, thr / 64), cap);
     // (one profile name per instantiation, as rocprofv3 lists them: the four sites run four different kernels)
-#define DCF_FGI(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_inv<" #CJ_ ">", (double)max_entries * (8.0 + 2.0 * Cb * sizeof(T)), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_, false>), dim3(blocks), dim3(FGI_THREADS), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, sl))
+#define DCF_FGI(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_inv<" #CJ_ ">", (double)max_entries * (8.0 + 2.0 * Cb * sizeof(T)), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_, false>), dim3(blocks), dim3(thr), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, sl))
     DCF_DISPATCH_DTYPE(dtype, {
         if (Cb == 64) DCF_FGI(1);
         else if (Cb == 128) DCF_FGI(2);
@@ -548,8 +550,9 @@ extern "C" int dcf_fusion_gather_bwd_pts(int dtype, const void *P, const float *
     hipStream_t s = S(stream);
     static const char *cap_env = getenv("DCF_FUSION_BWD_BLOCKS");
     const int cap = cap_env ? atoi(cap_env) : 256;
-    const int blocks = std::min(cdiv(n_rows, FGI_THREADS / 64), cap);
-#define DCF_FGP(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_pts", (double)max_entries * (8.0 + 2.0 * Cb * sizeof(T)) + (double)n_rows * Cb * sizeof(T), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_, true>), dim3(blocks), dim3(FGI_THREADS), sizeof(float) * Cb * 4, s, (const T *)P, xyz, start, start, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, n_rows))
+    const int thr = Cb >= 256 ? FGI_THREADS / 2 : FGI_THREADS;
+    const int blocks = std::min(cdiv(n_rows, thr / 64), cap);
+#define DCF_FGP(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_pts", (double)max_entries * (8.0 + 2.0 * Cb * sizeof(T)) + (double)n_rows * Cb * sizeof(T), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_, true>), dim3(blocks), dim3(thr), sizeof(float) * Cb * 4, s, (const T *)P, xyz, start, start, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, n_rows))
     DCF_DISPATCH_DTYPE(dtype, {
         if (Cb == 64) DCF_FGP(1);
         else if (Cb == 128) DCF_FGP(2);
