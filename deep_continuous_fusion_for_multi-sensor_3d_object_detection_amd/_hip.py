@@ -26,6 +26,7 @@ P = c_void_p
 SIGNATURES = {
     "dcf_last_error": (ctypes.c_char_p, []),
     "dcf_version": (c_int, []),
+    "dcf_set_option": (c_int, [ctypes.c_char_p, ctypes.c_char_p]),
     "dcf_prof_enable": (c_int, [c_int]),
     "dcf_prof_reset": (c_int, []),
     "dcf_prof_calibrate": (c_int, [P, c_int]),
@@ -179,6 +180,14 @@ def call(name, *args):
     if fn.restype is c_int and rc != 0 and name not in ("dcf_version", "dcf_conv2d_wgrad_splits", "dcf_prof_read", "dcf_conv2d_wgrad_groupable"):
         raise DcfError("%s failed (%d): %s" % (name, rc, L.dcf_last_error().decode()))
     return rc
+
+
+def set_option(name, value):
+    """Tuning option of the library (dcf_set_option): which kernel / tile shape a launch takes, never its result.
+    value None = unset (back to the built-in choice)."""
+    rc = lib().dcf_set_option(name.encode(), None if value is None else str(value).encode())
+    if rc != 0:
+        raise DcfError("dcf_set_option(%r) failed: %s" % (name, lib().dcf_last_error().decode()))
 
 
 def dtype_code(dt):

@@ -168,6 +168,7 @@ class HipBackend(object):
         else:
             self.grads.zero_()
         self._wq = []                      # weight gradients collected by a backward that did not finish are dropped
+        self.__dict__.pop("_done", None)   # ... and so is its half-finished bucket state (a backward that raised after bucket_ready)
 
     # Gradient buckets (data parallel): the layer table is ordered LiDAR stream | camera stream | fusion layers, and so is
     # the parameter arena.  With a hook installed (train.Train, world size > 1) the backward finalises the LiDAR + fusion

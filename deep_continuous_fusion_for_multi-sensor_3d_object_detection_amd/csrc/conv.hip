@@ -57,11 +57,11 @@ struct ConvArgs {
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
 __device__ long long g_dcf_dbg_t[8];     // DCF_WGRAD3_DBG / DCF_IGEMM_DBG & 2: phase timestamps (s_memtime) of workgroup 0, wave 0
-#define DCF_STAMP(i) do { if ((a.dbg & 2) && blockIdx.x == 0 && threadIdx.x == 0) g_dcf_dbg_t[i] = clock64(); } while (0)
+#define DCF_STAMP(i) do { if ((DCF_DBG(a) & 2) && blockIdx.x == 0 && threadIdx.x == 0) g_dcf_dbg_t[i] = clock64(); } while (0)
 // DBG & 4: first start / last end over ALL workgroups on the 100 MHz wall clock, plus the sum of workgroup lifetimes
 __device__ unsigned long long g_dcf_dbg_w[4];
-#define DCF_WSTART() long long w_start__ = 0; do { if ((a.dbg & 4) && threadIdx.x == 0) { w_start__ = wall_clock64(); atomicMin(&g_dcf_dbg_w[0], (unsigned long long)w_start__); } } while (0)
-#define DCF_WEND() do { if ((a.dbg & 4) && threadIdx.x == 0) { const long long e__ = wall_clock64(); atomicMax(&g_dcf_dbg_w[1], (unsigned long long)e__); atomicAdd(&g_dcf_dbg_w[2], (unsigned long long)(e__ - w_start__)); atomicMax(&g_dcf_dbg_w[3], (unsigned long long)(e__ - w_start__)); } } while (0)
+#define DCF_WSTART() long long w_start__ = 0; do { if ((DCF_DBG(a) & 4) && threadIdx.x == 0) { w_start__ = wall_clock64(); atomicMin(&g_dcf_dbg_w[0], (unsigned long long)w_start__); } } while (0)
+#define DCF_WEND() do { if ((DCF_DBG(a) & 4) && threadIdx.x == 0) { const long long e__ = wall_clock64(); atomicMax(&g_dcf_dbg_w[1], (unsigned long long)e__); atomicAdd(&g_dcf_dbg_w[2], (unsigned long long)(e__ - w_start__)); atomicMax(&g_dcf_dbg_w[3], (unsigned long long)(e__ - w_start__)); } } while (0)
 
 // ------------------------------------------------------------------------------------
 // forward / dgrad kernel.  Block = 256 threads = WN x WM waves; wave tile TN*32 output
@@ -510,8 +510,7 @@ int launch_igemm(const ConvArgs &a_in, hipStream_t s, const char *base, double f
     do {                                                                                                            \
         constexpr int BN_ = WN_ * TN_ * 32, BM_ = WM_ * TM_ * 32;                                                   \
         ConvArgs a = a_in;                                                                                          \
-        static const char *dbg_env = getenv("DCF_IGEMM_DBG");                                                       \
-        a.dbg = dbg_env ? atoi(dbg_env) : 0;                                                                        \
+                a.dbg = dcf_ablate_opt("IGEMM_DBG");                                                                        \
         int mtiles = cdiv(a.M, BM_);                                                                                \
         if (a.parity) {   /* tile list = (region, class) with the class fastest; every class gets the largest class's count */ \
             int mx = 0;                                                                                             \
@@ -521,12 +520,12 @@ int launch_igemm(const ConvArgs &a_in, hipStream_t s, const char *base, double f
         dim3 grid((((int64_t)mtiles * (a.Cn / BN_) + 7) / 8) * 8);                                                  \
         const bool db = (int64_t)mtiles * (a.Cn / BN_) <= 512;   /* <= 2 workgroups per CU: 1-barrier pipeline */   \
         snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d%s>", base, KB_, TN_, TM_, WN_, WM_, db ? ",db" : "");        \
-        if (a.dbg & 4) {                                                                                            \
+        if (DCF_DBG(a) & 4) {                                                                                            \
             unsigned long long w[4] = {~0ull, 0, 0, 0};                                                             \
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dcf_dbg_w), w, sizeof(w));                                               \
         }                                                                                                           \
         constexpr int NS_ = (BN_ + BM_) <= 128 ? 4 : 3;                                                              \
-        static const char *dma_env = getenv("DCF_IGEMM_DMA");                                                       \
+        static DcfOpt dma_env_o("IGEMM_DMA"); const char *dma_env = dma_env_o.str();                                                       \
         const int dma_mode = dma_env ? atoi(dma_env) : 1;      /* 0 off, 1 small-M tiles, 2 every bf16 KB=128 launch */ \
         bool launched = false;                                                                                      \
         if constexpr (ES == 2 && KB_ == 128) {                                                                      \
@@ -543,14 +542,14 @@ int launch_igemm(const ConvArgs &a_in, hipStream_t s, const char *base, double f
         if (launched) {                                                                                             \
         } else if (db) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR, true>), grid, dim3(256), 0, s, a)); \
         else DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv_igemm<T, KB_, TN_, TM_, WN_, WM_, TR, false>), grid, dim3(256), 0, s, a)); \
-        if (a.dbg & 4) {                                                                                            \
+        if (DCF_DBG(a) & 4) {                                                                                            \
             unsigned long long w[4];                                                                                \
             (void)hipStreamSynchronize(s);                                                                              \
             (void)hipMemcpyFromSymbol(w, HIP_SYMBOL(g_dcf_dbg_w), sizeof(w));                                             \
             fprintf(stderr, "[%s M=%d Ck=%d Cn=%d taps=%d blocks=%d] span %.2f us, mean workgroup life %.2f us, max %.2f us\n", name, a.M, a.Ck, a.Cn, a.kh * a.kw, (int)grid.x, \
                     (w[1] - w[0]) * 0.01, w[2] * 0.01 / grid.x, w[3] * 0.01);                                       \
         }                                                                                                           \
-        if (a.dbg & 2) {                                                                                            \
+        if (DCF_DBG(a) & 2) {                                                                                            \
             long long tt[8];                                                                                        \
             (void)hipStreamSynchronize(s);                                                                              \
             (void)hipMemcpyFromSymbol(tt, HIP_SYMBOL(g_dcf_dbg_t), sizeof(tt));                                           \
@@ -561,7 +560,7 @@ int launch_igemm(const ConvArgs &a_in, hipStream_t s, const char *base, double f
     } while (0)
     // tile choice: the biggest tile that still gives the chip >= ~1 workgroup per CU
     // (DCF_TILE=0..3 forces a tile for experiments: 128x128, 64x128, 64x64, 32x128 channels x pixels)
-    static const char *force_env = getenv("DCF_TILE");
+    static DcfOpt force_env_o("TILE"); const char *force_env = force_env_o.str();
     const int force = force_env ? atoi(force_env) : -1;
     if (force == 0 && a.Cn % 128 == 0) { if (kb128) DCF_IGEMM(128, 2, 2, 2, 2); else DCF_IGEMM(64, 2, 2, 2, 2); }
     if (force == 1 && a.Cn % 64 == 0) { if (kb128) DCF_IGEMM(128, 2, 1, 1, 4); else DCF_IGEMM(64, 2, 1, 1, 4); }
@@ -1205,7 +1204,7 @@ __device__ __forceinline__ void wgrad3g_body(const WgArgs &a, const int bid)
     const int lrA = lane / LPA, lrB = lane / LPB;
     const int chA = (RA == 128) ? ((lane % LPA) ^ (((lrA >> 1) & 1) << 2)) : (lane % LPA);
     const int chB = (RB == 128) ? ((lane % LPB) ^ (((lrB >> 1) & 1) << 2)) : (lane % LPB);
-    const bool chokA = (chA * 16 < coutA) & !(a.dbg & 1), chokB = (chB * 16 < cinB) & !(a.dbg & 1);
+    const bool chokA = (chA * 16 < coutA) & !(DCF_DBG(a) & 1), chokB = (chB * 16 < cinB) & !(DCF_DBG(a) & 1);
     const __amdgpu_buffer_rsrc_t srcG = __builtin_amdgcn_make_buffer_rsrc((void *)a.gy, 0, a.gbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t srcX = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
     constexpr unsigned OOB = 0xFFFFFF00u;
@@ -1440,7 +1439,7 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
                           int B, int H, int W, int Ck, int Cn, int relu, int flip, const char *name_base, double flops, hipStream_t s);
 static bool use_rs(int dtype, int kh, int kw, int stride, int pad)
 {
-    static const char *e = getenv("DCF_CONV_RS");
+    static DcfOpt e_o("CONV_RS"); const char *e = e_o.str();
     return !(e && atoi(e) == 0) && dtype != DCF_F32 && kh == 3 && kw == 3 && stride == 1 && pad == 1;
 }
 
@@ -1505,7 +1504,7 @@ extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const
     ConvArgs a;
     a.x = (const char *)gy; a.w = (const char *)wt; a.shift = nullptr; a.res = (const char *)res; a.y = (char *)gx;
     a.mask = (const char *)mask;
-    static const char *par_env = getenv("DCF_DGRAD_PARITY");     // experiments: 0 = off, 1 = all stride-2 layers, 2 = full-line pixels only
+    static DcfOpt par_env_o("DGRAD_PARITY"); const char *par_env = par_env_o.str();     // experiments: 0 = off, 1 = all stride-2 layers, 2 = full-line pixels only
     const int par_mode = par_env ? atoi(par_env) : 1;
     // (a 1x1 stride-2 layer has one live class and three that only store zeros: one plain pass is cheaper)
     a.parity = (stride == 2 && kh * kw > 1 && par_mode && (par_mode == 1 || Cin * (dtype == DCF_F32 ? 4 : 2) >= 128)) ? 1 : 0;
@@ -1534,20 +1533,20 @@ static void wgrad_tiles(int Cin, int Cout, int &TM, int &TN) { TM = Cout >= 64 ?
 // 3x3 / stride-1 layers: tile of the row-sharing kernel; KR = kernel rows per wave
 static int wgrad3_nw()
 {
-    static const char *e = getenv("DCF_WGRAD3_NW");
+    static DcfOpt e_o("WGRAD3_NW"); const char *e = e_o.str();
     return (e && atoi(e) == 4) ? 4 : 8;
 }
 
 static bool wgrad3_dma(int Wo, int TM, int TN)
 {
-    static const char *e = getenv("DCF_WGRAD3_DMA");
+    static DcfOpt e_o("WGRAD3_DMA"); const char *e = e_o.str();
     if (e && atoi(e) == 0) return false;
     return (Wo + 2 >= (TN == 2 ? 40 : 48)) && (TM * TN >= 2);   // a stage's rows wrap into the next image row at most once
 }
 
 static bool wgrad3_tiles(int Cin, int Cout, int kh, int kw, int stride, int &TM, int &TN, int &KR)
 {
-    static const char *off = getenv("DCF_WGRAD3");
+    static DcfOpt off_o("WGRAD3"); const char *off = off_o.str();
     if (off && atoi(off) == 0) return false;
     if (!(kh == 3 && kw == 3 && stride == 1)) return false;
     TM = Cout >= 64 ? 2 : 1; TN = Cin >= 64 ? 2 : 1;
@@ -1563,7 +1562,7 @@ extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout,
         const int kind = dcf_wgrad3s_kind(DCF_BF16, B, Ho, Wo, Cin, Cout);
         if (kind) return dcf_wgrad3s_splits(kind, B, Ho, Wo, Cin, Cout);
     }
-    static const char *gb = getenv("DCF_WGRAD_BLOCKS");
+    static DcfOpt gb_o("WGRAD_BLOCKS"); const char *gb = gb_o.str();
     // Workgroups per layer.  The backward issues the weight gradients in grouped launches (dcf_conv2d_wgrad_group), where
     // the layers overlap each other: a layer does not have to fill the chip on its own, and fewer pixel ranges mean fewer
     // slabs to write / reduce and fewer in-kernel epilogues.  Swept on cfg2 (40-step runs): 240/1024 -> 264.8 frames/s,
@@ -1572,7 +1571,7 @@ extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout,
     bool dma = false;
     if (wgrad3_tiles(Cin, Cout, kh, kw, stride, TM, TN, KR)) {
         tiles = cdiv(Cout, TM * 32) * cdiv(Cin, TN * 32) * (3 / KR);
-        static const char *wb = getenv("DCF_WGRAD3_BLOCKS");
+        static DcfOpt wb_o("WGRAD3_BLOCKS"); const char *wb = wb_o.str();
         // the LDS-DMA kernel runs one workgroup per CU: one wave of workgroups (floor, not ceil)
         dma = wgrad3_dma(Wo, TM, TN);
         // LDS-DMA kernel: one workgroup per CU, 3 workgroups per unit; 120 workgroups = 5 units per XCD (see below)
@@ -1589,7 +1588,7 @@ extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout,
     if (want > maxs) want = maxs;
     // keep each layer's slab arena small: it is written once and re-read by dcf_wgrad_finalize
     const int64_t slab_bytes = (int64_t)cdiv(Cout, 32) * 32 * kh * kw * Cin * 4;
-    static const char *cap_env = getenv("DCF_SLAB_CAP_MB");
+    static DcfOpt cap_env_o("SLAB_CAP_MB"); const char *cap_env = cap_env_o.str();
     const int64_t cap = ((int64_t)(cap_env ? atoi(cap_env) : 16) << 20) / slab_bytes;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
@@ -1605,8 +1604,7 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
     if (rc) return rc;
     DCF_REQUIRE(x && gy && slabs && nsplit > 0, "dcf_conv2d_wgrad: bad arguments");
     WgArgs a;
-    static const char *dbg_env = getenv("DCF_WGRAD3_DBG");
-    a.dbg = dbg_env ? atoi(dbg_env) : 0;
+    a.dbg = dcf_ablate_opt("WGRAD3_DBG");
     a.x = (const char *)x; a.gy = (const char *)gy; a.slabs = slabs; a.gsum = gsum;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
@@ -1650,7 +1648,7 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
             else DCF_WG3G(1, 2);
 #undef DCF_WG3G
 #undef DCF_WG3G_T
-            if (a.dbg & 2) {
+            if (DCF_DBG(a) & 2) {
                 long long tt[8];
                 (void)hipStreamSynchronize(s);
                 (void)hipMemcpyFromSymbol(tt, HIP_SYMBOL(g_dcf_dbg_t), sizeof(tt));
@@ -1695,7 +1693,7 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
 // ---- grouped weight gradients (3x3 / stride 1 / pad 1 layers of the LDS-DMA kernel, 64x64 tiles)
 extern "C" int dcf_conv2d_wgrad_groupable(int dtype, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad)
 {
-    static const char *e = getenv("DCF_WGRAD_GROUP");
+    static DcfOpt e_o("WGRAD_GROUP"); const char *e = e_o.str();
     if (e && atoi(e) == 0) return 0;
     int TM, TN, KR;
     if (dtype == DCF_F32 || pad != 1 || !wgrad3_tiles(Cin, Cout, kh, kw, stride, TM, TN, KR)) return 0;
@@ -1746,7 +1744,7 @@ extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_st
                 if (rc) return rc;
             }
         }
-    static const char *gen_env = getenv("DCF_WGRAD_GROUP_GENERIC");
+    static DcfOpt gen_env_o("WGRAD_GROUP_GENERIC"); const char *gen_env = gen_env_o.str();
     const bool group_generic = !(gen_env && atoi(gen_env) == 0);
     for (int bk = 0; bk <= 4; ++bk) {
         for (int dt = DCF_BF16; dt <= DCF_F16; ++dt) {

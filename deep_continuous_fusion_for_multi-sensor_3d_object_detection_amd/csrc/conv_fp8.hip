@@ -371,7 +371,7 @@ int launch_f8(const Conv8Args &a, hipStream_t s, double flops)
         return DCF_OK;                                                                                              \
     } while (0)
     // KB = 64 everywhere: two stages of a 128x128 (or 64x256) tile stay under the 64-KB static LDS limit
-    static const char *force_env = getenv("DCF_F8_TILE");
+    static DcfOpt force_env_o("F8_TILE"); const char *force_env = force_env_o.str();
     const int force = force_env ? atoi(force_env) : -1;
     auto blocks = [&](int bn, int bm) { return (int64_t)cdiv(a.M, bm) * (a.Cn / bn); };
     // the biggest tile that still gives the chip >= ~2 workgroups per CU

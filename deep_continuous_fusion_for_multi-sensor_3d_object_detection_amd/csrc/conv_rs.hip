@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
     const T *mask = reinterpret_cast<const T *>(a.mask);
     auto store_tile = [&](int q0c, int n0c) __attribute__((always_inline)) {
         // exactly cnt x TN x 2 store instructions per wave, whatever the tile (see gst16)
-        if (a.dbg & 4) {
+        if (DCF_DBG(a) & 4) {
 #pragma unroll
             for (int j = 0; j < TMMAX; ++j)
                 if (j < cnt)
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
         };
         auto issue_w = [&](int d, int kj, int slot) __attribute__((always_inline)) {                  // weights of tap kj of stage s + d
             const unsigned dst = __builtin_amdgcn_readfirstlane(ldsW0 + slot * WSLOT + wid * PWW * 1024);
-            const bool ok = kis[d] < 3 && !(a.dbg & 16);
+            const bool ok = kis[d] < 3 && !(DCF_DBG(a) & 16);
             const unsigned koff = (unsigned)(wst[d] + kj * tapstep);
 #pragma unroll
             for (int j = 0; j < PWW; ++j) glds16(srcW, ok ? wbase[j] + koff : OOB, dst + j * 1024);
@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
             for (int j = 0; j < PXW; ++j)
                 if (j >= j0 && j < j1) {
                     const unsigned dst = __builtin_amdgcn_readfirstlane(ldsX0 + slot * XSLOT + (wid + j * NW) * 1024);
-                    glds16(srcX, (((xok[j] >> ki) & 1) && !(a.dbg & 2)) ? (unsigned)(xbase[j] + xst[d]) : OOB, dst);
+                    glds16(srcX, (((xok[j] >> ki) & 1) && !(DCF_DBG(a) & 2)) ? (unsigned)(xbase[j] + xst[d]) : OOB, dst);
                 }
         };
         auto begin_tile = [&]() __attribute__((always_inline)) {                                      // stage bookkeeping of a fresh tile + its first groups
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
                 auto issue_part = [&](int part) {
                     if constexpr (S3) {                    // the stage's group (3 PWW weight + CX pixel pieces) over its 12 K-quarters
                         const int q12 = kj * 4 + part;
-                        const bool okw = kis[DX] < 3 && !(a.dbg & 16);
+                        const bool okw = kis[DX] < 3 && !(DCF_DBG(a) & 16);
 #pragma unroll
                         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
@@ -458,13 +458,13 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
                         for (int j = 0; j < PXW; ++j)
                             if (j < CX && (3 * PWW + j) % 12 == q12) {
                                 const unsigned dst = __builtin_amdgcn_readfirstlane(ldsX0 + xsi * XSLOT + (wid + j * NW) * 1024);
-                                glds16(srcX, (((xok[j] >> kix) & 1) && !(a.dbg & 2)) ? (unsigned)(xbase[j] + xst[DX]) : OOB, dst);
+                                glds16(srcX, (((xok[j] >> kix) & 1) && !(DCF_DBG(a) & 2)) ? (unsigned)(xbase[j] + xst[DX]) : OOB, dst);
                             }
                         return;
                     }
                     const int dw = (kj + DW) / 3, kw = (kj + DW) % 3;
                     const unsigned dstw = __builtin_amdgcn_readfirstlane(ldsW0 + wsi * WSLOT + wid * PWW * 1024);
-                    const bool okw = kis[dw] < 3 && !(a.dbg & 16);
+                    const bool okw = kis[dw] < 3 && !(DCF_DBG(a) & 16);
                     const unsigned koff = (unsigned)(wst[dw] + kw * tapstep);
 #pragma unroll
                     for (int j = 0; j < PWW; ++j)
@@ -474,10 +474,10 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
                     for (int j = 0; j < PXW; ++j)
                         if (j >= xj0 && j < xj1 && ((PWW + j - xj0) & 3) == part) {
                             const unsigned dst = __builtin_amdgcn_readfirstlane(ldsX0 + xsi * XSLOT + (wid + j * NW) * 1024);
-                            glds16(srcX, (((xok[j] >> kix) & 1) && !(a.dbg & 2)) ? (unsigned)(xbase[j] + xst[DX]) : OOB, dst);
+                            glds16(srcX, (((xok[j] >> kix) & 1) && !(DCF_DBG(a) & 2)) ? (unsigned)(xbase[j] + xst[DX]) : OOB, dst);
                         }
                 };
-                if (!DCF_RS_SPREAD || C == 0 || (a.dbg & 1)) {
+                if (!DCF_RS_SPREAD || C == 0 || (DCF_DBG(a) & 1)) {
                     if constexpr (S3) {
                         if (kj == 0) {
                             issue_x(DX, xsi, 0, CX);
@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(RsArgs a)
                         if (kj == 1) issue_x(DX, xsi, PXA, CX);
                     }
                 }
-                if constexpr (C > 0) if (!(a.dbg & 1)) {
+                if constexpr (C > 0) if (!(DCF_DBG(a) & 1)) {
                     const char *pw = lds + wsr * WSLOT + rdA;
                     const char *px = lds + NSW * WSLOT + xsr * XSLOT + rdX + kj * 128;
                     const int swx0 = (h ^ (((r + kj) >> 1) & 7)) << 4;
@@ -573,7 +573,8 @@ static const RsKind RS_KINDS[3] = {{128, 2, 5, 2, 512, 1}, {64, 4, 3, 2, 512, 1}
 
 static RsPlan rs_plan(int64_t Q, int Cn)
 {
-    const char *ek = getenv("DCF_RS_KIND"), *en = getenv("DCF_RS_NPT");
+    static DcfOpt ek_o("RS_KIND"), en_o("RS_NPT");
+    const char *ek = ek_o.str(), *en = en_o.str();
     const int ncu = 256;
     RsPlan best = {-1, 0};
     double best_t = 1e30;
@@ -613,21 +614,21 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
     a.x = (const char *)x; a.w = (const char *)w; a.shift = shift; a.res = (const char *)res; a.mask = (const char *)mask; a.y = (char *)y;
     a.B = B; a.H = H; a.W = W; a.Ck = Ck; a.Cn = Cn; a.relu = relu; a.flip = flip;
     a.npt = p.npt; a.Q = (int)Q;
-    { const char *e = getenv("DCF_RS_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.dbg = dcf_ablate_opt("RS_DBG");
     a.mtiles = (int)((Q + 32 * p.npt - 1) / (32 * p.npt));
     a.xbytes = (unsigned)((int64_t)B * H * W * Ck * 2);
     a.wbytes = (unsigned)((int64_t)Cn * 9 * Ck * 2);
     a.ybytes = (unsigned)((int64_t)B * H * W * Cn * 2);
     const int BN = RS_KINDS[p.kind].BN;
     // persistent workgroups: at most one per CU, each walking its XCD's share of the tile list
-    static const char *pe = getenv("DCF_RS_PERSIST");
+    static DcfOpt pe_o("RS_PERSIST"); const char *pe = pe_o.str();
     int64_t nwg = (((int64_t)a.mtiles * (Cn / BN) + 7) / 8) * 8;
     if (!(pe && atoi(pe) == 0)) nwg = std::min<int64_t>(nwg, 256 * RS_KINDS[p.kind].per_cu);
     const dim3 grid((unsigned)nwg);
     char name[96];
     snprintf(name, sizeof(name), "%s<rs%d,%d>", name_base, p.kind, p.npt);
     const double bytes = (double)a.xbytes + (double)a.wbytes + (double)B * H * W * Cn * 2.0 * (1 + (res ? 1 : 0) + (mask ? 1 : 0));
-    static const char *s3e = getenv("DCF_RS_S3");
+    static DcfOpt s3e_o("RS_S3"); const char *s3e = s3e_o.str();
     const bool s3 = !(s3e && atoi(s3e) == 0);
 #define DCF_RS(T_)                                                                                                               \
     do {                                                                                                                         \

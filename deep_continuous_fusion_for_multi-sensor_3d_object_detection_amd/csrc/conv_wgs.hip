@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(A * BC * G * 64) k_conv_wgrad3s_grp(WsGroup g)
 // kind: 0 = not this kernel's; 1 = quadrants 2 x 2 (128 x 128 output tiles: channel counts multiples of 128)
 int dcf_wgrad3s_kind(int dtype, int B, int H, int W, int Cin, int Cout)
 {
-    static const char *e = getenv("DCF_WGRAD3S");
+    static DcfOpt e_o("WGRAD3S"); const char *e = e_o.str();
     if (e && atoi(e) == 0) return 0;
     if (dtype == DCF_F32 || W + 2 < 40) return 0;
     if ((int64_t)B * H * W * Cin * 2 >= (1ll << 31) || (int64_t)B * H * W * Cout * 2 >= (1ll << 31)) return 0;
@@ -369,7 +369,7 @@ int dcf_wgrad3s_kind(int dtype, int B, int H, int W, int Cin, int Cout)
 // layer should not need more than ~96 workgroups (the grouped launch overlaps the layers)
 int dcf_wgrad3s_splits(int kind, int B, int H, int W, int Cin, int Cout)
 {
-    static const char *e = getenv("DCF_WGRAD3S_BLOCKS");
+    static DcfOpt e_o("WGRAD3S_BLOCKS"); const char *e = e_o.str();
     const int want_blocks = e ? atoi(e) : 72;
     const int qco = kind == 1 ? 128 : 192, qci = kind == 1 ? 128 : 64;
     const int tiles = cdiv(Cout, qco) * cdiv(Cin, qci) * 3;
@@ -417,7 +417,7 @@ int dcf_wgrad3s_launch(int dtype, int kind, const dcf_wgs_item *items_in, int n,
             a.rot = rot;
             rot = (rot + cdiv(units, upx)) & 7;
         }
-        static const char *dbg = getenv("DCF_WGRAD3S_DBG");
+        static DcfOpt dbg_o("WGRAD3S_DBG"); const char *dbg = dbg_o.str();
         if (dbg && atoi(dbg))
             for (int k = 0; k < cnt; ++k)
                 fprintf(stderr, "wgrad3s kind %d: B %d H %d W %d Cin %d Cout %d nsplit %d per_split %d blocks %d\n", kind, g.a[k].B, g.a[k].H,

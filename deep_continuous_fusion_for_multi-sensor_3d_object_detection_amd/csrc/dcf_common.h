@@ -52,6 +52,32 @@ extern int g_dcf_prof_on;
         }                                                                           \
     } while (0)
 
+// ---------------------------------------------------------------- tuning options
+// Every tuning switch of the library is a named option, seeded ONCE per process from the environment variable DCF_<NAME> (on
+// first use) and changed afterwards only through dcf_set_option() (tests and tools compare kernels that way).  None of them
+// changes results.  Switches that DO -- the timing ablations that turn phases of a kernel off -- exist only in builds with
+// -DDCF_ABLATE (make ABLATE=1; tools/rs_ablate.py and friends): the shipped library has no way to reach them.
+const char *dcf_opt(const char *name);          // current value or nullptr (runtime.cpp)
+extern int g_dcf_opt_epoch;                      // bumped by dcf_set_option
+struct DcfOpt {                                  // a call site's cached view of one option: static DcfOpt o("RS_KIND");
+    const char *name, *val;
+    int epoch;
+    explicit DcfOpt(const char *n) : name(n), val(nullptr), epoch(-1) {}
+    const char *str()
+    {
+        if (epoch != g_dcf_opt_epoch) { val = dcf_opt(name); epoch = g_dcf_opt_epoch; }
+        return val;
+    }
+};
+#ifdef DCF_ABLATE
+#include <stdlib.h>
+static inline int dcf_ablate_opt(const char *name) { const char *e = dcf_opt(name); return e ? atoi(e) : 0; }
+#define DCF_DBG(a) ((a).dbg)
+#else
+static inline int dcf_ablate_opt(const char *) { return 0; }
+#define DCF_DBG(a) 0
+#endif
+
 static inline hipStream_t S(dcf_stream_t s) { return (hipStream_t)s; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline double esize_of(int dtype) { return dtype == DCF_F32 ? 4.0 : 2.0; }

@@ -982,7 +982,7 @@ extern "C" int dcf_image_to_nhwc4(int dtype, const uint8_t *img, void *y, int B,
 
 static inline int64_t chan_stride(int64_t nvec, int cgroups, int &blocks, int kthreads = 256)
 {
-    static const char *env = getenv("DCF_CHANSUM_KTHREADS");
+    static DcfOpt env_o("CHANSUM_KTHREADS"); const char *env = env_o.str();
     const int64_t cap = (env ? atoi(env) : kthreads) * 1024ll;
     int64_t want = nvec < cap ? nvec : cap;                // 256 k threads = ~1024 blocks of 256 threads
     if (want < cgroups) want = cgroups;
@@ -1115,7 +1115,7 @@ static int wgrad_finalize_impl(const char *who, const dcf_conv_param *table, int
 {
     DCF_REQUIRE(table && nconv > 0 && params && ssarena && slabs && gsum && grads, "%s: bad arguments", who);
     hipStream_t s = S(stream);
-    static const char *grp_env = getenv("DCF_FINALIZE_GROUPS");
+    static DcfOpt grp_env_o("FINALIZE_GROUPS"); const char *grp_env = grp_env_o.str();
     const int grouped = grp_env ? atoi(grp_env) : 1;
     FinRows rows;
     rows.n = 0;

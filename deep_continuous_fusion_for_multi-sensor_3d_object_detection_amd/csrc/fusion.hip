@@ -481,12 +481,12 @@ extern "C" int dcf_fusion_gather_bwd(int dtype, const void *P, const float *xyz,
     const int64_t hw = (int64_t)h * w;
     // pixels per thread run: swept on cfg2 (div 32..512): ~256k threads is the sweet spot between
     // latency hiding (more, shorter runs) and atomic aggregation (fewer, longer runs)
-    static const char *thr_env = getenv("DCF_FUSION_THREADS_K");
+    static DcfOpt thr_env_o("FUSION_THREADS_K"); const char *thr_env = thr_env_o.str();
     const int64_t threads = (thr_env ? atoi(thr_env) : 256) * 1024ll;
     int chunk = (int)(hw * Cb / threads);
     if (chunk < 8) chunk = 8;
     const int64_t groups = (hw + chunk - 1) / chunk;
-    static const char *pipe_env = getenv("DCF_FUSION_PIPE");
+    static DcfOpt pipe_env_o("FUSION_PIPE"); const char *pipe_env = pipe_env_o.str();
     const bool pipe = !(pipe_env && atoi(pipe_env) == 0);
 #define DCF_FGB(KT_) DCF_LAUNCH_B("fusion_gather_bwd", (double)hw * (K * (4.0 + 2.0 * Cb * sizeof(T)) + Cb * sizeof(T)), s, hipLaunchKernelGGL((k_fusion_gather_bwd_pipe<T, KT_>), dim3(cdiv(groups * Cb, 256)), dim3(256), sizeof(float) * Cb * 4, s, (const T *)P, xyz, idx, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, chunk))
     DCF_DISPATCH_DTYPE(dtype, {
@@ -517,7 +517,7 @@ extern "C" int dcf_fusion_gather_bwd_inv(int dtype, const void *P, const float *
     int sl = cdiv(cdiv(max_entries, 4096), 16) * 16;
     sl = sl < 16 ? 16 : (sl > 128 ? 128 : sl);
     const int waves = cdiv(max_entries, sl);
-    static const char *cap_env = getenv("DCF_FUSION_BWD_BLOCKS");
+    static DcfOpt cap_env_o("FUSION_BWD_BLOCKS"); const char *cap_env = cap_env_o.str();
     const int cap = cap_env ? atoi(cap_env) : 256;     // swept: 128 / 256 / 512 / uncapped = 0.52 / 0.34 / 0.36 / 0.44 ms per step
     // (256 channels: 4 accumulator sets per lane do not fit the 128 registers of a 1024-thread block -- 512 threads there)
     const int thr = Cb >= 256 ? FGI_THREADS / 2 : FGI_THREADS;
@@ -548,7 +548,7 @@ extern "C" int dcf_fusion_gather_bwd_pts(int dtype, const void *P, const float *
     FuseGeom g;
     g.h = h; g.w = w; g.stride = stride; g.K = 0; g.xs = xs; g.xo = xo; g.ys = ys; g.yo = yo;
     hipStream_t s = S(stream);
-    static const char *cap_env = getenv("DCF_FUSION_BWD_BLOCKS");
+    static DcfOpt cap_env_o("FUSION_BWD_BLOCKS"); const char *cap_env = cap_env_o.str();
     const int cap = cap_env ? atoi(cap_env) : 256;
     const int thr = Cb >= 256 ? FGI_THREADS / 2 : FGI_THREADS;
     const int blocks = std::min(cdiv(n_rows, thr / 64), cap);

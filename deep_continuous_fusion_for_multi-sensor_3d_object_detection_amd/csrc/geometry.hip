@@ -1011,8 +1011,8 @@ static int knn_bev_impl(const char *who, const float *xyz, const int32_t *count_
     }
     const int nbp = cdiv(g.h8 * g.w8, 4);   // one wave per 8x8 pixel tile
     // coarse sites: one wave per pixel (lanes split the candidates).  DCF_KNN_KERNEL = wave | tile forces one of the two
-    // kernels (read per call: the parity tests compare them on the same site; both produce the exact (d2, index) order)
-    const char *force = getenv("DCF_KNN_KERNEL");
+    // kernels (dcf_set_option: the parity tests compare them on the same site; both produce the exact (d2, index) order)
+    static DcfOpt force_o("KNN_KERNEL"); const char *force = force_o.str();
     const bool per_wave = force && force[0] == 'w' ? true : (force && force[0] == 't' ? false : (h * w <= 20000));
     const int nbw = cdiv(h * w, 4);
 #define KNN_CASE(KK)                                                                                                     \

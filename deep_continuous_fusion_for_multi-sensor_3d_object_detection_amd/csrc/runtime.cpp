@@ -1,5 +1,6 @@
 // runtime.cpp -- error text, version and the optional event-timing layer of libdcf_hip.so.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <map>
 #include <mutex>
@@ -20,6 +21,36 @@ void dcf_set_error(const char *fmt, ...)
 
 extern "C" const char *dcf_last_error(void) { return g_err; }
 extern "C" int dcf_version(void) { return 100; }
+
+// ------------------------------------------------------------------ tuning options (dcf_common.h)
+int g_dcf_opt_epoch = 0;
+namespace {
+std::mutex g_opt_mu;
+std::map<std::string, const char *> g_opts;      // name -> interned value (nullptr = unset); never freed: call sites cache the pointers
+}  // namespace
+
+const char *dcf_opt(const char *name)
+{
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    auto it = g_opts.find(name);
+    if (it != g_opts.end()) return it->second;
+    const char *e = getenv((std::string("DCF_") + name).c_str());   // once per option and process
+    const char *v = e ? strdup(e) : nullptr;
+    g_opts[name] = v;
+    return v;
+}
+
+extern "C" int dcf_set_option(const char *name, const char *value)
+{
+    if (!name || !*name) {
+        dcf_set_error("dcf_set_option: empty name");
+        return DCF_EINVAL;
+    }
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    g_opts[name] = value ? strdup(value) : nullptr;
+    ++g_dcf_opt_epoch;
+    return DCF_OK;
+}
 
 // ------------------------------------------------------------------ profiling
 // HIP events recorded on the launch stream around every DCF_LAUNCH while enabled.

@@ -18,8 +18,13 @@ All arithmetic goes through a backend object (`backend_hip.HipBackend`: HIP kern
 the C ABI).  The engine itself only sequences calls; tests may pass a different backend to
 check the sequencing/maths on CPU, the product never does.
 """
+import os
+
 import numpy as np
 import torch
+
+# experiments (read once per process): "0" = no inverse KNN maps at all, "2" = build them but run the pixel-run backward
+FUSION_INV = os.environ.get("DCF_FUSION_INV", "1")
 
 
 class ConvLayer(object):
@@ -211,17 +216,24 @@ class StackPlan(object):
         if not self.ctx:
             raise RuntimeError("backward through a forward that ran without saving activations")
         self.ctx = None
+        have = [t for t, g in zip(self.taps, gouts) if g is not None]
+        top = max(have) if have else -1
+        # stages past the last output that carries a gradient take no part in this backward: their layers are planned with no
+        # slabs (out_shape None -> nsplit 0), so that the finalisation launch writes ZERO gradients for them instead of reducing
+        # whatever an earlier backward left in the slab arena
+        for si in range(top + 1, len(self.stages)):
+            for b in self.stages[si]:
+                b.saved = None
+                for L in (b.conv1, b.conv2, b.down):
+                    if L is not None:
+                        L.out_shape = None
         K.begin_backward(self.layers)
         gmap = dict((t, K.nchw_to_nhwc(g.contiguous())) for t, g in zip(self.taps, gouts) if g is not None)
         g, masked = None, False
-        for si in range(len(self.stages) - 1, -1, -1):
+        for si in range(top, -1, -1):
             blocks = self.stages[si]
             if g is None:
                 g, masked = gmap.get(si), False
-                if g is None:                       # nothing downstream of this stage carries a gradient
-                    for b in blocks:
-                        b.saved = None
-                    continue
             for bi in range(len(blocks) - 1, -1, -1):
                 extra = gmap.get(si - 1) if bi == 0 else None
                 prev = blocks[bi - 1] if bi > 0 else (self.stages[si - 1][-1] if si > 0 else None)
@@ -589,10 +601,7 @@ class Plan(object):
         K.rowscale_bias_bwd(g, s["cnt"], f["b2_off"])
         K.conv_wgrad(f["fc2"], s["hsum"], g, defer=False)      # g is masked in place by the stage's last block afterwards
         ghsum = K.conv_dgrad(f["fc2"], g, tuple(s["hsum"].shape), None)
-        inv = geom.get("inv")
-        import os
-        if os.environ.get("DCF_FUSION_INV", "1") == "2":
-            inv = None
+        inv = geom.get("inv") if FUSION_INV != "2" else None
         if inv and geom.get("inv_event") is not None and not geom.get("_inv_waited"):
             K.wait_event(geom["inv_event"])            # inverse KNN maps produced on the geometry side stream
             geom["_inv_waited"] = True

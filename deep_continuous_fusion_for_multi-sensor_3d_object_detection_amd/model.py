@@ -447,8 +447,8 @@ class ObjectDetection_DCF(_FlatParamModule):
         """The fusion backward gathers by POINT: invert every site's KNN map (pairs sorted by point id).  Only the
         backward needs it, so a caller with a side stream records its own event after this (train.geometry_async)."""
         from . import ops
-        import os
-        if os.environ.get("DCF_FUSION_INV", "1") == "0":
+        from .engine import FUSION_INV
+        if FUSION_INV == "0":
             return geom
         n_max = geom["xyz"].shape[1]
         maps = [t[b] for t in geom["idx"] for b in range(t.shape[0])]          # map index = site * B + frame
@@ -501,6 +501,7 @@ class _RunStack(torch.autograd.Function):
     def forward(ctx, x, token, module, need):
         ctx.module, ctx.saved_graph = module, need
         outs = module._plan.forward(module._backend, x, save=need)
+        module._fwd_serial = ctx.serial = getattr(module, "_fwd_serial", 0) + 1
         return tuple(outs)
 
     @staticmethod
@@ -508,6 +509,9 @@ class _RunStack(torch.autograd.Function):
         m = ctx.module
         if not ctx.saved_graph:
             raise RuntimeError("backward through a forward that ran without saving activations")
+        if ctx.serial != m._fwd_serial:
+            raise RuntimeError("backward of a stale forward: this module keeps the activations of its LAST forward only "
+                               "(call backward before the next forward; gradients are overwritten, not accumulated)")
         gx = m._plan.backward(m._backend, list(gouts))
         m._bind_grads()
         return gx, None, None, None

@@ -86,15 +86,28 @@ class Train(nn.Module):
         self._side = None
         self.static_geometry = bool(config.get("static_geometry", True))
         self._geo_sets, self._geo_slot = {}, 0
-        # data parallel: all-reduce the LiDAR + fusion gradient bucket under the camera stream's backward
-        self.overlap_allreduce = bool(config.get("overlap_allreduce", os.environ.get("DCF_OVERLAP_ALLREDUCE", "1") != "0"))
+        # data parallel: all-reduce the LiDAR + fusion gradient bucket under the camera stream's backward.  True (default) =
+        # when the world has more than one rank; "force" = also in a one-rank process group (the functional test of the
+        # bucketed path on RCCL with the one GPU a test box has, tests/test_gpu_dp.py); False = one all-reduce at the end.
+        ov = config.get("overlap_allreduce", os.environ.get("DCF_OVERLAP_ALLREDUCE", "1") != "0")
+        self.overlap_force = ov == "force"
+        self.overlap_allreduce = bool(ov)
+        # factor applied to every rank's gradient INSIDE the RCCL reduction (ncclRedOp PreMulSum) and undone in the Adam step's
+        # gradient scale -- e.g. a power of two that lifts small fp16 gradients over the exchange; None = plain sum
+        self.allreduce_premul = config.get("allreduce_premul", None)
         self._pending, self._reduced = [], 0
 
     def sync_replicas(self):
-        """Identical replicas: rank 0's parameters, buffers and optimiser moments win (called at construction; call it
-        again after loading weights on rank 0 only)."""
+        """Identical replicas: rank 0's parameters, buffers, optimiser moments and step count win (called at construction;
+        call it again after loading weights or a checkpoint on rank 0 only)."""
         for t in (self.model.flat_params, self.model._bufflat, self.optimizer.m, self.optimizer.v):
             broadcast_from_rank0(t)
+        if world() > 1:                          # Adam's bias correction depends on it
+            sc = torch.tensor([self.optimizer.step_count], dtype=torch.int64)
+            if dist.get_backend() != "gloo":
+                sc = sc.to(self.model.flat_params.device)
+            dist.broadcast(sc, 0)
+            self.optimizer.step_count = int(sc.item())
 
     def _geo_set(self, B, mp, fast, dims):
         """Persistent device buffers of the per-step geometry, two sets used in turn: a step's geometry is produced on the side
@@ -233,7 +246,8 @@ class Train(nn.Module):
                 dist.all_reduce(h, op=dist.ReduceOp.SUM)
                 seg.copy_(h)
             else:
-                self._pending.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
+                op = dist.ReduceOp.SUM if self.allreduce_premul is None else dist._make_nccl_premul_sum(float(self.allreduce_premul))
+                self._pending.append(dist.all_reduce(seg, op=op, async_op=True))
             self._reduced += b - a
 
     def one_step(self, lidar_voxel, camera_image, object_data, num_ref_box, **extra):
@@ -241,7 +255,10 @@ class Train(nn.Module):
         self.loss_value = self.loss_total(object_data, num_ref_box, pred_cls, pred_reg)
         self.optimizer.zero_grad()
         n = world()
-        overlap = n > 1 and self.overlap_allreduce and not self.model.use_graphs and self.model._backend is not None
+        grouped = dist.is_available() and dist.is_initialized()
+        overlap = ((n > 1 or (self.overlap_force and grouped)) and self.overlap_allreduce and not self.model.use_graphs
+                   and self.model._backend is not None)
+        premul = 1.0
         self._pending, self._reduced = [], 0
         if overlap:
             self.model._backend.bucket_hook = self._bucket_ready
@@ -253,13 +270,15 @@ class Train(nn.Module):
         if overlap and self._reduced == self.model.flat_grads.numel():
             for w in self._pending:
                 w.wait()
+            if self.allreduce_premul is not None and not _through_host(self.model.flat_grads):
+                premul = float(self.allreduce_premul)
         else:                                      # single rank, captured graphs, or a backward that skipped the buckets
             for w in self._pending:
                 w.wait()
             if self._reduced:
                 raise RuntimeError("gradient buckets covered %d of %d elements" % (self._reduced, self.model.flat_grads.numel()))
             allreduce_grads(self.model.flat_grads)
-        self.optimizer.step(1.0 / n)
+        self.optimizer.step(1.0 / (n * premul))
         st = (extra.get("geom") or {}).get("_set")
         if st is not None:                         # the geometry buffers of this step may be refilled from here on
             st["free_event"] = torch.cuda.Event()
@@ -299,7 +318,8 @@ class Train(nn.Module):
 def init_distributed():
     """env:// rendezvous, one rank per GPU (RANK/LOCAL_RANK/WORLD_SIZE from torchrun)."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
-    if ws > 1 and not dist.is_initialized():
+    # (DCF_FORCE_DIST=1: a process group even for one rank -- the RCCL path on a one-GPU test box)
+    if (ws > 1 or os.environ.get("DCF_FORCE_DIST") == "1") and not dist.is_initialized():
         local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -40,6 +40,10 @@ enum { DCF_PROJ_COMPAT = 0, DCF_PROJ_CORRECT = 1 };
 
 const char *dcf_last_error(void);
 int dcf_version(void);
+/* Tuning options (which kernel / tile shape a launch takes; never the results): each is seeded once per process from the
+ * environment variable DCF_<NAME> and changed afterwards only here (value NULL = unset).  Tests use it to compare two
+ * kernels on the same input (e.g. "KNN_KERNEL" = "tile" | "wave").  HOST strings. */
+int dcf_set_option(const char *name, const char *value);
 /* Optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg). */
 int dcf_prof_enable(int on);
 int dcf_prof_reset(void);

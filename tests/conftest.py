@@ -15,34 +15,34 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def pytest_sessionstart(session):
-    """Start the child processes of tests/test_gpu_dp.py (two data-parallel ranks sharing GPU 0 + the one-rank run they
-    must equal) BEFORE this process initialises the GPU: torch.cuda.device_count() does not, anything later does, and a
-    process that has initialised HIP must not exec another program on the GPU pool."""
+def _free_port():
     import socket
-    import subprocess
-    import tempfile
-    import torch
-    config = session.config
-    expr = getattr(config.option, "markexpr", "") or ""
-    if "not gpu" in expr or os.environ.get("DCF_NO_DP_CHILDREN") or torch.cuda.device_count() < 1:
-        return
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = str(s.getsockname()[1])
     s.close()
+    return port
+
+
+def _start_dp_children(config):
+    """Child processes of tests/test_gpu_dp.py: two data-parallel ranks sharing GPU 0 + the one-rank run they must equal, a
+    world-size-1 RCCL rank (the bucketed, overlapped all-reduce on the real backend), and bench.py with two ranks.  They are
+    started BEFORE this process initialises the GPU: torch.cuda.device_count() does not, anything later does, and a process
+    that has initialised HIP must not exec another program on the GPU pool."""
+    import subprocess
+    import tempfile
     outdir = tempfile.mkdtemp(prefix="dcf_dp_")
     child = os.path.join(ROOT, "tests", "dp_child.py")
     procs = []
+    port = _free_port()
     for name, world, rank in (("w1_r0", 1, 0), ("w2_r0", 2, 0), ("w2_r1", 2, 1)):
         log = open(os.path.join(outdir, name + ".log"), "w")
         procs.append((name, subprocess.Popen([sys.executable, child, str(world), str(rank), port, outdir], stdout=log, stderr=subprocess.STDOUT,
                                              cwd=ROOT)))
+    log = open(os.path.join(outdir, "rccl1.log"), "w")
+    procs.append(("rccl1", subprocess.Popen([sys.executable, child, "rccl1", "0", _free_port(), outdir], stdout=log, stderr=subprocess.STDOUT, cwd=ROOT)))
     # ... and bench.py itself with two ranks on this one GPU (gloo instead of RCCL): the N > 1 code path of the benchmark
-    s2 = socket.socket()
-    s2.bind(("127.0.0.1", 0))
-    port2 = str(s2.getsockname()[1])
-    s2.close()
+    port2 = _free_port()
     for rank in range(2):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port2, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", DCF_DIST_BACKEND="gloo")
         out = open(os.path.join(outdir, "bench_r%d.out" % rank), "w")
@@ -50,6 +50,20 @@ def pytest_sessionstart(session):
         procs.append(("bench_r%d" % rank, subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                                                             "--no-cpu-baseline"], stdout=out, stderr=log, cwd=ROOT, env=env)))
     config._dcf_dp_children = (outdir, procs)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Children that are still running (an aborted or deselected session) are ended here: none outlives the session."""
+    kids = getattr(session.config, "_dcf_dp_children", None)
+    if not kids:
+        return
+    for name, p in kids[1]:
+        if p.poll() is None:
+            p.kill()
+            try:
+                p.wait(timeout=30)
+            except Exception:
+                pass
 
 
 @pytest.fixture(scope="session")
@@ -63,9 +77,18 @@ def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
 
 
+@pytest.hookimpl(trylast=True)          # after -m / -k have deselected
 def pytest_collection_modifyitems(config, items):
-    # GPU tests are skipped automatically where no GPU is visible (the CPU container).
     import torch
+    # The data-parallel children are started only when their tests were collected AND will run (a GPU is visible, the
+    # selection keeps them) -- and before anything below initialises the GPU in this process.  Under pytest-xdist every
+    # worker would start its own set on the one GPU: the tests skip there instead.
+    expr = getattr(config.option, "markexpr", "") or ""
+    wanted = [it for it in items if it.fspath.basename == "test_gpu_dp.py"]
+    if (wanted and "not gpu" not in expr and not os.environ.get("DCF_NO_DP_CHILDREN") and not os.environ.get("PYTEST_XDIST_WORKER")
+            and torch.cuda.device_count() >= 1 and not hasattr(config, "_dcf_dp_children")):
+        _start_dp_children(config)
+    # GPU tests are skipped automatically where no GPU is visible (the CPU container).
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

@@ -65,3 +65,47 @@ def test_two_ranks_equal_one_rank_with_twice_the_batch(request):
         assert float(d.max()) <= 2.5 * lr * (step + 1), "step %d: parameters %g apart" % (step, float(d.max()))
     # the steps moved the parameters at all (learning rate 1e-3, Adam: ~1e-3 per step)
     assert float((one["params"][1] - one["params"][0]).abs().max()) > 1e-4
+
+
+def test_rccl_bucketed_allreduce_world_size_one(request):
+    """The product's overlapped, bucketed gradient all-reduce on RCCL itself (backend "nccl", a one-rank process group on the
+    one GPU of this box; tests/dp_child.py run_rccl1): the LiDAR + fusion bucket is finalised and handed to
+    dist.all_reduce(async_op=True) from the autograd thread while the camera stream's backward still runs, the camera bucket
+    follows, Adam waits for both.  Gradients over three steps equal those of the plain single-rank step (to the 1e-5 the
+    float atomics of the fusion backward allow between any two runs; parameters as far as Adam keeps noise-level gradients
+    together).  With a PreMulSum reduction the collective DOUBLES the buffer: the arena then holds exactly twice the plain
+    gradient -- which it can only when RCCL's stream ran behind the finalisation launch -- and the negative control (hook
+    called before the finalisation: the launch overwrites the doubled, stale arena) is detected.
+    Reference: /root/reference/train.py:24,51-56."""
+    outdir = _wait(request, "rccl1")
+    r = torch.load(os.path.join(outdir, "rccl1.pt"))
+    assert r["backend"] == "nccl"
+    plain, ov = r["plain"], r["overlap"]
+    assert "error" not in plain and "error" not in ov, (plain.get("error"), ov.get("error"))
+    # the hook really ran per bucket: (LiDAR, fusion) then (camera), together covering the arena
+    assert [len(c) for c in ov["hook_calls"]] == [2, 1] * 3
+    assert sum(b - a for c in ov["hook_calls"][:2] for a, b in c) == ov["numel"]
+    assert not plain["hook_calls"]
+    lr = 1e-3
+
+    def close(a, b, what):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), "%s: %g apart (max %g)" % (what, float((a - b).abs().max()), float(b.abs().max()))
+
+    def params_close(a, b, step, what):
+        d = (a - b).abs()
+        assert float((d > 1e-5 * float(a.abs().max())).float().mean()) < 1e-3 and float(d.max()) <= 2.5 * lr * (step + 1), what
+
+    close(ov["grads"][0], plain["grads"][0], "bucketed gradients, step 0")
+    for step in range(3):
+        params_close(ov["params"][step], plain["params"][step], step, "bucketed path, parameters after step %d" % step)
+    pm, wrong = r["premul"], r["wrong"]
+    assert "error" not in pm, pm.get("error")
+    close(pm["grads"][0], 2.0 * plain["grads"][0], "PreMulSum reduction, step 0")
+    for step in range(3):
+        params_close(pm["params"][step], plain["params"][step], step, "PreMulSum path, parameters after step %d" % step)
+    assert "error" not in wrong, wrong.get("error")
+    (a0, b0), _ = wrong["hook_calls"][0]            # LiDAR-stream range of the arena
+    got, want = wrong["grads"][0][a0:b0], 2.0 * plain["grads"][0][a0:b0]
+    assert float((got - want).abs().max()) > 0.25 * float(want.abs().max()), \
+        "negative control: an all-reduce started before the finalisation launch went unnoticed"
+    close(wrong["grads"][0][a0:b0], plain["grads"][0][a0:b0], "negative control: the finalisation's own (undoubled) values")

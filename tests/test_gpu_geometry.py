@@ -316,7 +316,7 @@ def test_knn_cfg2_whole_site_sampled_bruteforce(K, stride):
 
 
 @pytest.mark.parametrize("stride,K", [(2, 3), (4, 5), (8, 3)])
-def test_knn_tile_kernel_equals_wave_kernel_full_site(stride, K, monkeypatch):
+def test_knn_tile_kernel_equals_wave_kernel_full_site(stride, K):
     """k_knn_search (one wave per 8x8 tile, window + coarse rings) and k_knn_search_wave (one wave per pixel, lanes split
     the candidates) are two implementations of the same exact (d2, index) order: whole-site equality at cfg2 size, in both
     directions of the dispatch threshold (a fine site forced onto the wave kernel, a coarse one onto the tile kernel)."""
@@ -326,18 +326,22 @@ def test_knn_tile_kernel_equals_wave_kernel_full_site(stride, K, monkeypatch):
     h, w = 704 // stride, 800 // stride
     d = torch.from_numpy(xyz).cuda()
     cnt = torch.tensor([n], dtype=torch.int32, device="cuda")
-    monkeypatch.setenv("DCF_KNN_KERNEL", "tile")
-    a = ops.knn_bev(d, cnt, K, h, w, stride, g.aff)
-    monkeypatch.setenv("DCF_KNN_KERNEL", "wave")
-    b = ops.knn_bev(d, cnt, K, h, w, stride, g.aff)
-    monkeypatch.delenv("DCF_KNN_KERNEL")
-    c = ops.knn_bev(d, cnt, K, h, w, stride, g.aff)
-    assert torch.equal(a, b) and torch.equal(a, c)
-    # ... and with a radius cut that leaves pixels with fewer than K neighbours
-    monkeypatch.setenv("DCF_KNN_KERNEL", "tile")
-    a = ops.knn_bev(d, cnt, K, h, w, stride, g.aff, rmax=1.5)
-    monkeypatch.setenv("DCF_KNN_KERNEL", "wave")
-    b = ops.knn_bev(d, cnt, K, h, w, stride, g.aff, rmax=1.5)
+    H = pkg("_hip")
+    try:
+        H.set_option("KNN_KERNEL", "tile")
+        a = ops.knn_bev(d, cnt, K, h, w, stride, g.aff)
+        H.set_option("KNN_KERNEL", "wave")
+        b = ops.knn_bev(d, cnt, K, h, w, stride, g.aff)
+        H.set_option("KNN_KERNEL", None)
+        c = ops.knn_bev(d, cnt, K, h, w, stride, g.aff)
+        assert torch.equal(a, b) and torch.equal(a, c)
+        # ... and with a radius cut that leaves pixels with fewer than K neighbours
+        H.set_option("KNN_KERNEL", "tile")
+        a = ops.knn_bev(d, cnt, K, h, w, stride, g.aff, rmax=1.5)
+        H.set_option("KNN_KERNEL", "wave")
+        b = ops.knn_bev(d, cnt, K, h, w, stride, g.aff, rmax=1.5)
+    finally:
+        H.set_option("KNN_KERNEL", None)
     assert torch.equal(a, b) and int((a < 0).sum()) > 0
 
 

@@ -561,3 +561,45 @@ def test_stale_forward_backward_fails_loudly():
     assert "stale forward" in str(e.value)
     b.sum().backward()                       # the last forward is fine
     assert float(net.flat_grads.abs().sum()) > 0
+
+
+def test_stack_backward_without_gradient_for_the_deep_outputs():
+    """ResnetCustomed returns (x4, x3, x2); a loss that only uses x2 leaves layer4 / layer5 without a gradient: their
+    parameters' .grad must come out ZERO (not whatever an earlier backward left in the slab arena), the rest must equal the
+    CPU statement; and a stale forward's backward raises, as for the full model."""
+    from oracle import model_ref
+    z = load_golden("model_tiny.npz")
+    cfg = golden_cfg(z)
+    lm = cfg["lidar_module"]
+    M, det = pkg("model"), pkg("detfill")
+    net = M.ResnetCustomed(tuple(lm["out_feature%d" % i] for i in range(1, 6)), tuple(lm["num_res_block%d" % i] for i in range(1, 6)))
+    sd_full, sd = _backbone_sd(cfg)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    x = tiny_input()
+    x4, x3, x2 = net(x.cuda().requires_grad_(True))
+    (x4.sum() + x3.sum() + x2.sum()).backward()                     # fills every slab
+    assert float(dict(net.named_parameters())["layer5.sequential.resblock_0.conv1.weight"].grad.abs().max()) > 0
+    xg = x.cuda().requires_grad_(True)
+    x4, x3, x2 = net(xg)
+    R = torch.from_numpy(det.uniform(tuple(x2.shape), 901, -1.0, 1.0))
+    (x2 * R.cuda()).sum().backward()
+    params = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd_full.items()}
+    bb = "lidar_backbone.backbone."
+    xi = x.clone().requires_grad_(True)
+    t = xi
+    for name in ("layer1", "layer2", "layer3"):
+        t = model_ref._stage(params, bb + name, t, "eval")
+    (t * R).sum().backward()
+    assert float((xg.grad.cpu() - xi.grad).abs().max() / xi.grad.abs().max()) < 2e-3
+    for k, p in net.named_parameters():
+        if k.startswith("layer4") or k.startswith("layer5"):
+            assert float(p.grad.abs().max()) == 0.0, k
+        else:
+            want = params[bb + k].grad
+            assert float((p.grad.cpu() - want).abs().max() / (want.abs().max() + 1e-12)) < 2e-3, k
+    a = net(x.cuda())
+    b = net(x.cuda() * 0.5)
+    with pytest.raises(RuntimeError) as e:
+        a[2].sum().backward()
+    assert "stale forward" in str(e.value)

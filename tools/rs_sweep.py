@@ -9,6 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from conv_bench import LIDAR, IMAGE, timeit
 ops = importlib.import_module("deep_continuous_fusion_for_multi-sensor_3d_object_detection_amd.ops")
+H = importlib.import_module("deep_continuous_fusion_for_multi-sensor_3d_object_detection_amd._hip")
 KINDS = {0: (128, 10), 1: (64, 12), 2: (64, 4)}
 
 
@@ -21,14 +22,14 @@ def main():
         x = (torch.rand((B, Hh, W, Ci), device="cuda") - 0.5).bfloat16()
         w = ((torch.rand((Co, 3, 3, Ci), device="cuda") - 0.5) * 0.1).bfloat16()
         fl = 2.0 * B * Hh * W * Co * Ci * 9
-        os.environ.pop("DCF_RS_KIND", None); os.environ.pop("DCF_RS_NPT", None)
+        H.set_option("RS_KIND", None); H.set_option("RS_NPT", None)
         t0 = timeit(lambda: ops.conv2d_fwd(1, x, w, None, None, 3, 3, 1, 1, False, Co))
         res = []
         for kind, (bn, nmax) in KINDS.items():
             if Co % bn:
                 continue
             for npt in range(1, nmax + 1):
-                os.environ["DCF_RS_KIND"], os.environ["DCF_RS_NPT"] = str(kind), str(npt)
+                H.set_option("RS_KIND", kind); H.set_option("RS_NPT", npt)
                 t = timeit(lambda: ops.conv2d_fwd(1, x, w, None, None, 3, 3, 1, 1, False, Co), iters=10)
                 res.append((t, kind, npt))
         res.sort()
