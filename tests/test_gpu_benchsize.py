@@ -1,0 +1,265 @@
+"""GPU parity AT THE BENCHMARK'S SIZES of the parts of the step the reference lacks (continuous-fusion gather backward,
+point sampling backward, camera stream backward -- SURVEY.md App. D; intent at /root/reference/model.py:192,199-203) and of
+the cfg4 configuration.  The small-shape tests elsewhere pin the arithmetic; these pin the launch shapes the bench really
+takes: ~845 k (pixel, point) pairs over ~40 k points per frame at the stride-2 site, run-length aggregation over long runs,
+16-wave blocks, the 512-thread shape of the 256-channel site, index ranges beyond 2^16 rows, batch-4 plans.
+
+Oracle: fp64 torch-CPU statements written here from the definition in include/dcf_hip.h / oracle/model_ref.py (test
+infrastructure).  A ReLU decision that lies within 1e-5 of zero may legitimately fall either way between fp32 and fp64: the
+statement returns, next to every sum, the total weight of such ambiguous terms, and the comparison allows for exactly that."""
+import numpy as np
+import pytest
+import torch
+
+from _util import golden_cfg, load_golden, pkg
+from oracle import geometry_ref, model_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg2_frame(seed=5, npts=100000):
+    """One cfg2 frame's in-frustum cloud (~40 k of 100 k points) with the grid constants, from the C oracle."""
+    det, calib, ops = pkg("detfill"), pkg("calib"), pkg("ops")
+    cfg = golden_cfg(load_golden("geometry_carla.npz"))
+    cfg.update(dict(voxel_length=704, voxel_width=800, lidar_x_max=70.4, lidar_y_min=-40.0, lidar_y_max=40.0,
+                    image_height=375, image_width=1242, max_num_pc=npts))
+    pts = det.synthetic_points(npts, (0.0, 70.4, -40.0, 40.0, -2.4, 0.8), seed=seed)
+    _, pc, uv, n, _ = geometry_ref.voxelization_projection(pts, cfg, calib.kitti_like_crt(), proj_mode="correct")
+    return ops.GridSpec(cfg), np.ascontiguousarray(pc), np.ascontiguousarray(uv), int(n)
+
+
+def fusion_bwd_statement(P, xyz, idx, stride, aff, w1d, b1, ghs, eps=1e-5):
+    """dP [rows,Cb], dW1d [Cb,3], db1 [Cb] of  hsum[p] = sum_k relu(P[idx_k] + W1d.(dx,dy,z) + b1)  for upstream gradient
+    ghs [h,w,Cb], in fp64 (inputs as given), plus the per-output weight of the terms whose ReLU argument is within eps of 0."""
+    K, h, w = idx.shape
+    rows, Cb = P.shape
+    xs, xo, ys, yo = [np.float32(v) for v in aff[:4]]
+    X = ((np.arange(h, dtype=np.float32) + np.float32(0.5)) * np.float32(stride) - xo) / xs          # fp32, as the device forms it
+    Y = ((np.arange(w, dtype=np.float32) + np.float32(0.5)) * np.float32(stride) - yo) / ys
+    P64, g64 = P.double(), ghs.reshape(h * w, Cb).double()
+    w64, b64 = w1d.double(), b1.double()
+    Xp = torch.from_numpy(X).repeat_interleave(w)
+    Yp = torch.from_numpy(Y).repeat(h)
+    dP, sP = torch.zeros(rows, Cb, dtype=torch.float64), torch.zeros(rows, Cb, dtype=torch.float64)
+    dW, sW = torch.zeros(Cb, 3, dtype=torch.float64), torch.zeros(Cb, 3, dtype=torch.float64)
+    db, sb = torch.zeros(Cb, dtype=torch.float64), torch.zeros(Cb, dtype=torch.float64)
+    for k in range(K):
+        ids = idx[k].reshape(-1).long()
+        valid = ids >= 0
+        safe = ids.clamp(min=0)
+        d = torch.stack(((xyz[safe, 0] - Xp), (xyz[safe, 1] - Yp), xyz[safe, 2]), 1).double()          # fp32 differences, exact in fp64
+        pre = P64[safe] + d @ w64.t() + b64
+        m = (pre > 0) & valid[:, None]
+        amb = (pre.abs() <= eps) & valid[:, None]
+        g = g64 * m
+        ga = g64.abs() * amb
+        dP.index_add_(0, safe, g)
+        sP.index_add_(0, safe, ga)
+        dW += g.t() @ d
+        sW += ga.t() @ d.abs()
+        db += g.sum(0)
+        sb += ga.sum(0)
+    return (dP, dW, db), (sP, sW, sb)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("K", [3, 5])
+def test_fusion_backward_by_point_at_cfg2_size(K, dtype):
+    """dcf_fusion_invert (all four sites of a frame in one call, n_max = 100 000 as in the bench) +
+    dcf_fusion_gather_bwd_inv per site -- 352x400 / Cb 64, 176x200 / Cb 128, 88x100 / Cb 192, 44x50 / Cb 256 (the 512-thread
+    launch shape) -- on the cfg2 cloud, against the fp64 statement of dP, dW1d, db1."""
+    ops, H = pkg("ops"), pkg("_hip")
+    g, pc, uv, n = _cfg2_frame()
+    n_max = pc.shape[0]
+    assert 20000 < n < 80000 and n_max == 100000
+    xyz = torch.from_numpy(pc)
+    xyz_d = xyz.cuda()
+    cnt = torch.tensor([n], dtype=torch.int32, device="cuda")
+    sites = [(2, 64), (4, 128), (8, 192), (16, 256)]
+    maps = [ops.knn_bev(xyz_d, cnt, K, 704 // s, 800 // s, s, g.aff) for s, _ in sites]
+    inv = ops.fusion_invert(maps, n_max)
+    rows = (n + 255) // 256 * 256                      # the engine sizes the per-point tensors by the valid count (Plan._fusion_rows)
+    code = H.dtype_code(dtype)
+    tdt = H.torch_dtype(code)
+    gen = torch.Generator().manual_seed(100 + K)
+    for si, (stride, Cb) in enumerate(sites):
+        h, w = 704 // stride, 800 // stride
+        idx = maps[si].cpu()
+        assert int(idx.min()) >= 0 and int(idx.max()) < n
+        P = (torch.rand(rows, Cb, generator=gen) - 0.5).to(tdt)
+        ghs = (torch.rand(h, w, Cb, generator=gen) - 0.5).to(tdt)
+        w1d = (torch.rand(Cb, 3, generator=gen) - 0.5) * 0.2
+        b1 = (torch.rand(Cb, generator=gen) - 0.5) * 0.2
+        got = [torch.zeros(rows, Cb, device="cuda"), torch.zeros(Cb * 3, device="cuda"), torch.zeros(Cb, device="cuda")]
+        ops.fusion_gather_bwd_inv(code, P.cuda(), xyz_d, inv, n_max, si, (K, h, w), stride, g.aff, w1d.reshape(-1).cuda(), b1.cuda(),
+                                  ghs.cuda(), *got)
+        want, slack = fusion_bwd_statement(P.float(), xyz, idx, stride, g.aff, w1d, b1, ghs.float())
+        got = [got[0].cpu().double(), got[1].cpu().double().view(Cb, 3), got[2].cpu().double()]
+        for name, a, b, s_, tol in (("dP", got[0], want[0], slack[0], 2e-5), ("dW1d", got[1], want[1], slack[1], 3e-4), ("db1", got[2], want[2], slack[2], 3e-4)):
+            scale = float(b.abs().max())
+            assert scale > 0
+            over = (a - b).abs() - (tol * scale + 1.01 * s_)
+            assert float(over.max()) <= 0, "site %d (stride %d, Cb %d, K %d, %s) %s: off by %g of max %g" % (
+                si, stride, Cb, K, dtype, name, float((a - b).abs().max()), scale)
+        # the pixel-run kernel (the path taken without inverse maps) on the same site
+        ref2 = [torch.zeros(rows, Cb, device="cuda"), torch.zeros(Cb * 3, device="cuda"), torch.zeros(Cb, device="cuda")]
+        ops.fusion_gather_bwd(code, P.cuda(), xyz_d, maps[si], stride, g.aff, w1d.reshape(-1).cuda(), b1.cuda(), ghs.cuda(), *ref2)
+        a, b, s_ = ref2[0].cpu().double(), want[0], slack[0]
+        assert float(((a - b).abs() - (2e-5 * float(b.abs().max()) + 1.01 * s_)).max()) <= 0, "pixel-run kernel, site %d" % si
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_point_sample_backward_at_cfg2_size(dtype):
+    """dcf_point_sample_bwd on the camera map of cfg2 (94 x 311 x 64) with the frame's ~40 k projected points: the scatter of
+    dL/dfp into the four bilinear taps (fp32 atomics) against the fp64 statement; and the forward on the same points."""
+    ops, H = pkg("ops"), pkg("_hip")
+    g, pc, uv, n = _cfg2_frame(seed=6)
+    Hf, Wf, Cf = 94, 311, 64
+    rows = (n + 255) // 256 * 256
+    code = H.dtype_code(dtype)
+    tdt = H.torch_dtype(code)
+    gen = torch.Generator().manual_seed(3)
+    gfp = (torch.rand(rows, Cf, generator=gen) - 0.5).to(tdt)
+    fmap = (torch.rand(Hf, Wf, Cf, generator=gen) - 0.5).to(tdt)
+    uvt = torch.from_numpy(uv)
+    cnt = torch.tensor([n], dtype=torch.int32, device="cuda")
+    gF = torch.zeros(Hf, Wf, Cf, device="cuda")
+    ops.point_sample_bwd(code, gfp.cuda(), uvt.cuda(), cnt, rows, gF)
+    fp = ops.point_sample_fwd(code, fmap.cuda(), uvt.cuda(), cnt, rows)
+    # fp64 statement (oracle/model_ref.bilinear_sample's taps and weights; weights formed in fp32 like the device)
+    u, v = uvt[:n, 0], uvt[:n, 1]
+    ix, iy = u * 0.25 - 0.5, v * 0.25 - 0.5
+    x0f, y0f = torch.floor(ix), torch.floor(iy)
+    wx, wy = (ix - x0f).double(), (iy - y0f).double()
+    x0, y0 = x0f.long(), y0f.long()
+    x1, y1 = (x0 + 1).clamp(0, Wf - 1), (y0 + 1).clamp(0, Hf - 1)
+    x0, y0 = x0.clamp(0, Wf - 1), y0.clamp(0, Hf - 1)
+    want = torch.zeros(Hf * Wf, Cf, dtype=torch.float64)
+    g64 = gfp[:n].double()
+    ref_fp = torch.zeros(n, Cf, dtype=torch.float64)
+    f64 = fmap.double().reshape(Hf * Wf, Cf)
+    for yy, xx, ww in ((y0, x0, (1 - wy) * (1 - wx)), (y0, x1, (1 - wy) * wx), (y1, x0, wy * (1 - wx)), (y1, x1, wy * wx)):
+        want.index_add_(0, yy * Wf + xx, g64 * ww[:, None])
+        ref_fp += f64[yy * Wf + xx] * ww[:, None]
+    got = gF.cpu().double().reshape(Hf * Wf, Cf)
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert float(gF.abs().sum()) > 0
+    gotf = fp[:n].float().cpu().double()
+    tol = 1e-5 if dtype == "f32" else 2.0 ** -8
+    assert float((gotf - ref_fp).abs().max()) <= tol * float(ref_fp.abs().max())
+    assert float(fp[n:].float().abs().max()) == 0.0          # rows past the valid count stay zero
+
+
+def _cfg2_config(dtype, batch=1, n_points=100000, K=3, stream="resnet18"):
+    import os
+    import yaml
+    from _util import PKG, ROOT
+    cfg = yaml.safe_load(open(os.path.join(ROOT, PKG, "config", "config_carla.yaml")))
+    cfg.update(dict(voxel_length=704, voxel_width=800, voxel_channel=32, lidar_x_min=0.0, lidar_x_max=70.4, lidar_y_min=-40.0,
+                    lidar_y_max=40.0, lidar_z_min=-2.4, lidar_z_max=0.8, image_height=375, image_width=1242, max_num_pc=n_points,
+                    batch_size=batch, dtype=dtype, projection_mode="correct", voxel_mode="compat"))
+    cfg["fusion"] = dict(enabled=True, K=K, r_max=None, image_channels=64, image_stream=stream, zero_init_last=False)
+    return cfg
+
+
+def test_cfg2_size_fp32_backward_matches_cpu_statement():
+    """BASELINE configs[1] at FULL size, one frame: the fp32 HIP BACKWARD (every launch shaped as in the bench: KNN inverse
+    maps, by-point fusion backward on all four sites, point-sample scatter into the 94x311 camera map, camera stream, grouped
+    weight gradients) against autograd through the CPU statement (oracle/model_ref.py, its own brute-force KNN) for
+    d<pred, R>/d(every parameter): <= 2e-3 of the tensor's maximum on every parameter tensor, with the tensors the verdict
+    named (fusion MLP weights of all four sites, camera layer1.0.conv1, FPN smoothing, LiDAR layer2 / layer3 first
+    convolutions) asserted present."""
+    det, calib, D = pkg("detfill"), pkg("calib"), pkg("data_import_carla")
+    cfg = _cfg2_config("f32")
+    crt = calib.kitti_like_crt()
+    pts = det.synthetic_points(100000, (0.0, 70.4, -40.0, 40.0, -2.4, 0.8), 23)
+    img = torch.from_numpy(det.synthetic_image(375, 1242, 23)).unsqueeze(0)
+    net = pkg("model").ObjectDetection_DCF(cfg)
+    det.fill_state_dict(net)
+    net = net.cuda()
+    geo = D.FrameGeometry(cfg, crt)
+    vox, pc, uv, cnt, _ = geo(torch.from_numpy(pts))
+    R = torch.from_numpy(det.uniform((1, 32, 176, 200), 97, -1.0, 1.0))
+    R[:, 18:] = 0
+    pred = net(vox.unsqueeze(0), img.cuda(), points=pc.unsqueeze(0), uv=uv.unsqueeze(0), n_valid=cnt)
+    (pred * R.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    grid, pc_ref, uv_ref, n_ref, _ = geometry_ref.voxelization_projection(pts, cfg, crt, proj_mode="correct")
+    shapes = {}
+    shapes.update(model_ref.lidar_state_shapes(cfg)); shapes.update(model_ref.image_state_shapes(64)); shapes.update(model_ref.fusion_state_shapes(cfg, 64))
+    sd = model_ref.make_state_dict(shapes)
+    params = {k: (v.clone().requires_grad_(True) if (v.dtype.is_floating_point and "running" not in k) else v) for k, v in sd.items()}
+    gc = geometry_ref.grid_constants(cfg)
+    out = model_ref.forward(params, cfg, torch.from_numpy(grid).unsqueeze(0), img, torch.from_numpy(pc_ref).unsqueeze(0),
+                            torch.from_numpy(uv_ref).unsqueeze(0), [n_ref], "eval", fusion={"K": 3, "aff": gc["aff"], "rmax": None})
+    assert float((pred.detach().cpu() - out.detach()).abs().max() / out.detach().abs().max()) < 1e-3
+    (out * R).sum().backward()
+    errs = {}
+    for k, p in net.named_parameters():
+        want = params[k].grad
+        got = p.grad.detach().cpu()
+        scale = float(want.abs().max())
+        errs[k] = (float((got - want).abs().max()) / (scale + 1e-20), scale)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1][0])[:6]
+    print("cfg2-size fp32 backward, worst parameter gradients (max-rel, scale):", worst)
+    named = ["fusion.site%d.%s" % (s, t) for s in range(1, 5) for t in ("fc1_feat.weight", "fc1_geo.weight", "fc1.bias", "fc2.weight", "fc2.bias")]
+    named += ["image_backbone.layer1.0.conv1.weight", "image_fpn.smooth.weight",
+              "lidar_backbone.backbone.layer2.sequential.resblock_0.conv1.weight",
+              "lidar_backbone.backbone.layer3.sequential.resblock_0.conv1.weight"]
+    for k in named:
+        assert k in errs and errs[k][1] > 0, k
+        assert errs[k][0] < 2e-3, "gradient of %s: rel err %g (scale %g)" % (k, errs[k][0], errs[k][1])
+    bad = [(k, e, s) for k, (e, s) in errs.items() if e > 2e-3 and e * s > 1e-6]
+    assert not bad, "%d parameter tensors off, worst %s" % (len(bad), sorted(bad, key=lambda t: -t[1])[:5])
+
+
+def test_cfg4_full_size_f16_step_matches_fp32_path():
+    """BASELINE configs[3] at FULL size: 120 k points, 1242x375 image, ResNet-50 camera stream (Bottleneck 1x1 / 3x3 / 1x1 with
+    up to 2048 channels), K = 5, fp16, batch 4 -- one forward + backward of the f16 path against the fp32 HIP path on the same
+    frames and weights (the fp32 path is checked against the CPU statement at cfg2 size above and, with this stream and K, in
+    miniature in test_gpu_fusion.py).  Loss-scaled by 1024 like a real fp16 run (no loss scaling in the reference: it trains
+    in fp32).  Bounds as test_cfg2_size_16bit_step_matches_fp32_path: rounding noise, orders of magnitude below what a dropped
+    tile, a wrong tap or a mis-sized batch-4 plan produces."""
+    det, calib, D, T = pkg("detfill"), pkg("calib"), pkg("data_import_carla"), pkg("train")
+    lim6 = (0.0, 70.4, -40.0, 40.0, -2.4, 0.8)
+    crt = calib.kitti_like_crt()
+    B = 4
+    pts = [torch.from_numpy(det.synthetic_points(120000, lim6, 71 + b)).cuda() for b in range(B)]
+    img = torch.stack([torch.from_numpy(det.synthetic_image(375, 1242, 71 + b)) for b in range(B)], 0).cuda()
+    res, R = {}, None
+    for dt in ("f32", "f16"):
+        cfg = _cfg2_config(dt, batch=B, n_points=120000, K=5, stream="resnet50")
+        tr = T.Train(cfg)
+        det.fill_state_dict(tr.model)
+        geo = D.FrameGeometry(cfg, crt)
+        x_lidar, geom = tr.geometry_async(geo, pts)
+        pred = tr.model(x_lidar, img, geom=geom)
+        if R is None:
+            R = torch.from_numpy(det.uniform(tuple(pred.shape), 98, -1.0, 1.0)).cuda()
+            R[:, 18:] = 0
+        ((pred * R).sum() * 1024.0).backward()
+        torch.cuda.synchronize()
+        res[dt] = (pred.detach().float().cpu(), (tr.model.flat_grads / 1024.0).cpu(), tr.model._plan.table.entries)
+        del tr
+        torch.cuda.empty_cache()
+    p32, g32, entries = res["f32"]
+    p16, g16, _ = res["f16"]
+    assert p16.shape == (B, 32, 176, 200) and torch.isfinite(p16).all() and torch.isfinite(g16).all()
+    for name, sl in (("cls", slice(0, 4)), ("reg", slice(4, 18)), ("bbox", slice(18, 32))):
+        a, b = p16[:, sl], p32[:, sl]
+        assert float((a - b).abs().max() / b.abs().max()) < 4e-3, name
+        assert float((a - b).norm() / b.norm()) < 2e-3, name
+    assert float((g16 - g32).norm() / g32.norm()) < 2e-2
+    errs = []
+    for (key, shape, off, n, layout) in entries:
+        if n < 4096:
+            continue
+        a, b = g16[off:off + n], g32[off:off + n]
+        if float(b.abs().max()) < 1e-12:
+            continue
+        errs.append((float((a - b).norm() / (b.norm() + 1e-20)), float((a - b).abs().max() / (b.abs().max() + 1e-20)), key))
+    errs.sort(reverse=True)
+    print("cfg4 full size, worst per-tensor gradient errors (L2-rel, max-rel):", errs[:6])
+    assert any("image_backbone.layer4" in e[2] for e in errs) and any("fusion.site4" in e[2] for e in errs)
+    assert errs[0][0] < 0.08, "gradient of %s: relative L2 error %g" % (errs[0][2], errs[0][0])
+    assert max(e[1] for e in errs) < 0.15, "gradient of %s: rel err %g" % (max(errs, key=lambda e: e[1])[2], max(e[1] for e in errs))

@@ -226,6 +226,11 @@ BIG_SHAPES = [
     (1, 352, 400, 128, 192, 1, 1),   # 1x1 (latconv2 shape), 128 -> 192
     (1, 301, 397, 64, 64, 3, 1),     # row-sharing kernel, persistent workgroups over three rounds of tiles, odd sizes
     (2, 203, 199, 128, 128, 3, 1),   # same on the 128-channel kind (five / four position tiles per wave)
+    # ResNet-50 Bottleneck 1x1 convolutions at cfg4's sizes (batch 4, 1242x375 image)
+    (4, 94, 311, 256, 64, 1, 1),     # layer1 conv1: 117 k pixels, 914 x 1 tiles; dgrad widens 64 -> 256
+    (4, 24, 78, 1024, 256, 1, 1),    # layer3 conv1: K = 1024
+    (4, 12, 39, 512, 2048, 1, 1),    # layer4 conv3 shape class (wide output: 16-32 channel tiles per pixel tile)
+    (4, 47, 156, 256, 512, 1, 2),    # layer2 downsample: 1x1 / stride 2
 ]
 
 
@@ -281,7 +286,7 @@ def test_conv_dgrad_big_launch(shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", [1, 0])
-@pytest.mark.parametrize("shape", [BIG_SHAPES[0], BIG_SHAPES[5], BIG_SHAPES[3]])
+@pytest.mark.parametrize("shape", [BIG_SHAPES[0], BIG_SHAPES[5], BIG_SHAPES[3], BIG_SHAPES[9], BIG_SHAPES[10], BIG_SHAPES[12]])
 def test_conv_wgrad_big_launch(shape, dtype):
     """Weight gradient at bench-size pixel counts (many pixel ranges per layer, ranges crossing image rows / frames)."""
     ops = pkg("ops")

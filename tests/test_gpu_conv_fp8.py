@@ -83,6 +83,10 @@ CASES = [
     (1, 16, 16, 64, 32, 1, 2, False, False),
     (3, 48, 64, 64, 128, 3, 1, False, True),       # enough pixels for the large tiles
     (1, 5, 6, 512, 256, 3, 1, True, True),
+    # launches of >= 512 output tiles -- the only ones the product sends to this kernel (backend fp8_min_blocks)
+    (1, 176, 200, 128, 128, 3, 1, True, True),     # LiDAR stage-3 body: 275 pixel tiles x 2 channel tiles
+    (4, 88, 100, 192, 192, 3, 1, False, True),     # stage-4 body at batch 4: 275 x 3 tiles of 64 channels
+    (4, 135, 240, 256, 128, 1, 1, False, False),   # cfg5 camera map (1080p / 8) at batch 4, 1x1: 1013 x 2 tiles
 ]
 
 
