@@ -159,31 +159,41 @@ int dcf_oracle_project(const float *pts, int n, const float *crt, float ulim, fl
 void dcf_oracle_knn_bev(const float *xyz, int n, int K, int h, int w, int stride,
                         float xs, float xo, float ys, float yo, float rmax2, int32_t *out)
 {
-    float *bd = (float *)malloc(sizeof(float) * (size_t)K);
-    int32_t *bi = (int32_t *)malloc(sizeof(int32_t) * (size_t)K);
-    for (int i = 0; i < h; ++i) {
-        float X = (((float)i + 0.5f) * (float)stride - xo) / xs;
-        for (int j = 0; j < w; ++j) {
-            float Y = (((float)j + 0.5f) * (float)stride - yo) / ys;
-            int cnt = 0;
-            for (int k = 0; k < n; ++k) {
-                float dx = xyz[3 * k] - X, dy = xyz[3 * k + 1] - Y;
-                float a = dx * dx, b = dy * dy;
-                float d2 = a + b;
-                if (rmax2 >= 0.0f && d2 > rmax2) continue;
-                /* insert keeping (d2, index) ascending; k ascends, so ties keep the earlier */
-                if (cnt < K || d2 < bd[cnt - 1]) {
-                    int pos = (cnt < K) ? cnt : K - 1;
-                    while (pos > 0 && bd[pos - 1] > d2) { bd[pos] = bd[pos - 1]; bi[pos] = bi[pos - 1]; --pos; }
-                    bd[pos] = d2; bi[pos] = k;
-                    if (cnt < K) ++cnt;
+    /* pixel rows are independent: threaded over i when built with OpenMP (bench.py's cpu_baseline uses all host cores);
+     * every pixel's scan is the same sequential loop either way, so the result does not depend on the thread count */
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+    {
+        float *bd = (float *)malloc(sizeof(float) * (size_t)K);
+        int32_t *bi = (int32_t *)malloc(sizeof(int32_t) * (size_t)K);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int i = 0; i < h; ++i) {
+            float X = (((float)i + 0.5f) * (float)stride - xo) / xs;
+            for (int j = 0; j < w; ++j) {
+                float Y = (((float)j + 0.5f) * (float)stride - yo) / ys;
+                int cnt = 0;
+                for (int k = 0; k < n; ++k) {
+                    float dx = xyz[3 * k] - X, dy = xyz[3 * k + 1] - Y;
+                    float a = dx * dx, b = dy * dy;
+                    float d2 = a + b;
+                    if (rmax2 >= 0.0f && d2 > rmax2) continue;
+                    /* insert keeping (d2, index) ascending; k ascends, so ties keep the earlier */
+                    if (cnt < K || d2 < bd[cnt - 1]) {
+                        int pos = (cnt < K) ? cnt : K - 1;
+                        while (pos > 0 && bd[pos - 1] > d2) { bd[pos] = bd[pos - 1]; bi[pos] = bi[pos - 1]; --pos; }
+                        bd[pos] = d2; bi[pos] = k;
+                        if (cnt < K) ++cnt;
+                    }
                 }
+                for (int q = 0; q < K; ++q)
+                    out[((size_t)q * h + i) * w + j] = (q < cnt) ? bi[q] : -1;
             }
-            for (int q = 0; q < K; ++q)
-                out[((size_t)q * h + i) * w + j] = (q < cnt) ? bi[q] : -1;
         }
+        free(bd); free(bi);
     }
-    free(bd); free(bi);
 }
 
 /* Same contract, for a LIST of pixels (pi[q], pj[q]) of the site instead of the whole

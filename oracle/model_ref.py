@@ -185,10 +185,12 @@ def fusion_site(sd, pfx, x, Fmap, xyz, uv, n, stride, aff, K, rmax=None, knn_idx
 
 # ----------------------------------------------------------------- whole forward
 def forward(sd, cfg, x_lidar, x_image=None, points=None, uv=None, n_valid=None, bn_mode="eval",
-            fusion=None, return_stages=False):
+            fusion=None, return_stages=False, knn_maps=None):
     """model.py:194-204 (+ App. D when `fusion` is a dict(K=..., rmax=..., aff=...)).
 
     sd: state_dict with the reference's key names (optionally 'module.'-stripped).
+    knn_maps: optional precomputed KNN indices, knn_maps[site][b] = int32 tensor [K,h,w] (bench.py times the
+    brute-force search apart from the network); default: searched here.
     Returns pred [B,32,h,w] = cat(cls[4], reg[14], bbox[14]) (and stage outputs).
     """
     pre = "lidar_backbone."
@@ -209,7 +211,8 @@ def forward(sd, cfg, x_lidar, x_image=None, points=None, uv=None, n_valid=None, 
             for b in range(B):
                 nb = int(n_valid[b])
                 xb, _ = fusion_site(sd, "fusion.site%d" % si, x[b], fmap[b], points[b], uv[b], nb,
-                                    stride, fusion["aff"], fusion["K"], fusion.get("rmax"))
+                                    stride, fusion["aff"], fusion["K"], fusion.get("rmax"),
+                                    None if knn_maps is None else knn_maps[si - 1][b])
                 fused.append(xb)
             x = torch.stack(fused, 0)
         stages[name] = x
