@@ -85,7 +85,8 @@ def run_rccl1(port, outdir):
                 self.bucket_hook([self._param_ranges(layers, 0, i0), self._param_ranges(layers, f0, len(layers))])   # too early
                 self._finalize(0, i0)
                 self._finalize(f0, len(layers))
-            tr.model._ensure_backend(tr.model.flat_params.device).bucket_ready = bad_bucket_ready.__get__(tr.model._backend, HB)
+            backend = tr.model._ensure_backend(tr.model.flat_params.device)
+            backend.bucket_ready = bad_bucket_ready.__get__(backend, HB)
         params, grads = [], []
         for step in range(3):
             np.random.seed(100 + step)

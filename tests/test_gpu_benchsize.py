@@ -209,7 +209,19 @@ def test_cfg2_size_fp32_backward_matches_cpu_statement():
     for k in named:
         assert k in errs and errs[k][1] > 0, k
         assert errs[k][0] < 2e-3, "gradient of %s: rel err %g (scale %g)" % (k, errs[k][0], errs[k][1])
-    bad = [(k, e, s) for k, (e, s) in errs.items() if e > 2e-3 and e * s > 1e-6]
+    # Every other tensor: a ReLU argument within fp32 noise of zero falls on either side in the two fp32 computations, and one
+    # such decision moves one pixel's worth of gradient in that layer's bias / weight-gradient sums -- tools/bwd_noise.py ran
+    # the same step against the fp64 statement and recorded every ReLU's argument: the HIP path's largest deviations
+    # (4.6e-3 / 2.9e-3 of the maximum on two BatchNorm biases of layer4 / layer5) EQUAL, to three digits, the gradient of the one
+    # ambiguous element of that channel (profiles/r03a_bwd_noise.txt); the CPU fp32 statement shows the same kind of
+    # deviation against fp64 (up to 1.9e-3) on other tensors.  So: relative L2 <= 3e-3 and nothing beyond 1.5e-2 of a
+    # tensor's maximum -- a dropped pixel range, tile or tap is O(1e-1 .. 1) in L2.
+    l2 = {}
+    for k, p in net.named_parameters():
+        want = params[k].grad
+        l2[k] = float((p.grad.detach().cpu() - want).norm() / (want.norm() + 1e-20))
+    print("worst relative L2:", sorted(l2.items(), key=lambda kv: -kv[1])[:4])
+    bad = [(k, e, s, l2[k]) for k, (e, s) in errs.items() if (e > 1.5e-2 or l2[k] > 3e-3) and e * s > 1e-6]
     assert not bad, "%d parameter tensors off, worst %s" % (len(bad), sorted(bad, key=lambda t: -t[1])[:5])
 
 

@@ -108,4 +108,4 @@ def test_rccl_bucketed_allreduce_world_size_one(request):
     got, want = wrong["grads"][0][a0:b0], 2.0 * plain["grads"][0][a0:b0]
     assert float((got - want).abs().max()) > 0.25 * float(want.abs().max()), \
         "negative control: an all-reduce started before the finalisation launch went unnoticed"
-    close(wrong["grads"][0][a0:b0], plain["grads"][0][a0:b0], "negative control: the finalisation's own (undoubled) values")
+    # (what it holds instead is a race between the collective and the launch: the undoubled gradient, or twice the stale arena)
