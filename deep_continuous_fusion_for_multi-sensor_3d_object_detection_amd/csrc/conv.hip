@@ -1437,6 +1437,9 @@ __global__ void __launch_bounds__(256) k_conv_wgrad_grp(WgGroup g)
 // row-sharing kernel for the 3x3 / stride-1 / pad-1 layers (conv_rs.hip)
 int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *shift, const void *res, const void *mask, void *y,
                           int B, int H, int W, int Ck, int Cn, int relu, int flip, const char *name_base, double flops, hipStream_t s);
+// spatial-tile streaming kernel for the HBM-bound 32 / 64-channel 3x3 / stride-1 layers (conv_sp.hip)
+int dcf_conv3x3_sp_launch(int dtype, const void *x, const void *w, const float *shift, const void *res, const void *mask, void *y,
+                          int B, int H, int W, int Ck, int Cn, int relu, int flip, const char *name_base, double flops, hipStream_t s);
 static bool use_rs(int dtype, int kh, int kw, int stride, int pad)
 {
     static DcfOpt e_o("CONV_RS"); const char *e = e_o.str();
@@ -1485,6 +1488,8 @@ extern "C" int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const flo
     a.wbytes = (unsigned)((int64_t)Cout * kh * kw * a.pixbytes);
     const double flops = 2.0 * a.M * Cout * (double)Cin * kh * kw;
     if (use_rs(dtype, kh, kw, stride, pad)) {
+        rc = dcf_conv3x3_sp_launch(dtype, x, w, shift, res, nullptr, y, B, H, W, Cin, Cout, relu, 0, dtype == DCF_F16 ? "conv_fwd_f16" : "conv_fwd_bf16", flops, S(stream));
+        if (rc != DCF_EUNSUPPORTED) return rc;
         rc = dcf_conv3x3_rs_launch(dtype, x, w, shift, res, nullptr, y, B, H, W, Cin, Cout, relu, 0, dtype == DCF_F16 ? "conv_fwd_f16" : "conv_fwd_bf16", flops, S(stream));
         if (rc != DCF_EUNSUPPORTED) return rc;
     }
@@ -1520,6 +1525,8 @@ extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const
     a.wbytes = (unsigned)((int64_t)Cin * kh * kw * a.pixbytes);
     const double flops = 2.0 * B * Ho * Wo * Cout * (double)Cin * kh * kw;   // algorithmic (= the forward conv's)
     if (use_rs(dtype, kh, kw, stride, pad)) {
+        rc = dcf_conv3x3_sp_launch(dtype, gy, wt, nullptr, res, mask, gx, B, H, W, Cout, Cin, 0, 1, dtype == DCF_F16 ? "conv_dgrad_f16" : "conv_dgrad_bf16", flops, S(stream));
+        if (rc != DCF_EUNSUPPORTED) return rc;
         rc = dcf_conv3x3_rs_launch(dtype, gy, wt, nullptr, res, mask, gx, B, H, W, Cout, Cin, 0, 1, dtype == DCF_F16 ? "conv_dgrad_f16" : "conv_dgrad_bf16", flops, S(stream));
         if (rc != DCF_EUNSUPPORTED) return rc;
     }

@@ -257,10 +257,20 @@ def test_cfg4_full_size_f16_step_matches_fp32_path():
     p32, g32, entries = res["f32"]
     p16, g16, _ = res["f16"]
     assert p16.shape == (B, 32, 176, 200) and torch.isfinite(p16).all() and torch.isfinite(g16).all()
-    for name, sl in (("cls", slice(0, 4)), ("reg", slice(4, 18)), ("bbox", slice(18, 32))):
+    for name, sl in (("cls", slice(0, 4)), ("reg", slice(4, 18))):
         a, b = p16[:, sl], p32[:, sl]
         assert float((a - b).abs().max() / b.abs().max()) < 4e-3, name
         assert float((a - b).norm() / b.norm()) < 2e-3, name
+    # decoded boxes (model.py:126-136): a deviation d of an offset moves x, y by d * diagonal, z by d * height, the sizes by the
+    # FACTOR exp(d) (the largest boxes here are e^4 anchors wide), the yaw by d on the circle
+    import math
+    d = float((p16[:, 4:18] - p32[:, 4:18]).abs().max())
+    box16, box32 = p16[:, 18:32], p32[:, 18:32]
+    err = (box16 - box32).abs()
+    for c in (6, 13):
+        err[:, c] = torch.minimum(err[:, c], (2.0 * math.pi - err[:, c]).abs())
+    bound = (math.exp(2.0 * d) - 1.0) * box32.abs() + 8.0 * d + 1e-3
+    assert bool((err <= bound).all()), "decoded boxes: %g beyond the bound (offset deviation %g)" % (float((err - bound).max()), d)
     assert float((g16 - g32).norm() / g32.norm()) < 2e-2
     errs = []
     for (key, shape, off, n, layout) in entries:

@@ -308,3 +308,61 @@ def test_conv_wgrad_big_launch(shape, dtype):
     assert e < 2e-4, "wgrad rel err %g" % e                       # fp32 accumulation of exactly representable products
     want = gy.sum((0, 2, 3))
     assert float((gsum.sum(0).cpu() - want).abs().max()) < 2e-4 * float(gy.abs().sum((0, 2, 3)).max())
+
+
+# ---- spatial-tile streaming kernel (conv_sp.hip: Cin == Cout in {32, 64}, 3x3 / stride 1).  The product sends it the launches of
+# >= 200 000 pixels (BIG_SHAPES above: 704x800x32, 352x400x64, 301x397x64); here it is FORCED onto small, awkward shapes
+# (option CONV_SP_MIN_PIX = 0): partial tiles in both directions, tiles crossing nothing / everything, several frames, fewer
+# tiles than workgroups, one-pixel-wide tails.
+SP_SHAPES = [
+    (1, 16, 16, 32, 32, 3, 1),
+    (2, 9, 33, 32, 32, 3, 1),        # one pixel into the second tile column; 9 rows = one row into the second tile row
+    (1, 40, 52, 32, 32, 3, 1),
+    (3, 17, 31, 32, 32, 3, 1),
+    (2, 37, 61, 64, 64, 3, 1),
+    (3, 33, 75, 64, 64, 3, 1),
+    (1, 8, 32, 64, 64, 3, 1),        # exactly one tile
+    (1, 95, 129, 64, 64, 3, 1),      # more tiles than one round of workgroups per XCD chunk at 2 per CU
+]
+
+
+@pytest.mark.parametrize("dtype", [1, 2])
+@pytest.mark.parametrize("shape", SP_SHAPES)
+def test_conv_sp_kernel_forced_on_small_shapes(shape, dtype):
+    ops, H = pkg("ops"), pkg("_hip")
+    B, Hh, W, Cin, Cout, k, s = shape
+    x, w = _mk(shape, dtype, 81)
+    shift = rnd((Cout,), 82)
+    ref_lin = F.conv2d(x, w, None, 1, 1)
+    res = q(rnd(tuple(ref_lin.shape), 83), dtype)
+    xd, wd = to_dev(x, dtype), to_dev(w, dtype)
+    xg = x.clone().requires_grad_(True)
+    yr = F.conv2d(xg, w, None, 1, 1)
+    gy = q(rnd(tuple(yr.shape), 84), dtype)
+    yr.backward(gy)
+    wt = w.permute(1, 2, 3, 0).contiguous().cuda().to(TORCH_DT[dtype])
+    gres = q(rnd((B, Cin, Hh, W), 85), dtype)
+    gmask = q(rnd((B, Cin, Hh, W), 86), dtype)
+    try:
+        H.set_option("CONV_SP_MIN_PIX", 0)
+        H.call("dcf_prof_reset")
+        H.call("dcf_prof_enable", 1)
+        y = ops.conv2d_fwd(dtype, xd, wd, None, None, 3, 3, 1, 1, False, Cout)
+        y2 = ops.conv2d_fwd(dtype, xd, wd, shift.cuda(), to_dev(res, dtype), 3, 3, 1, 1, True, Cout)
+        gx = ops.conv2d_dgrad(dtype, to_dev(gy, dtype), wt, None, (B, Hh, W, Cin), 3, 3, 1, 1)
+        gx3 = ops.conv2d_dgrad(dtype, to_dev(gy, dtype), wt, to_dev(gres, dtype), (B, Hh, W, Cin), 3, 3, 1, 1, to_dev(gmask, dtype))
+        torch.cuda.synchronize()
+        H.call("dcf_prof_enable", 0)
+        names = H.prof_read()
+    finally:
+        H.call("dcf_prof_enable", 0)
+        H.call("dcf_prof_reset")
+        H.set_option("CONV_SP_MIN_PIX", None)
+    assert any("<sp%d>" % Cin in n and n.startswith("conv_fwd") for n in names), sorted(names)
+    assert any("<sp%d>" % Cin in n and n.startswith("conv_dgrad") for n in names), sorted(names)
+    _assert_quantised_close(from_dev(y), ref_lin, dtype, "sp plain")
+    _assert_quantised_close(from_dev(y2), torch.relu(ref_lin + shift.view(1, -1, 1, 1) + res), dtype, "sp fused")
+    _assert_quantised_close(from_dev(gx), xg.grad, dtype, "sp dgrad")
+    got3 = from_dev(gx3)
+    _assert_quantised_close(got3, (xg.grad + gres) * (gmask > 0), dtype, "sp dgrad+res+mask")
+    assert float((got3 * (gmask <= 0)).abs().max()) == 0.0

@@ -93,7 +93,8 @@ def test_rccl_bucketed_allreduce_world_size_one(request):
 
     def params_close(a, b, step, what):
         d = (a - b).abs()
-        assert float((d > 1e-5 * float(a.abs().max())).float().mean()) < 1e-3 and float(d.max()) <= 2.5 * lr * (step + 1), what
+        # (Adam divides by sqrt(v): parameters whose gradients are at noise level drift apart by up to +-lr per step in any two runs)
+        assert float((d > 1e-5 * float(a.abs().max())).float().mean()) < 1e-3 * (step + 1) and float(d.max()) <= 2.5 * lr * (step + 1), what
 
     close(ov["grads"][0], plain["grads"][0], "bucketed gradients, step 0")
     for step in range(3):
