@@ -88,6 +88,9 @@ SIGNATURES = {
     "dcf_rowscale_bias_bwd": (c_int, [c_int, P, P, P, c_i64, c_int, P]),
     "dcf_cast": (c_int, [c_int, P, c_int, P, c_i64, P]),
     "dcf_loss_fwd_bwd": (c_int, [P, c_i64, P, c_i64, P, P, P, c_int, c_int, c_float, c_int, P, P, c_i64, P, c_i64, P]),
+    "dcf_loss_sample_rand": (ctypes.c_uint32, [ctypes.c_uint64, c_int, c_int, c_int, c_int]),
+    "dcf_loss_sample_fwd_bwd": (c_int, [P, c_i64, P, c_i64, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
+                                        c_int, c_int, c_int, c_int, ctypes.c_uint64, c_float, c_int, P, P, c_i64, P, c_i64, P, P, P, P]),
     "dcf_adam_step": (c_int, [P, P, P, P, c_i64, c_float, c_float, c_float, c_float, c_int, c_float, P]),
 }
 

@@ -7,6 +7,10 @@ device half (gathers, cross-entropy, Smooth-L1 and their gradients) is ONE HIP l
 (csrc/loss.hip, dcf_loss_fwd_bwd -- SURVEY.md §8(f) row N1); CPU tensors (the host-logic tests) go through
 the same arithmetic as a handful of torch ops.
 
+`loss_sampling: device` moves the target assignment onto the device too (csrc/loss.hip, dcf_loss_sample_fwd_bwd: windows,
+subset, negatives, terms and gradients in one launch, a stateless counter hash seeded by `loss_seed` and the call count
+instead of numpy's generator) -- no host loop, no index lists over PCIe; `compat` (default) is the mode pinned to the reference.
+
 Reference quirks are kept behind `loss_reduction: last` (default): cross-entropy on already
 soft-maxed scores (loss.py:17-20,139), 129 negatives (:125), only the last sample of the
 batch contributes (:71).  'sum' / 'mean' accumulate over the batch instead.
@@ -52,12 +56,52 @@ class _FusedLoss(torch.autograd.Function):
         return g * go, None, None, None, None, None, None, None, None, None
 
 
+class _FusedLossSample(torch.autograd.Function):
+    """dcf_loss_sample_fwd_bwd: target assignment + loss + gradients in one launch (loss_sampling: device)."""
+
+    @staticmethod
+    def forward(ctx, base, cls, reg, anc, boxes, nbox, geo, seed, gain, reduction, outs):
+        from . import _hip as H
+        src = base if base is not None else cls
+        B, _, Hh, W = cls.shape
+        loss = torch.zeros(1, dtype=torch.float32, device=src.device)
+        if base is not None:
+            g = torch.zeros_like(base)
+            gcls, greg = g, g[:, 4:]
+            ctx.split = False
+        else:
+            gcls, greg = torch.zeros_like(cls), torch.zeros_like(reg)
+            g = (gcls, greg)
+            ctx.split = True
+        xs, xo, ys, yo, rs, span, rtype, pos_cap, neg_count = geo
+        H.call("dcf_loss_sample_fwd_bwd", cls, cls.stride(0), reg, reg.stride(0), anc, boxes, nbox, boxes.shape[1], boxes.shape[2], B, Hh, W,
+               float(xs), float(xo), float(ys), float(yo), float(rs), int(span), int(rtype), int(pos_cap), int(neg_count), int(seed),
+               float(gain), int(reduction), loss, gcls, gcls.stride(0), greg, greg.stride(0),
+               None if outs is None else outs[0], None if outs is None else outs[1], None if outs is None else outs[2], H.stream_ptr())
+        ctx.g = g
+        return loss
+
+    @staticmethod
+    def backward(ctx, go):
+        g = ctx.g
+        if ctx.split:
+            return (None, g[0] * go, g[1] * go) + (None,) * 8
+        return (g * go,) + (None,) * 10
+
+
 class LossTotal(nn.Module):
     def __init__(self, config):
         super(LossTotal, self).__init__()
         self.config = config
         self.regress_type = config["regress_type"]
         self.reduction = config.get("loss_reduction", "last")
+        self.sampling = config.get("loss_sampling", "compat")
+        if self.sampling not in ("compat", "device"):
+            raise ValueError("loss_sampling must be compat or device (got %r)" % (self.sampling,))
+        self.seed = int(config.get("loss_seed", 0))
+        self.calls = 0                     # device sampling: the call count enters the hash, so every step draws fresh lists
+        self.last_samples = None           # device sampling with keep_samples: (pos [B,cap], neg [B,n], counts [B,2]) of the last call
+        self.keep_samples = False
         anc = AnchorBoundingBoxFeature(config)()
         self.register_buffer("anchor_set", anc.reshape(2, 7, anc.shape[1], anc.shape[2]), persistent=False)
         L, W = config["voxel_length"], config["voxel_width"]
@@ -136,6 +180,15 @@ class LossTotal(nn.Module):
             head += [o + 6 * B, npos, nneg, nrow, of, nb]
         di, df = self._stage(head + ints, floats, cls.device)
         HW = H * W
+        base, cls, reg = self._head_views(cls, reg, H, W)
+        red = {"last": 0, "sum": 1, "mean": 2}[self.reduction]
+        return _FusedLoss.apply(base, cls, reg, anc, di, df, B, HW, self.config["regress_loss_gain"], red)
+
+    @staticmethod
+    def _head_views(cls, reg, H, W):
+        """(base, cls, reg): base = the contiguous [B,>=18,h,w] head tensor cls / reg are views of (the gradient then goes straight
+        to it), or None."""
+        HW = H * W
         ok = lambda t, c: t.dtype == torch.float32 and t.stride(1) == HW and t.stride(2) == W and t.stride(3) == 1 and t.shape[1] == c
         if not ok(cls, 4):
             cls = cls.float().contiguous()
@@ -145,8 +198,38 @@ class LossTotal(nn.Module):
         if not (base is not None and reg._base is base and base.dim() == 4 and base.is_contiguous() and base.shape[1] >= 18
                 and cls.data_ptr() == base.data_ptr() and reg.data_ptr() == base.data_ptr() + 4 * HW * 4 and base.requires_grad):
             base = None
+        return base, cls, reg
+
+    def _forward_device_sampling(self, boxes, nbox, cls, reg, anc, B, H, W):
+        c = self.config
+        dev = cls.device
+        # labels: [B,max,9] fp32 and the counts, one small asynchronous copy each when they arrive on the host
+        if not boxes.is_cuda:
+            st = getattr(self, "_box_stage", None)
+            if st is None or st[0].shape != boxes.shape:
+                st = [torch.empty(boxes.shape, dtype=torch.float32).pin_memory(), None]
+                self._box_stage = st
+            if st[1] is not None:
+                st[1].synchronize()          # the previous step's copy has long completed
+            st[0].copy_(boxes)
+            boxes = st[0].to(dev, non_blocking=True)
+            st[1] = torch.cuda.Event()
+            st[1].record()
+        else:
+            boxes = boxes.float().contiguous()
+        nb = nbox.to(device=dev, dtype=torch.int32, non_blocking=True) if torch.is_tensor(nbox) else torch.tensor([int(v) for v in nbox], dtype=torch.int32, device=dev)
+        base, cls, reg = self._head_views(cls, reg, H, W)
+        geo = (self._xs, self._xo, self._ys, self._yo, c["anchor_bbox_feature"]["reduced_scale"], c["positive_range"], self.regress_type,
+               c["pos_sample_threshold"], c["neg_sample_threshold"] + 1)
+        outs = None
+        if self.keep_samples:
+            outs = (torch.empty((B, geo[7]), dtype=torch.int32, device=dev), torch.empty((B, geo[8]), dtype=torch.int32, device=dev),
+                    torch.empty((B, 2), dtype=torch.int32, device=dev))
+            self.last_samples = outs
+        seed = (self.seed * 0x9E3779B1 + self.calls) & 0xFFFFFFFFFFFFFFFF
+        self.calls += 1
         red = {"last": 0, "sum": 1, "mean": 2}[self.reduction]
-        return _FusedLoss.apply(base, cls, reg, anc, di, df, B, HW, self.config["regress_loss_gain"], red)
+        return _FusedLossSample.apply(base, cls, reg, anc, boxes, nb, geo, seed, c["regress_loss_gain"], red, outs)
 
     def forward(self, reference_bboxes_batch, num_ref_bbox_batch, predicted_class_feature_batch, predicted_regress_feature_batch):
         cls, reg = predicted_class_feature_batch, predicted_regress_feature_batch
@@ -156,6 +239,10 @@ class LossTotal(nn.Module):
         if getattr(self, "_anc_dev", None) is None or self._anc_dev.device != dev:
             self._anc_dev = self.anchor_set.to(dev).reshape(2, 7, H * W)
         anc = self._anc_dev
+        if self.sampling == "device":
+            if dev.type != "cuda":
+                raise RuntimeError("loss_sampling: device needs CUDA tensors (the host path is loss_sampling: compat)")
+            return self._forward_device_sampling(reference_bboxes_batch, num_ref_bbox_batch, cls, reg, anc, B, H, W)
         # pass CPU boxes (what a DataLoader yields) to avoid a device round trip
         boxes_host = reference_bboxes_batch.detach().cpu() if reference_bboxes_batch.is_cuda else reference_bboxes_batch.detach()
         # ---- host: target assignment for every sample, packed into flat lists

@@ -336,6 +336,23 @@ int dcf_loss_fwd_bwd(const float *cls, int64_t cls_bstride, const float *reg, in
                      const int64_t *ints, const float *floats, int B, int HW, float reg_gain, int reduction,
                      float *loss, float *gcls, int64_t gcls_bstride, float *greg, int64_t greg_bstride, dcf_stream_t stream);
 
+/* The same objective with the target assignment ON THE DEVICE (loss.py:74-127 without the host): per sample the
+ * positive windows (span x span cells around each labelled box's centre cell, fp32 arithmetic as loss.py:85-86), a uniform subset
+ * of pos_cap entries when there are more (loss.py:107-110), neg_count cells drawn with replacement and rejected against the
+ * selected positives (loss.py:117-126), then the terms and gradients of dcf_loss_fwd_bwd -- one launch, one workgroup per sample.
+ * boxes [B][max_box][box_stride] fp32 on the device (x, y, z, l, w, h, yaw first), nbox_dev int32 [B]; xs, xo, ys, yo = grid scale /
+ * offset (data_import_carla.py:35-43), reduced_scale = anchor stride.  Randomness = dcf_loss_sample_rand(seed, sample, stream, index,
+ * attempt), a stateless 64-bit mix (stream 1: subset keys, the pos_cap smallest (key, entry) win; stream 2: negative item `index`,
+ * cell = (rand * H*W) >> 32).  Optional outputs for inspection: pos_out int32 [B][pos_cap] (-1 padded), neg_out [B][neg_count],
+ * counts_out [B][2] = {selected positives, window entries}.  max_box <= 64, max_box * span^2 <= 1024, neg_count <= 512. */
+uint32_t dcf_loss_sample_rand(uint64_t seed, int sample, int stream, int index, int attempt);
+int dcf_loss_sample_fwd_bwd(const float *cls, int64_t cls_bstride, const float *reg, int64_t reg_bstride, const float *anchors,
+                            const float *boxes, const int32_t *nbox_dev, int max_box, int box_stride, int B, int H, int W,
+                            float xs, float xo, float ys, float yo, float reduced_scale, int span, int regress_type, int pos_cap,
+                            int neg_count, uint64_t seed, float reg_gain, int reduction, float *loss, float *gcls,
+                            int64_t gcls_bstride, float *greg, int64_t greg_bstride, int32_t *pos_out, int32_t *neg_out,
+                            int32_t *counts_out, dcf_stream_t stream);
+
 /* ------------------------------------------------- evaluation post-processing
  * What /root/reference/test.py:88-206 does on the host, box by box.
  * dcf_eval_score_filter: test.py:88-108.  pred [B][32][h][w] fp32 (the model output: scores in channels 2a+1, decoded boxes in

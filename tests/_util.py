@@ -48,3 +48,18 @@ def q(x, dtype):
 
 def rel_err(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+# ---- the stateless sampler hash of csrc/loss.hip (dcf_loss_sample_rand), restated
+M64 = (1 << 64) - 1
+
+
+def mix64(z):
+    z = (z + 0x9E3779B97F4A7C15) & M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return z ^ (z >> 31)
+
+
+def rand32(seed, sample, stream, index, attempt):
+    return mix64(seed ^ mix64((sample << 44) | (stream << 40) | (attempt << 20) | index)) >> 32

@@ -4,7 +4,7 @@ import ctypes
 import os
 import re
 
-from _util import ROOT, pkg
+from _util import M64, ROOT, pkg, rand32
 
 
 def declared_symbols():
@@ -56,3 +56,11 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         raise AssertionError("expected DcfError")
     except H.DcfError as e:
         assert "no CPU fallback" in str(e)
+
+
+def test_sampler_hash_restatement_equals_the_library():
+    """dcf_loss_sample_rand (host-callable; the device sampler of loss_sampling: device uses the same function) against the Python
+    restatement the GPU tests build their expected lists from."""
+    lib = pkg("_hip").lib()
+    for args in ((0, 0, 1, 0, 0), (12345678901234567, 3, 2, 511, 7), (M64, 15, 1, 1023, 0), (42, 1, 2, 128, 1000), (2 ** 63 + 5, 7, 2, 99999, 3)):
+        assert lib.dcf_loss_sample_rand(*args) == rand32(*args)
