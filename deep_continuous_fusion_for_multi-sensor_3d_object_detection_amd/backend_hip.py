@@ -310,6 +310,7 @@ class HipBackend(object):
         self._wq = []                      # the launches are enqueued: x / gy may be released (same stream)
 
     _wq = []
+    _fus_ws = None
     _group = os.environ.get("DCF_WGRAD_GROUP", "1") != "0"
     # one-writer-per-point fusion backward (dcf_fusion_gather_bwd_pts: no zero-fill, no atomics on dP, no cast): correct, but a
     # point that thousands of pixels chose is then one wave's serial work -- measured 1.07 vs 0.30 ms per step at cfg2, so off
@@ -426,8 +427,10 @@ class HipBackend(object):
         gP = torch.zeros(P.shape, dtype=torch.float32, device=self.dev)
         for b in range(P.shape[0]):
             if use_inv:
+                if self._fus_ws is None:
+                    self._fus_ws = ops.fusion_bwd_workspace(self.dev)         # zeroed once: the kernel leaves its ticket word at zero
                 ops.fusion_gather_bwd_inv(self.dtype, P[b], xyz[b], inv, inv_nmax or P.shape[1], site * P.shape[0] + b, tuple(idx.shape[-3:]), stride, aff, self.params[w1d_off:],
-                                          self.params[b1_off:], ghsum[b], gP[b], self.grads[w1d_off:], self.grads[b1_off:])
+                                          self.params[b1_off:], ghsum[b], gP[b], self.grads[w1d_off:], self.grads[b1_off:], self._fus_ws)
             else:
                 ops.fusion_gather_bwd(self.dtype, P[b], xyz[b], idx[b], stride, aff, self.params[w1d_off:], self.params[b1_off:],
                                       ghsum[b], gP[b], self.grads[w1d_off:], self.grads[b1_off:])

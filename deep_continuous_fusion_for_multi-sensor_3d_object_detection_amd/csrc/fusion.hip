@@ -297,6 +297,7 @@ __global__ void __launch_bounds__(256) k_fusion_gather_bwd_pipe(const T *__restr
 // 16 waves per workgroup: the number of workgroups is capped (each ends with C x 4 same-address atomics on dW1d / db1), so
 // the waves that hide the gather latency have to come from inside the workgroup
 constexpr int FGI_THREADS = 1024;
+constexpr int FG_NSLOT = 16;          // copies of the dW1d / db1 accumulators in the workspace (see the end of the kernel)
 // EXCL: instead of slices of pairs, a wave owns a range of POINTS (all pairs of its points: start[p0] .. start[p1]), so every
 // row of gP has exactly one writer: it is stored whole in the compute type (zeros for points without pairs) -- no zero-fill
 // of an fp32 accumulator before, no float atomics, no cast kernel after.  e_begin then points at start[0] of the map, SL is
@@ -305,7 +306,7 @@ template <typename T, int CJ, bool EXCL>
 __global__ void __launch_bounds__(CJ >= 4 ? FGI_THREADS / 2 : FGI_THREADS) k_fusion_gather_bwd_inv(const T *__restrict__ P, const float *__restrict__ xyz, const int *__restrict__ e_begin, const int *__restrict__ e_end,
                                                                const int *__restrict__ ent_pix, const int *__restrict__ ent_pt, FuseGeom g,
                                                                const float *__restrict__ w1d, const float *__restrict__ b1, int C,
-                                                               const T *__restrict__ ghsum, void *gPv, float *gw1d, float *gb1, int SL)
+                                                               const T *__restrict__ ghsum, void *gPv, float *gw1d, float *gb1, int SL, float *part)
 {
     float *gP = reinterpret_cast<float *>(gPv);
     T *gPt = reinterpret_cast<T *>(gPv);
@@ -423,12 +424,42 @@ __global__ void __launch_bounds__(CJ >= 4 ? FGI_THREADS / 2 : FGI_THREADS) k_fus
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += blockDim.x) {
-        atomicAdd(&gw1d[i * 3 + 0], sm[i * 4 + 0]);
-        atomicAdd(&gw1d[i * 3 + 1], sm[i * 4 + 1]);
-        atomicAdd(&gw1d[i * 3 + 2], sm[i * 4 + 2]);
-        atomicAdd(&gb1[i], sm[i * 4 + 3]);
+    if (part == nullptr) {                         // no workspace: C x 4 device-scope atomics per workgroup, all on the same addresses
+        for (int i = threadIdx.x; i < C; i += blockDim.x) {
+            atomicAdd(&gw1d[i * 3 + 0], sm[i * 4 + 0]);
+            atomicAdd(&gw1d[i * 3 + 1], sm[i * 4 + 1]);
+            atomicAdd(&gw1d[i * 3 + 2], sm[i * 4 + 2]);
+            atomicAdd(&gb1[i], sm[i * 4 + 3]);
+        }
+        return;
     }
+    // Slotted reduction: 256 workgroups adding onto the SAME C x 4 addresses serialise per address (~15 of the ~46 us of a big
+    // site's launch, measured by leaving the atomics out).  With a workspace every workgroup adds its sums into one of
+    // FG_NSLOT copies (16 contenders per address instead of 256), takes a ticket once its atomics have been acknowledged, and
+    // the LAST workgroup folds the copies into dW1d / db1 (atomic exchanges: coherent reads that also clear the copies for
+    // the next launch).  No fences: everything that crosses workgroups is a device-scope atomic.  (A first version published
+    // per-workgroup rows behind an agent-scope release: the release writes back the L2 lines the dP atomics had dirtied --
+    // +50 us per launch.)  Workspace = ticket word at float 0, copies [FG_NSLOT][1024] from float 64; zero on entry, left zero.
+    const int n4 = C * 4;
+    unsigned *ticket = reinterpret_cast<unsigned *>(part);
+    float *slots = part + 64;
+    float *mine = slots + (blockIdx.x % FG_NSLOT) * 1024;
+    for (int i = threadIdx.x; i < n4; i += blockDim.x)
+        if (sm[i] != 0.f) atomicAdd(&mine[i], sm[i]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int s_last;
+    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < FG_NSLOT; ++q) tot += atomicExch(&slots[q * 1024 + i], 0.f);
+        const int c = i >> 2, q = i & 3;
+        if (q < 3) gw1d[c * 3 + q] += tot; else gb1[c] += tot;
+    }
+    if (threadIdx.x == 0) atomicExch(ticket, 0u);            // ready for the next launch on this stream
 }
 
 }  // namespace
@@ -501,11 +532,14 @@ extern "C" int dcf_fusion_gather_bwd(int dtype, const void *P, const float *xyz,
     return DCF_OK;
 }
 
+extern "C" size_t dcf_fusion_gather_bwd_workspace_bytes(int Cb) { (void)Cb; return ((size_t)FG_NSLOT * 1024 + 64) * sizeof(float); }
+
 extern "C" int dcf_fusion_gather_bwd_inv(int dtype, const void *P, const float *xyz, const int32_t *e_begin, const int32_t *e_end, const int32_t *ent_pix,
                                          const int32_t *ent_pt, int max_entries, int h, int w, int stride, float xs, float xo, float ys,
                                          float yo, const float *w1d, const float *b1, int Cb, const void *ghsum, float *gP, float *gw1d,
-                                         float *gb1, dcf_stream_t stream)
+                                         float *gb1, void *workspace, dcf_stream_t stream)
 {
+    float *ws = reinterpret_cast<float *>(workspace);
     DCF_REQUIRE(P && xyz && e_begin && e_end && ent_pix && ent_pt && w1d && b1 && ghsum && gP && gw1d && gb1, "dcf_fusion_gather_bwd_inv: null pointer");
     DCF_REQUIRE(Cb % 64 == 0 && Cb >= 64 && Cb <= 256, "dcf_fusion_gather_bwd_inv: Cb must be 64, 128, 192 or 256 (got %d)", Cb);
     if (max_entries <= 0) return DCF_OK;
@@ -523,7 +557,7 @@ extern "C" int dcf_fusion_gather_bwd_inv(int dtype, const void *P, const float *
     const int thr = Cb >= 256 ? FGI_THREADS / 2 : FGI_THREADS;
     const int blocks = std::min(cdiv(waves, thr / 64), cap);
     // (one profile name per instantiation, as rocprofv3 lists them: the four sites run four different kernels)
-#define DCF_FGI(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_inv<" #CJ_ ">", (double)max_entries * (8.0 + 2.0 * Cb * sizeof(T)), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_, false>), dim3(blocks), dim3(thr), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, sl))
+#define DCF_FGI(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_inv<" #CJ_ ">", (double)max_entries * (8.0 + 2.0 * Cb * sizeof(T)), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_, false>), dim3(blocks), dim3(thr), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, sl, ws))
     DCF_DISPATCH_DTYPE(dtype, {
         if (Cb == 64) DCF_FGI(1);
         else if (Cb == 128) DCF_FGI(2);
@@ -552,7 +586,7 @@ extern "C" int dcf_fusion_gather_bwd_pts(int dtype, const void *P, const float *
     const int cap = cap_env ? atoi(cap_env) : 256;
     const int thr = Cb >= 256 ? FGI_THREADS / 2 : FGI_THREADS;
     const int blocks = std::min(cdiv(n_rows, thr / 64), cap);
-#define DCF_FGP(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_pts", (double)max_entries * (8.0 + 2.0 * Cb * sizeof(T)) + (double)n_rows * Cb * sizeof(T), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_, true>), dim3(blocks), dim3(thr), sizeof(float) * Cb * 4, s, (const T *)P, xyz, start, start, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, n_rows))
+#define DCF_FGP(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_pts", (double)max_entries * (8.0 + 2.0 * Cb * sizeof(T)) + (double)n_rows * Cb * sizeof(T), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_, true>), dim3(blocks), dim3(thr), sizeof(float) * Cb * 4, s, (const T *)P, xyz, start, start, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, n_rows, (float *)nullptr))
     DCF_DISPATCH_DTYPE(dtype, {
         if (Cb == 64) DCF_FGP(1);
         else if (Cb == 128) DCF_FGP(2);

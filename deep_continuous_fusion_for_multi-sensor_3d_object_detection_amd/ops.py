@@ -412,14 +412,23 @@ def fusion_invert(maps, n_max, out=None):
     return start, ent
 
 
-def fusion_gather_bwd_inv(dtype, P, xyz, inv, n_max, g, khw, stride, aff, w1d, b1, ghsum, gP, gw1d, gb1):
+def fusion_bwd_workspace(device, Cb=256):
+    """Zeroed workspace of fusion_gather_bwd_inv's slotted dW1d / db1 reduction (left zero: reusable by calls ordered on one stream)."""
+    return torch.zeros((H.lib().dcf_fusion_gather_bwd_workspace_bytes(Cb) // 4,), dtype=torch.float32, device=device)
+
+
+def fusion_gather_bwd_inv(dtype, P, xyz, inv, n_max, g, khw, stride, aff, w1d, b1, ghsum, gP, gw1d, gb1, ws=None):
     """n_max: the point-id range fusion_invert was called with; g: index of this (site, frame) map in that call;
-    khw = (K, h, w) of the map.  P / gP may hold fewer rows than n_max (only ids below the valid count occur)."""
+    khw = (K, h, w) of the map.  P / gP may hold fewer rows than n_max (only ids below the valid count occur).
+    ws: fusion_bwd_workspace() -> gw1d / gb1 through 16 accumulator copies folded by the last workgroup (16 instead of 256
+    same-address atomics per word)."""
     start, ent = inv
     Cb = P.shape[1]
     seg = start[g * (n_max + 1):]
+    if ws is not None and ws.numel() * 4 < H.lib().dcf_fusion_gather_bwd_workspace_bytes(Cb):
+        raise H.DcfError("fusion_gather_bwd_inv: workspace too small for %d channels" % Cb)
     H.call("dcf_fusion_gather_bwd_inv", dtype, P, xyz, seg, seg[n_max:], ent[0], ent[1], khw[0] * khw[1] * khw[2], khw[1], khw[2], stride,
-           float(aff[0]), float(aff[1]), float(aff[2]), float(aff[3]), w1d, b1, Cb, ghsum, gP, gw1d, gb1, H.stream_ptr())
+           float(aff[0]), float(aff[1]), float(aff[2]), float(aff[3]), w1d, b1, Cb, ghsum, gP, gw1d, gb1, ws, H.stream_ptr())
 
 
 def rowscale_bias_fwd(dtype, y, cnt, b2):

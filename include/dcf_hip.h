@@ -310,11 +310,16 @@ int dcf_adam_step(float *params, const float *grads, float *m, float *v, int64_t
 
 /* dcf_fusion_gather_bwd driven by dcf_fusion_invert's pairs (Cb in {64,128,192,256}): same sums, no idx -> point -> row
  * dependency chain.  The map's pairs are [*e_begin, *e_end) = start[g*(n_max+1)], start[g*(n_max+1)+n_max];
- * max_entries = K*h*w sizes the grid. */
+ * max_entries = K*h*w sizes the grid.
+ * workspace (optional, dcf_fusion_gather_bwd_workspace_bytes(Cb), ZERO before its first use, left zero = reusable): with it the
+ * workgroups' sums of gw1d / gb1 go through 16 copies of the accumulators that the last-arriving workgroup folds (16 instead of
+ * 256 same-address atomics per word); NULL: float atomics straight onto gw1d / gb1.  Calls that share a workspace must be
+ * ordered on one stream. */
+size_t dcf_fusion_gather_bwd_workspace_bytes(int Cb);
 int dcf_fusion_gather_bwd_inv(int dtype, const void *P, const float *xyz, const int32_t *e_begin, const int32_t *e_end,
                               const int32_t *ent_pix, const int32_t *ent_pt, int max_entries, int h, int w, int stride, float xs,
                               float xo, float ys, float yo, const float *w1d, const float *b1, int Cb, const void *ghsum, float *gP,
-                              float *gw1d, float *gb1, dcf_stream_t stream);
+                              float *gw1d, float *gb1, void *workspace, dcf_stream_t stream);
 
 /* The same sums with ONE writer per point row (a wave owns a range of points and all their pairs): gP [n_rows][Cb] in the compute
  * dtype, every row written (zeros where no pixel chose the point) -- no zero-filled fp32 accumulator, no float atomics on gP, no

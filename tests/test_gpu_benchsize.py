@@ -82,6 +82,7 @@ def test_fusion_backward_by_point_at_cfg2_size(K, dtype):
     code = H.dtype_code(dtype)
     tdt = H.torch_dtype(code)
     gen = torch.Generator().manual_seed(100 + K)
+    ws = ops.fusion_bwd_workspace("cuda")              # one workspace for all sites, as the backend uses it (zeroed once)
     for si, (stride, Cb) in enumerate(sites):
         h, w = 704 // stride, 800 // stride
         idx = maps[si].cpu()
@@ -92,8 +93,22 @@ def test_fusion_backward_by_point_at_cfg2_size(K, dtype):
         b1 = (torch.rand(Cb, generator=gen) - 0.5) * 0.2
         got = [torch.zeros(rows, Cb, device="cuda"), torch.zeros(Cb * 3, device="cuda"), torch.zeros(Cb, device="cuda")]
         ops.fusion_gather_bwd_inv(code, P.cuda(), xyz_d, inv, n_max, si, (K, h, w), stride, g.aff, w1d.reshape(-1).cuda(), b1.cuda(),
-                                  ghs.cuda(), *got)
+                                  ghs.cuda(), *got, ws=ws)
         want, slack = fusion_bwd_statement(P.float(), xyz, idx, stride, g.aff, w1d, b1, ghs.float())
+        # the workspace path ACCUMULATES into gw1d / gb1 like the plain atomics (the frames of a batch add up) and leaves the
+        # workspace reusable: a second launch doubles the sums
+        again = [torch.zeros(rows, Cb, device="cuda"), got[1].clone(), got[2].clone()]
+        ops.fusion_gather_bwd_inv(code, P.cuda(), xyz_d, inv, n_max, si, (K, h, w), stride, g.aff, w1d.reshape(-1).cuda(), b1.cuda(),
+                                  ghs.cuda(), *again, ws=ws)
+        for a_, b_ in zip(again[1:], got[1:]):
+            assert float((a_ - 2.0 * b_).abs().max()) <= 1e-4 * float(b_.abs().max())
+        assert float(ws.abs().max()) == 0.0
+        # ... and without a workspace (float atomics) the same sums
+        plain = [torch.zeros(rows, Cb, device="cuda"), torch.zeros(Cb * 3, device="cuda"), torch.zeros(Cb, device="cuda")]
+        ops.fusion_gather_bwd_inv(code, P.cuda(), xyz_d, inv, n_max, si, (K, h, w), stride, g.aff, w1d.reshape(-1).cuda(), b1.cuda(),
+                                  ghs.cuda(), *plain)
+        for a_, b_ in zip(plain[1:], got[1:]):
+            assert float((a_ - b_).abs().max()) <= 1e-4 * float(b_.abs().max())
         got = [got[0].cpu().double(), got[1].cpu().double().view(Cb, 3), got[2].cpu().double()]
         for name, a, b, s_, tol in (("dP", got[0], want[0], slack[0], 2e-5), ("dW1d", got[1], want[1], slack[1], 3e-4), ("db1", got[2], want[2], slack[2], 3e-4)):
             scale = float(b.abs().max())

@@ -221,6 +221,11 @@ def test_fusion_backward_by_point_matches_pixel_run_kernel(Cb, K, case):
         start = inv[0].cpu()
         assert int(start[0]) == 0 and int(start[n_max]) == min(K, n) * h * w
         ops.fusion_gather_bwd_inv(dtype, Pd, xyz, inv, n_max, 0, (K, h, w), stride, aff, w1d, b1, gd, *got)
+        got_ws = [torch.zeros_like(t) for t in ref]          # ... and with the workspace (last-arriver reduction of dW1d / db1)
+        ops.fusion_gather_bwd_inv(dtype, Pd, xyz, inv, n_max, 0, (K, h, w), stride, aff, w1d, b1, gd, *got_ws, ws=ops.fusion_bwd_workspace("cuda", Cb))
+        for a, b in zip(got_ws, ref):
+            scale = max(float(b.abs().max()), 1e-6)
+            assert float((a - b).abs().max()) <= tol * scale * max(1.0, (h * w) ** 0.5), (case, Cb, "workspace")
         for a, b in zip(got, ref):
             scale = max(float(b.abs().max()), 1e-6)
             assert float((a - b).abs().max()) <= tol * scale * max(1.0, (h * w) ** 0.5), (case, Cb, float((a - b).abs().max()), scale)
