@@ -78,6 +78,10 @@ SIGNATURES = {
     "dcf_head_bwd": (c_int, [c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
     "dcf_point_sample_fwd": (c_int, [c_int, P, c_int, c_int, c_int, P, P, c_int, P, P]),
     "dcf_point_sample_bwd": (c_int, [c_int, P, c_int, c_int, c_int, P, P, c_int, P, P]),
+    "dcf_point_sample_fwd_batch": (c_int, [c_int, P, c_int, c_int, c_int, P, c_i64, P, c_int, P, c_int, P]),
+    "dcf_point_sample_bwd_batch": (c_int, [c_int, P, c_int, c_int, c_int, P, c_i64, P, c_int, P, c_int, P]),
+    "dcf_fusion_gather_fwd_batch": (c_int, [c_int, P, c_i64, P, c_i64, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P, P, c_int, P, P, c_int, P]),
+    "dcf_fusion_gather_bwd_inv_batch": (c_int, [c_int, P, c_i64, P, c_i64, P, P, c_i64, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P, P, c_int, P, P, P, P, P, c_int, P]),
     "dcf_fusion_gather_fwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P, P, c_int, P, P, P]),
     "dcf_fusion_gather_bwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P, P, c_int, P, P, P, P, P]),
     "dcf_fusion_invert_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -156,9 +160,17 @@ def lib():
     return _LIB
 
 
+_Tensor = torch.Tensor
+_Param = torch.nn.Parameter
+
+
 def _ptr(t):
-    if t is None:
-        return None
+    # hot path (~20 arguments per launch, ~230 launches per step): exact-type tests first, isinstance only for the rest
+    tt = type(t)
+    if tt is int or tt is float or t is None:
+        return t
+    if tt is _Tensor or tt is _Param:
+        return t.data_ptr()
     if isinstance(t, torch.Tensor):
         return t.data_ptr()
     if isinstance(t, np.ndarray):
@@ -167,22 +179,29 @@ def _ptr(t):
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_device = torch._C._cuda_getDevice if hasattr(torch._C, "_cuda_getDevice") else None
 
 
 def stream_ptr():
     """hipStream_t of torch's current stream on the current device (every launch goes onto it)."""
     if _raw_stream is not None:          # one C call instead of torch.cuda.current_stream()'s Python layers (~7 us, x600 per step)
-        return _raw_stream(torch._C._cuda_getDevice())
+        return _raw_stream(_get_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+_FN = {}                # name -> (bound foreign function, raises on a non-zero status)
+_NO_RAISE = ("dcf_version", "dcf_conv2d_wgrad_splits", "dcf_prof_read", "dcf_conv2d_wgrad_groupable")
 
 
 def call(name, *args):
     """Invoke dcf_<name>; tensors/ndarrays become raw pointers; non-zero status raises."""
-    L = lib()
-    fn = getattr(L, name)
-    rc = fn(*[_ptr(a) for a in args])
-    if fn.restype is c_int and rc != 0 and name not in ("dcf_version", "dcf_conv2d_wgrad_splits", "dcf_prof_read", "dcf_conv2d_wgrad_groupable"):
-        raise DcfError("%s failed (%d): %s" % (name, rc, L.dcf_last_error().decode()))
+    ent = _FN.get(name)
+    if ent is None:
+        fn = getattr(lib(), name)
+        ent = _FN[name] = (fn, fn.restype is c_int and name not in _NO_RAISE)
+    rc = ent[0](*[_ptr(a) for a in args])
+    if rc != 0 and ent[1]:
+        raise DcfError("%s failed (%d): %s" % (name, rc, lib().dcf_last_error().decode()))
     return rc
 
 

@@ -168,6 +168,7 @@ class HipBackend(object):
         else:
             self.grads.zero_()
         self._wq = []                      # weight gradients collected by a backward that did not finish are dropped
+        self._gp_pool = None               # the fusion backward's fp32 accumulators: one buffer, one fill per backward
         self.__dict__.pop("_done", None)   # ... and so is its half-finished bucket state (a backward that raised after bucket_ready)
 
     # Gradient buckets (data parallel): the layer table is ordered LiDAR stream | camera stream | fusion layers, and so is
@@ -311,6 +312,7 @@ class HipBackend(object):
 
     _wq = []
     _fus_ws = None
+    _gp_pool = None
     _group = os.environ.get("DCF_WGRAD_GROUP", "1") != "0"
     # one-writer-per-point fusion backward (dcf_fusion_gather_bwd_pts: no zero-fill, no atomics on dP, no cast): correct, but a
     # point that thousands of pixels chose is then one wave's serial work -- measured 1.07 vs 0.30 ms per step at cfg2, so off
@@ -394,6 +396,8 @@ class HipBackend(object):
     def point_sample_fwd(self, fmap, uv, cnt, n_max):
         B = fmap.shape[0]
         fp = torch.zeros((B, max(n_max, 1), fmap.shape[-1]), dtype=fmap.dtype, device=fmap.device)      # frames side by side: one fill, no stack copy
+        if uv.is_contiguous() and cnt.is_contiguous() and n_max > 0:
+            return ops.point_sample_fwd_batch(self.dtype, fmap, uv, cnt, n_max, fp)               # one launch for the batch
         for b in range(B):
             ops.point_sample_fwd(self.dtype, fmap[b], uv[b], cnt[b:b + 1], n_max, out=fp[b])
         return fp
@@ -401,6 +405,8 @@ class HipBackend(object):
     def point_sample_bwd(self, gfp, uv, cnt, n_max, fmap_shape, gF):
         if gF is None:
             gF = torch.zeros(fmap_shape, dtype=torch.float32, device=self.dev)
+        if uv.is_contiguous() and cnt.is_contiguous() and gfp.is_contiguous() and n_max > 0 and gfp.shape[1] == n_max:
+            return ops.point_sample_bwd_batch(self.dtype, gfp, uv, cnt, n_max, gF)
         for b in range(gfp.shape[0]):
             ops.point_sample_bwd(self.dtype, gfp[b], uv[b], cnt[b:b + 1], n_max, gF[b])
         return gF
@@ -409,6 +415,8 @@ class HipBackend(object):
         B, (K_, h, w) = P.shape[0], idx.shape[-3:]
         hsum = torch.empty((B, h, w, P.shape[2]), dtype=P.dtype, device=P.device)
         cnt = torch.empty((B, h * w), dtype=torch.float32, device=P.device)
+        if P.is_contiguous() and xyz.is_contiguous() and idx.is_contiguous():
+            return ops.fusion_gather_fwd_batch(self.dtype, P, xyz, idx, stride, aff, self.params[w1d_off:], self.params[b1_off:], hsum, cnt)
         for b in range(B):
             ops.fusion_gather_fwd(self.dtype, P[b], xyz[b], idx[b], stride, aff, self.params[w1d_off:], self.params[b1_off:], out=(hsum[b], cnt[b]))
         return hsum, cnt
@@ -424,17 +432,35 @@ class HipBackend(object):
                 ops.fusion_gather_bwd_pts(self.dtype, P[b], xyz[b], inv, inv_nmax or P.shape[1], site * P.shape[0] + b, tuple(idx.shape[-3:]), stride, aff,
                                           self.params[w1d_off:], self.params[b1_off:], ghsum[b], gP[b], self.grads[w1d_off:], self.grads[b1_off:])
             return gP
-        gP = torch.zeros(P.shape, dtype=torch.float32, device=self.dev)
+        gP = self._gp_zeros(P.shape)
+        if use_inv:
+            if self._fus_ws is None:
+                self._fus_ws = ops.fusion_bwd_workspace(self.dev)             # zeroed once: the kernel leaves it zero
+            if P.is_contiguous() and xyz.is_contiguous() and ghsum.is_contiguous() and P.shape[0] <= 64:
+                ops.fusion_gather_bwd_inv_batch(self.dtype, P, xyz, inv, inv_nmax or P.shape[1], site * P.shape[0], tuple(idx.shape[-3:]), stride, aff,
+                                                self.params[w1d_off:], self.params[b1_off:], ghsum, gP, self.grads[w1d_off:], self.grads[b1_off:], self._fus_ws)
+                return gP
         for b in range(P.shape[0]):
             if use_inv:
-                if self._fus_ws is None:
-                    self._fus_ws = ops.fusion_bwd_workspace(self.dev)         # zeroed once: the kernel leaves its ticket word at zero
                 ops.fusion_gather_bwd_inv(self.dtype, P[b], xyz[b], inv, inv_nmax or P.shape[1], site * P.shape[0] + b, tuple(idx.shape[-3:]), stride, aff, self.params[w1d_off:],
                                           self.params[b1_off:], ghsum[b], gP[b], self.grads[w1d_off:], self.grads[b1_off:], self._fus_ws)
             else:
                 ops.fusion_gather_bwd(self.dtype, P[b], xyz[b], idx[b], stride, aff, self.params[w1d_off:], self.params[b1_off:],
                                       ghsum[b], gP[b], self.grads[w1d_off:], self.grads[b1_off:])
         return gP
+
+    def _gp_zeros(self, shape):
+        """Zeroed fp32 [B, rows, Cb] accumulator of a site's fusion backward.  The sites of one backward (same B and rows) are carved
+        out of ONE buffer zeroed by one fill when the first of them asks: four fills per step become one."""
+        B, rows, cb = shape
+        pool = self._gp_pool
+        need = B * rows * cb
+        if pool is None or pool[1] != (B, rows) or pool[2] + need > pool[0].numel():
+            total = B * rows * sum(f["cb"] for f in self.plan.fusion) if getattr(self.plan, "fusion", None) else need
+            pool = self._gp_pool = [torch.zeros(max(total, need), dtype=torch.float32, device=self.dev), (B, rows), 0]
+        off = pool[2]
+        pool[2] = off + need
+        return pool[0][off:off + need].view(B, rows, cb)
 
     def rowscale_bias_fwd(self, y, cnt, b2_off):
         return ops.rowscale_bias_fwd(self.dtype, y, cnt, self.params[b2_off:])

@@ -38,9 +38,16 @@ __device__ __forceinline__ Taps make_taps(float u, float v, int Hf, int Wf)
     return t;
 }
 
+// Batched launches (grid.y = frame of the batch): element strides between the frames' tensors; all zero for a single frame.
+struct FrameStride {
+    int64_t a, b, c, d, e;
+};
+
 template <typename T>
-__global__ void __launch_bounds__(256) k_point_sample_fwd(const T *fmap, int Hf, int Wf, int C4, const float *uv, const int *count, int n_max, T *fp)
+__global__ void __launch_bounds__(256) k_point_sample_fwd(const T *fmap, int Hf, int Wf, int C4, const float *uv, const int *count, int n_max, T *fp,
+                                                          FrameStride fs)
 {
+    fmap += blockIdx.y * fs.a; uv += blockIdx.y * fs.b; count += blockIdx.y * fs.c; fp += blockIdx.y * fs.d;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int n = min(*count, n_max);
     const int64_t p = e / C4;
@@ -67,8 +74,9 @@ __device__ __forceinline__ void atomic_add4(float *p, float4 v, float w)
 // (256 B per 64 channels), the shape the memory-side atomic units run at full rate on.
 template <typename T>
 __global__ void __launch_bounds__(256) k_point_sample_bwd(const T *gfp, int Hf, int Wf, int C, const float *uv, const int *count, int n_max,
-                                                          float *gfmap)
+                                                          float *gfmap, FrameStride fs)
 {
+    gfp += blockIdx.y * fs.a; uv += blockIdx.y * fs.b; count += blockIdx.y * fs.c; gfmap += blockIdx.y * fs.d;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int n = min(*count, n_max);
     const int64_t p = e / C;
@@ -96,8 +104,9 @@ __device__ __forceinline__ void pixel_centre(const FuseGeom &g, int i, int j, fl
 
 template <typename T>
 __global__ void __launch_bounds__(256) k_fusion_gather_fwd(const T *P, const float *xyz, const int *idx, FuseGeom g, const float *w1d,
-                                                           const float *b1, int C4, T *hsum, float *cnt)
+                                                           const float *b1, int C4, T *hsum, float *cnt, FrameStride fs)
 {
+    P += blockIdx.y * fs.a; xyz += blockIdx.y * fs.b; idx += blockIdx.y * fs.c; hsum += blockIdx.y * fs.d; cnt += blockIdx.y * fs.e;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int hw = g.h * g.w;
     const int64_t p = e / C4;
@@ -306,10 +315,13 @@ template <typename T, int CJ, bool EXCL>
 __global__ void __launch_bounds__(CJ >= 4 ? FGI_THREADS / 2 : FGI_THREADS) k_fusion_gather_bwd_inv(const T *__restrict__ P, const float *__restrict__ xyz, const int *__restrict__ e_begin, const int *__restrict__ e_end,
                                                                const int *__restrict__ ent_pix, const int *__restrict__ ent_pt, FuseGeom g,
                                                                const float *__restrict__ w1d, const float *__restrict__ b1, int C,
-                                                               const T *__restrict__ ghsum, void *gPv, float *gw1d, float *gb1, int SL, float *part)
+                                                               const T *__restrict__ ghsum, void *gPv, float *gw1d, float *gb1, int SL, float *part,
+                                                               FrameStride fs)
 {
-    float *gP = reinterpret_cast<float *>(gPv);
-    T *gPt = reinterpret_cast<T *>(gPv);
+    // batched launch: frame blockIdx.y -- P / gP rows (a), xyz (b), the map's start segment (c: e_begin and e_end), ghsum (d)
+    P += blockIdx.y * fs.a; xyz += blockIdx.y * fs.b; e_begin += blockIdx.y * fs.c; e_end += blockIdx.y * fs.c; ghsum += blockIdx.y * fs.d;
+    float *gP = reinterpret_cast<float *>(gPv) + (EXCL ? 0 : blockIdx.y * fs.a);
+    T *gPt = reinterpret_cast<T *>(gPv) + (EXCL ? blockIdx.y * fs.a : 0);
     constexpr int U = 8;
     extern __shared__ float sm[];  // [C][4]: gw1d x3, gb1
     for (int i = threadIdx.x; i < C * 4; i += blockDim.x) sm[i] = 0.f;
@@ -443,13 +455,13 @@ __global__ void __launch_bounds__(CJ >= 4 ? FGI_THREADS / 2 : FGI_THREADS) k_fus
     const int n4 = C * 4;
     unsigned *ticket = reinterpret_cast<unsigned *>(part);
     float *slots = part + 64;
-    float *mine = slots + (blockIdx.x % FG_NSLOT) * 1024;
+    float *mine = slots + ((blockIdx.x + blockIdx.y * gridDim.x) % FG_NSLOT) * 1024;
     for (int i = threadIdx.x; i < n4; i += blockDim.x)
         if (sm[i] != 0.f) atomicAdd(&mine[i], sm[i]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ int s_last;
-    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x * gridDim.y - 1 ? 1 : 0;
     __syncthreads();
     if (!s_last) return;
     for (int i = threadIdx.x; i < n4; i += blockDim.x) {
@@ -465,25 +477,62 @@ __global__ void __launch_bounds__(CJ >= 4 ? FGI_THREADS / 2 : FGI_THREADS) k_fus
 }  // namespace
 
 // ================================================================== C ABI
+static int point_sample_fwd_impl(const char *who, int dtype, const void *fmap, int Hf, int Wf, int Cf, const float *uv, int64_t uv_fstride,
+                                 const int32_t *count_dev, int n_max, void *fp, int B, hipStream_t s)
+{
+    DCF_REQUIRE(fmap && uv && count_dev && fp && Cf % 4 == 0 && B >= 1 && B <= 65535, "%s: bad arguments", who);
+    if (n_max == 0) return DCF_OK;
+    const int64_t total = (int64_t)n_max * (Cf / 4);
+    const FrameStride fs = {(int64_t)Hf * Wf * Cf, uv_fstride, 1, (int64_t)n_max * Cf, 0};
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("point_sample_fwd", (double)B * n_max * (5.0 * Cf * sizeof(T) + 8.0), s, hipLaunchKernelGGL(k_point_sample_fwd<T>, dim3(cdiv(total, 256), B), dim3(256), 0, s, (const T *)fmap, Hf, Wf, Cf / 4, uv, count_dev, n_max, (T *)fp, fs)); })
+    return DCF_OK;
+}
+
 extern "C" int dcf_point_sample_fwd(int dtype, const void *fmap, int Hf, int Wf, int Cf, const float *uv, const int32_t *count_dev,
                                     int n_max, void *fp, dcf_stream_t stream)
 {
-    DCF_REQUIRE(fmap && uv && count_dev && fp && Cf % 4 == 0, "dcf_point_sample_fwd: bad arguments");
+    return point_sample_fwd_impl("dcf_point_sample_fwd", dtype, fmap, Hf, Wf, Cf, uv, 0, count_dev, n_max, fp, 1, S(stream));
+}
+
+extern "C" int dcf_point_sample_fwd_batch(int dtype, const void *fmap, int Hf, int Wf, int Cf, const float *uv, int64_t uv_fstride,
+                                          const int32_t *count_dev, int n_max, void *fp, int B, dcf_stream_t stream)
+{
+    return point_sample_fwd_impl("dcf_point_sample_fwd_batch", dtype, fmap, Hf, Wf, Cf, uv, uv_fstride, count_dev, n_max, fp, B, S(stream));
+}
+
+static int point_sample_bwd_impl(const char *who, int dtype, const void *gfp, int Hf, int Wf, int Cf, const float *uv, int64_t uv_fstride,
+                                 const int32_t *count_dev, int n_max, float *gfmap, int B, hipStream_t s)
+{
+    DCF_REQUIRE(gfp && uv && count_dev && gfmap && Cf % 4 == 0 && B >= 1 && B <= 65535, "%s: bad arguments", who);
     if (n_max == 0) return DCF_OK;
-    hipStream_t s = S(stream);
-    const int64_t total = (int64_t)n_max * (Cf / 4);
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("point_sample_fwd", (double)n_max * (5.0 * Cf * sizeof(T) + 8.0), s, hipLaunchKernelGGL(k_point_sample_fwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)fmap, Hf, Wf, Cf / 4, uv, count_dev, n_max, (T *)fp)); })
+    const int64_t total = (int64_t)n_max * Cf;
+    const FrameStride fs = {(int64_t)n_max * Cf, uv_fstride, 1, (int64_t)Hf * Wf * Cf, 0};
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("point_sample_bwd", (double)B * n_max * (Cf * sizeof(T) + 4.0 * Cf * 4.0 + 8.0), s, hipLaunchKernelGGL(k_point_sample_bwd<T>, dim3(cdiv(total, 256), B), dim3(256), 0, s, (const T *)gfp, Hf, Wf, Cf, uv, count_dev, n_max, gfmap, fs)); })
     return DCF_OK;
 }
 
 extern "C" int dcf_point_sample_bwd(int dtype, const void *gfp, int Hf, int Wf, int Cf, const float *uv, const int32_t *count_dev,
                                     int n_max, float *gfmap, dcf_stream_t stream)
 {
-    DCF_REQUIRE(gfp && uv && count_dev && gfmap && Cf % 4 == 0, "dcf_point_sample_bwd: bad arguments");
-    if (n_max == 0) return DCF_OK;
-    hipStream_t s = S(stream);
-    const int64_t total = (int64_t)n_max * Cf;
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("point_sample_bwd", (double)n_max * (Cf * sizeof(T) + 4.0 * Cf * 4.0 + 8.0), s, hipLaunchKernelGGL(k_point_sample_bwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)gfp, Hf, Wf, Cf, uv, count_dev, n_max, gfmap)); })
+    return point_sample_bwd_impl("dcf_point_sample_bwd", dtype, gfp, Hf, Wf, Cf, uv, 0, count_dev, n_max, gfmap, 1, S(stream));
+}
+
+extern "C" int dcf_point_sample_bwd_batch(int dtype, const void *gfp, int Hf, int Wf, int Cf, const float *uv, int64_t uv_fstride,
+                                          const int32_t *count_dev, int n_max, float *gfmap, int B, dcf_stream_t stream)
+{
+    return point_sample_bwd_impl("dcf_point_sample_bwd_batch", dtype, gfp, Hf, Wf, Cf, uv, uv_fstride, count_dev, n_max, gfmap, B, S(stream));
+}
+
+static int fusion_gather_fwd_impl(const char *who, int dtype, const void *P, int64_t p_rows, const float *xyz, int64_t xyz_fstride, const int32_t *idx,
+                                  int K, int h, int w, int stride, float xs, float xo, float ys, float yo, const float *w1d, const float *b1,
+                                  int Cb, void *hsum, float *cnt, int B, hipStream_t s)
+{
+    DCF_REQUIRE(P && xyz && idx && w1d && b1 && hsum && cnt && Cb % 4 == 0 && K >= 1 && B >= 1 && B <= 65535, "%s: bad arguments", who);
+    FuseGeom g;
+    g.h = h; g.w = w; g.stride = stride; g.K = K; g.xs = xs; g.xo = xo; g.ys = ys; g.yo = yo;
+    const int64_t total = (int64_t)h * w * (Cb / 4);
+    const FrameStride fs = {p_rows * Cb, xyz_fstride, (int64_t)K * h * w, (int64_t)h * w * Cb, (int64_t)h * w};
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("fusion_gather_fwd", (double)B * h * w * (K * (4.0 + (double)Cb * sizeof(T)) + Cb * sizeof(T) + 4.0), s, hipLaunchKernelGGL(k_fusion_gather_fwd<T>, dim3(cdiv(total, 256), B), dim3(256), 0, s, (const T *)P, xyz, idx, g, w1d, b1, Cb / 4, (T *)hsum, cnt, fs)); })
     return DCF_OK;
 }
 
@@ -491,13 +540,15 @@ extern "C" int dcf_fusion_gather_fwd(int dtype, const void *P, const float *xyz,
                                      int stride, float xs, float xo, float ys, float yo, const float *w1d, const float *b1,
                                      int Cb, void *hsum, float *cnt, dcf_stream_t stream)
 {
-    DCF_REQUIRE(P && xyz && idx && w1d && b1 && hsum && cnt && Cb % 4 == 0 && K >= 1, "dcf_fusion_gather_fwd: bad arguments");
-    FuseGeom g;
-    g.h = h; g.w = w; g.stride = stride; g.K = K; g.xs = xs; g.xo = xo; g.ys = ys; g.yo = yo;
-    hipStream_t s = S(stream);
-    const int64_t total = (int64_t)h * w * (Cb / 4);
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("fusion_gather_fwd", (double)h * w * (K * (4.0 + (double)Cb * sizeof(T)) + Cb * sizeof(T) + 4.0), s, hipLaunchKernelGGL(k_fusion_gather_fwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)P, xyz, idx, g, w1d, b1, Cb / 4, (T *)hsum, cnt)); })
-    return DCF_OK;
+    return fusion_gather_fwd_impl("dcf_fusion_gather_fwd", dtype, P, 0, xyz, 0, idx, K, h, w, stride, xs, xo, ys, yo, w1d, b1, Cb, hsum, cnt, 1, S(stream));
+}
+
+extern "C" int dcf_fusion_gather_fwd_batch(int dtype, const void *P, int64_t p_rows, const float *xyz, int64_t xyz_fstride, const int32_t *idx,
+                                           int K, int h, int w, int stride, float xs, float xo, float ys, float yo, const float *w1d,
+                                           const float *b1, int Cb, void *hsum, float *cnt, int B, dcf_stream_t stream)
+{
+    return fusion_gather_fwd_impl("dcf_fusion_gather_fwd_batch", dtype, P, p_rows, xyz, xyz_fstride, idx, K, h, w, stride, xs, xo, ys, yo, w1d, b1, Cb, hsum,
+                                  cnt, B, S(stream));
 }
 
 extern "C" int dcf_fusion_gather_bwd(int dtype, const void *P, const float *xyz, const int32_t *idx, int K, int h, int w,
@@ -532,32 +583,32 @@ extern "C" int dcf_fusion_gather_bwd(int dtype, const void *P, const float *xyz,
     return DCF_OK;
 }
 
-extern "C" size_t dcf_fusion_gather_bwd_workspace_bytes(int Cb) { (void)Cb; return ((size_t)FG_NSLOT * 1024 + 64) * sizeof(float); }
-
-extern "C" int dcf_fusion_gather_bwd_inv(int dtype, const void *P, const float *xyz, const int32_t *e_begin, const int32_t *e_end, const int32_t *ent_pix,
-                                         const int32_t *ent_pt, int max_entries, int h, int w, int stride, float xs, float xo, float ys,
-                                         float yo, const float *w1d, const float *b1, int Cb, const void *ghsum, float *gP, float *gw1d,
-                                         float *gb1, void *workspace, dcf_stream_t stream)
+static int fusion_gather_bwd_inv_impl(const char *who, int dtype, const void *P, int64_t p_rows, const float *xyz, int64_t xyz_fstride, const int32_t *e_begin,
+                                      const int32_t *e_end, int64_t seg_fstride, const int32_t *ent_pix, const int32_t *ent_pt, int max_entries, int h,
+                                      int w, int stride, float xs, float xo, float ys, float yo, const float *w1d, const float *b1, int Cb,
+                                      const void *ghsum, float *gP, float *gw1d, float *gb1, void *workspace, int B, hipStream_t s)
 {
     float *ws = reinterpret_cast<float *>(workspace);
-    DCF_REQUIRE(P && xyz && e_begin && e_end && ent_pix && ent_pt && w1d && b1 && ghsum && gP && gw1d && gb1, "dcf_fusion_gather_bwd_inv: null pointer");
-    DCF_REQUIRE(Cb % 64 == 0 && Cb >= 64 && Cb <= 256, "dcf_fusion_gather_bwd_inv: Cb must be 64, 128, 192 or 256 (got %d)", Cb);
+    DCF_REQUIRE(P && xyz && e_begin && e_end && ent_pix && ent_pt && w1d && b1 && ghsum && gP && gw1d && gb1, "%s: null pointer", who);
+    DCF_REQUIRE(Cb % 64 == 0 && Cb >= 64 && Cb <= 256, "%s: Cb must be 64, 128, 192 or 256 (got %d)", who, Cb);
+    DCF_REQUIRE(B >= 1 && B <= 64, "%s: 1..64 frames", who);
     if (max_entries <= 0) return DCF_OK;
     FuseGeom g;
     g.h = h; g.w = w; g.stride = stride; g.K = 0; g.xs = xs; g.xo = xo; g.ys = ys; g.yo = yo;
-    hipStream_t s = S(stream);
     // pairs per wave: 128 on the big sites; the coarse sites have few pairs (6.6 k at stride 16) and would otherwise run on
     // a few dozen waves, one exposed latency after the other
     int sl = cdiv(cdiv(max_entries, 4096), 16) * 16;
     sl = sl < 16 ? 16 : (sl > 128 ? 128 : sl);
     const int waves = cdiv(max_entries, sl);
     static DcfOpt cap_env_o("FUSION_BWD_BLOCKS"); const char *cap_env = cap_env_o.str();
-    const int cap = cap_env ? atoi(cap_env) : 256;     // swept: 128 / 256 / 512 / uncapped = 0.52 / 0.34 / 0.36 / 0.44 ms per step
+    // swept (one frame per launch): 128 / 256 / 512 / uncapped = 0.52 / 0.34 / 0.36 / 0.44 ms per step; a batched launch shares the cap
+    const int cap = std::max((cap_env ? atoi(cap_env) : 256) / B, 32);
     // (256 channels: 4 accumulator sets per lane do not fit the 128 registers of a 1024-thread block -- 512 threads there)
     const int thr = Cb >= 256 ? FGI_THREADS / 2 : FGI_THREADS;
     const int blocks = std::min(cdiv(waves, thr / 64), cap);
+    const FrameStride fs = {p_rows * Cb, xyz_fstride, seg_fstride, (int64_t)h * w * Cb, 0};
     // (one profile name per instantiation, as rocprofv3 lists them: the four sites run four different kernels)
-#define DCF_FGI(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_inv<" #CJ_ ">", (double)max_entries * (8.0 + 2.0 * Cb * sizeof(T)), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_, false>), dim3(blocks), dim3(thr), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, sl, ws))
+#define DCF_FGI(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_inv<" #CJ_ ">", (double)B * max_entries * (8.0 + 2.0 * Cb * sizeof(T)), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_, false>), dim3(blocks, B), dim3(thr), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, sl, ws, fs))
     DCF_DISPATCH_DTYPE(dtype, {
         if (Cb == 64) DCF_FGI(1);
         else if (Cb == 128) DCF_FGI(2);
@@ -566,6 +617,27 @@ extern "C" int dcf_fusion_gather_bwd_inv(int dtype, const void *P, const float *
     })
 #undef DCF_FGI
     return DCF_OK;
+}
+
+extern "C" size_t dcf_fusion_gather_bwd_workspace_bytes(int Cb) { (void)Cb; return ((size_t)FG_NSLOT * 1024 + 64) * sizeof(float); }
+
+extern "C" int dcf_fusion_gather_bwd_inv(int dtype, const void *P, const float *xyz, const int32_t *e_begin, const int32_t *e_end, const int32_t *ent_pix,
+                                         const int32_t *ent_pt, int max_entries, int h, int w, int stride, float xs, float xo, float ys,
+                                         float yo, const float *w1d, const float *b1, int Cb, const void *ghsum, float *gP, float *gw1d,
+                                         float *gb1, void *workspace, dcf_stream_t stream)
+{
+    return fusion_gather_bwd_inv_impl("dcf_fusion_gather_bwd_inv", dtype, P, 0, xyz, 0, e_begin, e_end, 0, ent_pix, ent_pt, max_entries, h, w, stride, xs, xo,
+                                      ys, yo, w1d, b1, Cb, ghsum, gP, gw1d, gb1, workspace, 1, S(stream));
+}
+
+extern "C" int dcf_fusion_gather_bwd_inv_batch(int dtype, const void *P, int64_t p_rows, const float *xyz, int64_t xyz_fstride, const int32_t *e_begin,
+                                               const int32_t *e_end, int64_t seg_fstride, const int32_t *ent_pix, const int32_t *ent_pt,
+                                               int max_entries, int h, int w, int stride, float xs, float xo, float ys, float yo, const float *w1d,
+                                               const float *b1, int Cb, const void *ghsum, float *gP, float *gw1d, float *gb1, void *workspace,
+                                               int B, dcf_stream_t stream)
+{
+    return fusion_gather_bwd_inv_impl("dcf_fusion_gather_bwd_inv_batch", dtype, P, p_rows, xyz, xyz_fstride, e_begin, e_end, seg_fstride, ent_pix, ent_pt,
+                                      max_entries, h, w, stride, xs, xo, ys, yo, w1d, b1, Cb, ghsum, gP, gw1d, gb1, workspace, B, S(stream));
 }
 
 // Same sums with one writer per point row (see k_fusion_gather_bwd_inv<.., EXCL>): gP [n_rows][Cb] in the COMPUTE type, every row
@@ -586,7 +658,7 @@ extern "C" int dcf_fusion_gather_bwd_pts(int dtype, const void *P, const float *
     const int cap = cap_env ? atoi(cap_env) : 256;
     const int thr = Cb >= 256 ? FGI_THREADS / 2 : FGI_THREADS;
     const int blocks = std::min(cdiv(n_rows, thr / 64), cap);
-#define DCF_FGP(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_pts", (double)max_entries * (8.0 + 2.0 * Cb * sizeof(T)) + (double)n_rows * Cb * sizeof(T), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_, true>), dim3(blocks), dim3(thr), sizeof(float) * Cb * 4, s, (const T *)P, xyz, start, start, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, n_rows, (float *)nullptr))
+#define DCF_FGP(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_pts", (double)max_entries * (8.0 + 2.0 * Cb * sizeof(T)) + (double)n_rows * Cb * sizeof(T), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_, true>), dim3(blocks), dim3(thr), sizeof(float) * Cb * 4, s, (const T *)P, xyz, start, start, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, n_rows, (float *)nullptr, FrameStride{0, 0, 0, 0, 0}))
     DCF_DISPATCH_DTYPE(dtype, {
         if (Cb == 64) DCF_FGP(1);
         else if (Cb == 128) DCF_FGP(2);

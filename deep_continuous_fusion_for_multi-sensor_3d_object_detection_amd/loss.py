@@ -152,7 +152,73 @@ class LossTotal(nn.Module):
                     negatives.append([x, y])
         return positives, negatives, regress, owner
 
+    def assign_arrays(self, boxes, H, W):
+        """assign() for the hot path: the same lists as flat integer codes (cell = px * W + py) -- (positive cells, negative cells,
+        regression cells, box of each regression cell, weight of each regression cell) -- with the same consumption of numpy's
+        legacy generator: RandomState.shuffle draws the same random_interval sequence for a 1-D array of n codes as for a list
+        of n pairs (and takes its C fast path there), the negatives are drawn in the same batches.  tests/test_host_logic.py
+        pins lists and generator state to assign().  boxes: float32 ndarray [n, >= 2]."""
+        c = self.config
+        rs, span, cap = c["anchor_bbox_feature"]["reduced_scale"], c["positive_range"], c["pos_sample_threshold"]
+        half = int(span / 2)
+        f32 = np.float32
+        nb = len(boxes)
+        # loss.py:85-86 on fp32 scalars: one rounding per operation, then truncation toward zero
+        if nb:
+            cxs = ((boxes[:, 0] * f32(self._xs) + f32(self._xo)) / f32(rs)).astype(np.int64).tolist()
+            cys = ((boxes[:, 1] * f32(self._ys) + f32(self._yo)) / f32(rs)).astype(np.int64).tolist()
+        else:
+            cxs = cys = []
+        cells, rows, row_box, row_w = [], [], [], []
+        centre_only = self.regress_type != 0
+        for k in range(nb):
+            cx, cy = cxs[k], cys[k]
+            if cx < 0 or cx > H - 1 or cy < 0 or cy > W - 1:
+                continue
+            x0, x1 = max(cx - half, 0), min(cx - half + span - 1, H - 1)
+            y0, y1 = max(cy - half, 0), min(cy - half + span - 1, W - 1)
+            win = [px * W + py for px in range(x0, x1 + 1) for py in range(y0, y1 + 1)]      # the reference's order: dx, then dy
+            cells += win
+            if centre_only:
+                rows.append(cx * W + cy); row_box.append(k); row_w.append(1.0 / 14)
+            else:
+                rows += win
+                row_box += [k] * len(win)
+                row_w += [1.0 / (len(win) * 14)] * len(win)
+        pos = np.array(cells, dtype=np.int64)
+        np.random.shuffle(pos)
+        pos = pos[:cap]
+        taken = set(pos.tolist())
+        want = c["neg_sample_threshold"] + 1
+        neg = []
+        while len(neg) < want:
+            dr = np.random.randint([H, W], size=(want - len(neg), 2))
+            for code in (dr[:, 0] * W + dr[:, 1]).tolist():
+                if code not in taken:
+                    neg.append(code)
+        return pos, np.array(neg, dtype=np.int64), np.array(rows, dtype=np.int64), np.array(row_box, dtype=np.int64), np.array(row_w, dtype=np.float32)
+
     # ------------------------------------------------------------------ device-side terms
+    def _stage_arrays(self, ints, floats, dev):
+        """_stage for numpy arrays (the CUDA path): straight into the pinned buffers."""
+        ni, nf = max(ints.size, 1), max(floats.size, 1)
+        st = getattr(self, "_stage_buf", None)
+        if st is None or st[0].numel() < ni or st[1].numel() < nf:
+            st = [torch.empty(max(ni, 1 << 16), dtype=torch.long).pin_memory(), torch.empty(max(nf, 1 << 12), dtype=torch.float32).pin_memory(), None]
+            st += [st[0].numpy(), st[1].numpy()]
+            self._stage_buf = st
+        if len(st) < 5:
+            st += [st[0].numpy(), st[1].numpy()]
+        if st[2] is not None:
+            st[2].synchronize()          # the previous step's copies have long completed
+        st[3][:ints.size] = ints
+        st[4][:floats.size] = floats
+        di = st[0][:ni].to(dev, non_blocking=True)
+        df = st[1][:nf].to(dev, non_blocking=True)
+        st[2] = torch.cuda.Event()
+        st[2].record()
+        return di, df
+
     def _stage(self, ints, floats, dev):
         """One pinned staging buffer per kind: all index lists / boxes of the step go up in two async copies,
         so the host never waits for the device while it builds the loss."""
@@ -183,6 +249,27 @@ class LossTotal(nn.Module):
         base, cls, reg = self._head_views(cls, reg, H, W)
         red = {"last": 0, "sum": 1, "mean": 2}[self.reduction]
         return _FusedLoss.apply(base, cls, reg, anc, di, df, B, HW, self.config["regress_loss_gain"], red)
+
+    def _forward_hip_arrays(self, cls, reg, anc, boxes_host, nbox, B, H, W):
+        """The CUDA path of the compat mode: numpy target assignment (assign_arrays) packed as dcf_loss_fwd_bwd wants it
+        (per-sample table, then per sample: positive, negative, regression cells, box of each regression cell | weights, boxes)."""
+        bh = boxes_host.numpy() if boxes_host.dtype == torch.float32 else boxes_host.float().numpy()
+        head = np.empty((B, 6), np.int64)
+        parts_i, parts_f = [], []
+        o, of = 6 * B, 0
+        for b in range(B):
+            nb = int(nbox[b])
+            pos, neg, rows, row_box, row_w = self.assign_arrays(bh[b, :nb], H, W)
+            head[b] = (o, pos.size, neg.size, rows.size, of, nb)
+            parts_i += [pos, neg, rows, row_box]
+            bx = bh[b, :nb, :7].reshape(-1)
+            parts_f += [row_w, bx]
+            o += pos.size + neg.size + 2 * rows.size
+            of += row_w.size + bx.size
+        di, df = self._stage_arrays(np.concatenate([head.reshape(-1)] + parts_i), np.concatenate(parts_f) if parts_f else np.zeros(0, np.float32), cls.device)
+        base, cls, reg = self._head_views(cls, reg, H, W)
+        red = {"last": 0, "sum": 1, "mean": 2}[self.reduction]
+        return _FusedLoss.apply(base, cls, reg, anc, di, df, B, H * W, self.config["regress_loss_gain"], red)
 
     @staticmethod
     def _head_views(cls, reg, H, W):
@@ -245,6 +332,8 @@ class LossTotal(nn.Module):
             return self._forward_device_sampling(reference_bboxes_batch, num_ref_bbox_batch, cls, reg, anc, B, H, W)
         # pass CPU boxes (what a DataLoader yields) to avoid a device round trip
         boxes_host = reference_bboxes_batch.detach().cpu() if reference_bboxes_batch.is_cuda else reference_bboxes_batch.detach()
+        if dev.type == "cuda":
+            return self._forward_hip_arrays(cls, reg, anc, boxes_host, num_ref_bbox_batch, B, H, W)
         # ---- host: target assignment for every sample, packed into flat lists
         ints, floats, plan = [], [], []
         for b in range(B):

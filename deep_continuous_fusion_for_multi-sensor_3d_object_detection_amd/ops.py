@@ -364,6 +364,40 @@ def point_sample_bwd(dtype, gfp, uv, cnt, n_max, gfmap):
     return gfmap
 
 
+def point_sample_fwd_batch(dtype, fmap, uv, cnt, n_max, out):
+    """All frames in one launch: fmap [B,Hf,Wf,Cf], uv [B,rows,2], cnt int32 [B], out ZEROED [B,n_max,Cf]."""
+    B, Hf, Wf, Cf = fmap.shape
+    H.call("dcf_point_sample_fwd_batch", dtype, _chk(fmap, "fmap"), Hf, Wf, Cf, _chk(uv, "uv"), uv.stride(0), cnt, n_max, _chk(out, "out"), B, H.stream_ptr())
+    return out
+
+
+def point_sample_bwd_batch(dtype, gfp, uv, cnt, n_max, gfmap):
+    """gfp [B,n_max,Cf], gfmap fp32 [B,Hf,Wf,Cf] (accumulated into)."""
+    B, Hf, Wf, Cf = gfmap.shape
+    H.call("dcf_point_sample_bwd_batch", dtype, _chk(gfp, "gfp"), Hf, Wf, Cf, _chk(uv, "uv"), uv.stride(0), cnt, n_max, _chk(gfmap, "gfmap"), B, H.stream_ptr())
+    return gfmap
+
+
+def fusion_gather_fwd_batch(dtype, P, xyz, idx, stride, aff, w1d, b1, hsum, cnt):
+    """P [B,rows,Cb], xyz [B,n,3], idx int32 [B,K,h,w] -> hsum [B,h,w,Cb], cnt fp32 [B,h*w] (written)."""
+    B, K, h, w = idx.shape
+    Cb = P.shape[2]
+    H.call("dcf_fusion_gather_fwd_batch", dtype, _chk(P, "P"), P.shape[1], _chk(xyz, "xyz"), xyz.stride(0), _chk(idx, "idx"), K, h, w, stride,
+           float(aff[0]), float(aff[1]), float(aff[2]), float(aff[3]), w1d, b1, Cb, _chk(hsum, "hsum"), _chk(cnt, "cnt"), B, H.stream_ptr())
+    return hsum, cnt
+
+
+def fusion_gather_bwd_inv_batch(dtype, P, xyz, inv, n_max, g0, khw, stride, aff, w1d, b1, ghsum, gP, gw1d, gb1, ws=None):
+    """fusion_gather_bwd_inv for the B frames of a batch in one launch: their maps are g0 .. g0 + B - 1 of the fusion_invert call;
+    P [B,rows,Cb], xyz [B,n,3], ghsum [B,h,w,Cb], gP fp32 [B,rows,Cb]."""
+    start, ent = inv
+    B, rows, Cb = P.shape
+    seg = start[g0 * (n_max + 1):]
+    H.call("dcf_fusion_gather_bwd_inv_batch", dtype, _chk(P, "P"), rows, _chk(xyz, "xyz"), xyz.stride(0), seg, seg[n_max:], n_max + 1, ent[0], ent[1],
+           khw[0] * khw[1] * khw[2], khw[1], khw[2], stride, float(aff[0]), float(aff[1]), float(aff[2]), float(aff[3]), w1d, b1, Cb,
+           _chk(ghsum, "ghsum"), _chk(gP, "gP"), gw1d, gb1, ws, B, H.stream_ptr())
+
+
 def fusion_gather_fwd(dtype, P, xyz, idx, stride, aff, w1d, b1, out=None):
     """out: optional (hsum [h,w,Cb], cnt [h*w]) to write into (a frame's slices of batch tensors)."""
     K, h, w = idx.shape

@@ -285,11 +285,21 @@ int dcf_point_sample_fwd(int dtype, const void *fmap, int Hf, int Wf, int Cf, co
 /*     backward: gF[tap] += w_tap * gfp (fp32 atomics into gfmap fp32 [Hf][Wf][Cf]) */
 int dcf_point_sample_bwd(int dtype, const void *gfp, int Hf, int Wf, int Cf, const float *uv, const int32_t *count_dev,
                          int n_max, float *gfmap, dcf_stream_t stream);
+/*     The B frames of a batch in one launch each (grid.y = frame): fmap / gfmap [B][Hf][Wf][Cf], uv frame b at uv + b * uv_fstride
+ *     floats, count_dev [B], fp / gfp [B][n_max][Cf].  Same results as B single-frame calls. */
+int dcf_point_sample_fwd_batch(int dtype, const void *fmap, int Hf, int Wf, int Cf, const float *uv, int64_t uv_fstride,
+                               const int32_t *count_dev, int n_max, void *fp, int B, dcf_stream_t stream);
+int dcf_point_sample_bwd_batch(int dtype, const void *gfp, int Hf, int Wf, int Cf, const float *uv, int64_t uv_fstride,
+                               const int32_t *count_dev, int n_max, float *gfmap, int B, dcf_stream_t stream);
 /* (2) per BEV pixel: hsum[p][c] = sum_k relu(P[idx_k][c] + W1d[c][0..2].(dx,dy,z) + b1[c]),
  *     cnt[p] = number of valid neighbours.  P [n][Cb] (dtype); w1d fp32 [Cb][3]; b1 fp32 [Cb]. */
 int dcf_fusion_gather_fwd(int dtype, const void *P, const float *xyz, const int32_t *idx, int K, int h, int w,
                           int stride, float xs, float xo, float ys, float yo, const float *w1d, const float *b1,
                           int Cb, void *hsum, float *cnt, dcf_stream_t stream);
+/*     batch form: P [B][p_rows][Cb], xyz frame b at xyz + b * xyz_fstride floats, idx [B][K][h][w], hsum [B][h][w][Cb], cnt [B][h*w] */
+int dcf_fusion_gather_fwd_batch(int dtype, const void *P, int64_t p_rows, const float *xyz, int64_t xyz_fstride, const int32_t *idx,
+                                int K, int h, int w, int stride, float xs, float xo, float ys, float yo, const float *w1d,
+                                const float *b1, int Cb, void *hsum, float *cnt, int B, dcf_stream_t stream);
 /*     backward: recompute the ReLU mask; gP[idx_k] += m*gh (fp32 atomics, gP fp32 [n][Cb]);
  *     gw1d[c][j] += sum m*gh*delta_j ; gb1[c] += sum m*gh. */
 int dcf_fusion_gather_bwd(int dtype, const void *P, const float *xyz, const int32_t *idx, int K, int h, int w,
@@ -320,6 +330,13 @@ int dcf_fusion_gather_bwd_inv(int dtype, const void *P, const float *xyz, const 
                               const int32_t *ent_pix, const int32_t *ent_pt, int max_entries, int h, int w, int stride, float xs,
                               float xo, float ys, float yo, const float *w1d, const float *b1, int Cb, const void *ghsum, float *gP,
                               float *gw1d, float *gb1, void *workspace, dcf_stream_t stream);
+/* The B frames of a batch (consecutive maps of one dcf_fusion_invert call) in one launch: P / gP [B][p_rows][Cb], xyz frame b at
+ * xyz + b * xyz_fstride floats, frame b's e_begin / e_end at + b * seg_fstride ints (= n_max + 1 for consecutive maps), ghsum
+ * [B][h][w][Cb]; gw1d / gb1 accumulate over the frames.  B <= 64. */
+int dcf_fusion_gather_bwd_inv_batch(int dtype, const void *P, int64_t p_rows, const float *xyz, int64_t xyz_fstride, const int32_t *e_begin,
+                                    const int32_t *e_end, int64_t seg_fstride, const int32_t *ent_pix, const int32_t *ent_pt, int max_entries,
+                                    int h, int w, int stride, float xs, float xo, float ys, float yo, const float *w1d, const float *b1, int Cb,
+                                    const void *ghsum, float *gP, float *gw1d, float *gb1, void *workspace, int B, dcf_stream_t stream);
 
 /* The same sums with ONE writer per point row (a wave owns a range of points and all their pairs): gP [n_rows][Cb] in the compute
  * dtype, every row written (zeros where no pixel chose the point) -- no zero-filled fp32 accumulator, no float atomics on gP, no

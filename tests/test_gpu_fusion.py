@@ -393,3 +393,57 @@ def test_voxel_image_fast_path_matches_fp32_grid_path(dtype):
         x2, geom2 = trainer.geometry_async(geo, dev_pts)
         b = trainer.model(grids, img.cuda(), geom=geom2)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_batched_fusion_kernels_equal_per_frame_calls(dtype):
+    """dcf_point_sample_fwd/bwd_batch, dcf_fusion_gather_fwd_batch, dcf_fusion_gather_bwd_inv_batch (grid.y = frame: one launch per
+    batch instead of one per frame) against the single-frame entry points on three frames of different density."""
+    ops, H = pkg("ops"), pkg("_hip")
+    tdt = H.torch_dtype(dtype)
+    g = torch.Generator().manual_seed(11)
+    B, n_max, K, h, w, stride, Cb, Cf, Hf, Wf = 3, 700, 3, 24, 40, 4, 128, 64, 24, 32
+    aff = (10.0, 0.0, 10.0, 400.0)
+    ns = [500, 37, 0]
+    xyz = torch.zeros(B, n_max, 3)
+    uv = torch.zeros(B, n_max, 2)
+    for b, n in enumerate(ns):
+        xyz[b, :n, 0] = torch.rand(n, generator=g) * (h * stride / aff[0])
+        xyz[b, :n, 1] = torch.rand(n, generator=g) * (w * stride / aff[2]) - aff[3] / aff[2]
+        xyz[b, :n, 2] = torch.rand(n, generator=g) * 2 - 1
+        uv[b, :n, 0] = torch.rand(n, generator=g) * (Wf * 4 - 1)
+        uv[b, :n, 1] = torch.rand(n, generator=g) * (Hf * 4 - 1)
+    xyz, uv = xyz.cuda(), uv.cuda()
+    cnt = torch.tensor(ns, dtype=torch.int32, device="cuda")
+    fmap = (torch.rand(B, Hf, Wf, Cf, generator=g) - 0.5).cuda().to(tdt)
+    # point sampling forward / backward
+    fp_b = ops.point_sample_fwd_batch(dtype, fmap, uv, cnt, n_max, torch.zeros(B, n_max, Cf, device="cuda", dtype=tdt))
+    gfp = (torch.rand(B, n_max, Cf, generator=g) - 0.5).cuda().to(tdt)
+    gF_b = ops.point_sample_bwd_batch(dtype, gfp, uv, cnt, n_max, torch.zeros(B, Hf, Wf, Cf, device="cuda"))
+    for b in range(B):
+        fp1 = ops.point_sample_fwd(dtype, fmap[b], uv[b], cnt[b:b + 1], n_max)
+        assert torch.equal(fp1, fp_b[b])
+        gF1 = ops.point_sample_bwd(dtype, gfp[b], uv[b], cnt[b:b + 1], n_max, torch.zeros(Hf, Wf, Cf, device="cuda"))
+        assert float((gF1 - gF_b[b]).abs().max()) <= 1e-5 * max(float(gF1.abs().max()), 1e-6)
+    # gather forward / backward by point
+    idx = torch.stack([ops.knn_bev(xyz[b], cnt[b:b + 1], K, h, w, stride, aff) for b in range(B)], 0)
+    P = (torch.rand(B, n_max, Cb, generator=g) - 0.5).cuda().to(tdt)
+    w1d = ((torch.rand(Cb, 3, generator=g) - 0.5) * 0.2).cuda().reshape(-1)
+    b1 = ((torch.rand(Cb, generator=g) - 0.5) * 0.2).cuda()
+    hs_b, c_b = ops.fusion_gather_fwd_batch(dtype, P, xyz, idx, stride, aff, w1d, b1, torch.empty(B, h, w, Cb, device="cuda", dtype=tdt),
+                                            torch.empty(B, h * w, device="cuda"))
+    ghs = (torch.rand(B, h, w, Cb, generator=g) - 0.5).cuda().to(tdt)
+    inv = ops.fusion_invert([idx[b] for b in range(B)], n_max)
+    ws = ops.fusion_bwd_workspace("cuda")
+    gP_b, gw_b, gb_b = torch.zeros(B, n_max, Cb, device="cuda"), torch.zeros(Cb * 3, device="cuda"), torch.zeros(Cb, device="cuda")
+    ops.fusion_gather_bwd_inv_batch(dtype, P, xyz, inv, n_max, 0, (K, h, w), stride, aff, w1d, b1, ghs, gP_b, gw_b, gb_b, ws)
+    gw_1, gb_1 = torch.zeros(Cb * 3, device="cuda"), torch.zeros(Cb, device="cuda")
+    for b in range(B):
+        hs1, c1 = ops.fusion_gather_fwd(dtype, P[b], xyz[b], idx[b], stride, aff, w1d, b1)
+        assert torch.equal(hs1, hs_b[b]) and torch.equal(c1, c_b[b])
+        gP1 = torch.zeros(n_max, Cb, device="cuda")
+        ops.fusion_gather_bwd_inv(dtype, P[b], xyz[b], inv, n_max, b, (K, h, w), stride, aff, w1d, b1, ghs[b], gP1, gw_1, gb_1, ws)
+        assert float((gP1 - gP_b[b]).abs().max()) <= 2e-5 * max(float(gP1.abs().max()), 1e-6)
+    for a_, b_ in ((gw_b, gw_1), (gb_b, gb_1)):
+        assert float((a_ - b_).abs().max()) <= 1e-4 * float(b_.abs().max())
+    assert float(ws.abs().max()) == 0.0

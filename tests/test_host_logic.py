@@ -184,3 +184,45 @@ def test_batched_negative_sampling_consumes_the_generator_like_scalar_calls():
                     got.append((x, y))
         assert got == ref and np.random.randint(1 << 30) == tail_ref
 
+
+
+def test_assign_arrays_equals_assign_lists_and_generator_state():
+    """LossTotal.assign_arrays (numpy, the CUDA path of the compat mode) against LossTotal.assign (lists; pinned to the reference's
+    golden loss above): same positive / negative / regression cells in the same order, same weights, and numpy's legacy
+    generator left in the same state -- over box counts from 0 to the maximum, clipped windows, boxes outside the grid, more
+    window cells than pos_sample_threshold (the subset branch), both regress types."""
+    import numpy as np
+    from _util import golden_cfg, load_golden, pkg
+    cfg0 = golden_cfg(load_golden("model_tiny.npz"))
+    rng = np.random.default_rng(3)
+    for regress_type in (0, 1):
+        cfg = dict(cfg0, voxel_length=704, voxel_width=800, lidar_x_min=0.0, lidar_x_max=70.4, lidar_y_min=-40.0, lidar_y_max=40.0,
+                   regress_type=regress_type)
+        L = pkg("loss").LossTotal(cfg)
+        H, W = 176, 200
+        for trial, nb in enumerate((0, 1, 3, 8, 20, 20)):
+            boxes = np.zeros((nb, 9), np.float32)
+            boxes[:, 0] = rng.uniform(-3.0, 75.0, nb)          # some centres outside the grid
+            boxes[:, 1] = rng.uniform(-42.0, 42.0, nb)
+            if nb >= 3:
+                boxes[1, :2] = (0.05, -39.95)                  # a corner: clipped window
+                boxes[2, :2] = (35.2, 0.0)                     # exactly on a cell boundary
+            if trial == 5:
+                boxes[:, 0] = rng.uniform(5.0, 65.0, nb); boxes[:, 1] = rng.uniform(-35.0, 35.0, nb)    # all inside: 500 cells > 128
+            tb = torch.from_numpy(boxes)
+            np.random.seed(40 + trial)
+            pos, neg, regress, owner = L.assign(tb, H, W)
+            tail = np.random.randint(1 << 30)
+            np.random.seed(40 + trial)
+            apos, aneg, rows, row_box, row_w = L.assign_arrays(boxes, H, W)
+            assert np.random.randint(1 << 30) == tail
+            assert apos.tolist() == [p[0] * W + p[1] for p in pos]
+            assert aneg.tolist() == [q[0] * W + q[1] for q in neg]
+            want_rows, want_box, want_w = [], [], []
+            for k in range(nb):
+                for m in owner[k]:
+                    want_rows.append(regress[m][0] * W + regress[m][1]); want_box.append(k); want_w.append(1.0 / (len(owner[k]) * 14))
+            assert rows.tolist() == want_rows and row_box.tolist() == want_box
+            assert np.allclose(row_w, np.array(want_w, np.float32), rtol=0, atol=0)
+            if trial == 5:
+                assert len(pos) == cfg["pos_sample_threshold"]
