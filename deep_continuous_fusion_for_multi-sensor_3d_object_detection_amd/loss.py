@@ -200,17 +200,22 @@ class LossTotal(nn.Module):
 
     # ------------------------------------------------------------------ device-side terms
     def _stage_arrays(self, ints, floats, dev):
-        """_stage for numpy arrays (the CUDA path): straight into the pinned buffers."""
+        """_stage for numpy arrays (the CUDA path): straight into pinned buffers.  A ring of three buffer pairs: the one being
+        refilled was last used three steps ago, so the wait for its copies never blocks -- with a single pair the host stalled
+        here every step until the GPU had reached the previous step's loss (the host enqueues a step about as fast as the GPU
+        runs it, so that wait set the pace)."""
         ni, nf = max(ints.size, 1), max(floats.size, 1)
-        st = getattr(self, "_stage_buf", None)
-        if st is None or st[0].numel() < ni or st[1].numel() < nf:
-            st = [torch.empty(max(ni, 1 << 16), dtype=torch.long).pin_memory(), torch.empty(max(nf, 1 << 12), dtype=torch.float32).pin_memory(), None]
-            st += [st[0].numpy(), st[1].numpy()]
-            self._stage_buf = st
-        if len(st) < 5:
-            st += [st[0].numpy(), st[1].numpy()]
+        ring = getattr(self, "_stage_ring", None)
+        if ring is None or ring[0][0].numel() < ni or ring[0][1].numel() < nf:
+            ring = []
+            for _ in range(3):
+                a, b = torch.empty(max(ni, 1 << 16), dtype=torch.long).pin_memory(), torch.empty(max(nf, 1 << 12), dtype=torch.float32).pin_memory()
+                ring.append([a, b, None, a.numpy(), b.numpy()])
+            self._stage_ring, self._stage_slot = ring, 0
+        st = ring[self._stage_slot]
+        self._stage_slot = (self._stage_slot + 1) % len(ring)
         if st[2] is not None:
-            st[2].synchronize()          # the previous step's copies have long completed
+            st[2].synchronize()
         st[3][:ints.size] = ints
         st[4][:floats.size] = floats
         di = st[0][:ni].to(dev, non_blocking=True)
@@ -292,12 +297,14 @@ class LossTotal(nn.Module):
         dev = cls.device
         # labels: [B,max,9] fp32 and the counts, one small asynchronous copy each when they arrive on the host
         if not boxes.is_cuda:
-            st = getattr(self, "_box_stage", None)
-            if st is None or st[0].shape != boxes.shape:
-                st = [torch.empty(boxes.shape, dtype=torch.float32).pin_memory(), None]
-                self._box_stage = st
+            ring = getattr(self, "_box_ring", None)
+            if ring is None or ring[0][0].shape != boxes.shape:
+                ring = self._box_ring = [[torch.empty(boxes.shape, dtype=torch.float32).pin_memory(), None] for _ in range(3)]
+                self._box_slot = 0
+            st = ring[self._box_slot]            # last used three steps ago: the wait below never blocks
+            self._box_slot = (self._box_slot + 1) % 3
             if st[1] is not None:
-                st[1].synchronize()          # the previous step's copy has long completed
+                st[1].synchronize()
             st[0].copy_(boxes)
             boxes = st[0].to(dev, non_blocking=True)
             st[1] = torch.cuda.Event()
