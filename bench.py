@@ -489,6 +489,7 @@ def main():
         out = {"metric": "frames/sec (train step) 100k-pt LiDAR + 1242x375 RGB", "value": round(frames / dt, 3), "unit": "frames/s",
                "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "ms_per_step_median": round(median_ms, 3), "ms_per_step_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)],
+               "ms_first_steps": [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(min(args.steps, 8))],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "%s: grid 32x704x800, %d pts/frame, %s RGB, %s image stream, K=%d fusion x4 sites, "
                                       "%s-mode BN%s, batch %d/GPU" % (
