@@ -42,6 +42,7 @@ SIGNATURES = {
     "dcf_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dcf_knn_bev": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, P, P, P]),
     "dcf_knn_bev_batch": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, P, P, c_size_t, P]),
+    "dcf_knn_bev_batch_shared": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, P, P, c_size_t, P, c_size_t, P]),
     "dcf_nchw_to_nhwc": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "dcf_nhwc_to_nchw": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "dcf_image_to_nhwc4": (c_int, [c_int, P, P, c_int, c_int, c_int, P]),

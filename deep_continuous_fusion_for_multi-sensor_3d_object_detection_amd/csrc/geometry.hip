@@ -763,6 +763,187 @@ __global__ void __launch_bounds__(256) k_knn_search_wave(const int *count, int n
     }
 }
 
+// Coarse sites, dense regions on a FINER site's cells (round 3).  k_knn_search_wave looks at the site's own cells: at stride 8 / 16 a
+// cell is 0.8 m / 1.6 m wide and the 5 x 5 window a wave scans first holds hundreds to thousands of points near the sensor.
+// k_knn_search_fine runs the same search, one wave per pixel, in two phases on two cell structures:
+//   phase 0: the 5 x 5 window of the site's own cells, as k_knn_search_wave -- unless it holds more than KNN_FINE_MIN_POINTS points:
+//   phase A: (those dense pixels) square windows of the FINE site's cells (0.2 m; built anyway for the stride-2 site), radius
+//            2, 4, 6, 8 cells; the cells of a window are probed one per lane and every lane inserts ITS cell's few points into
+//            its private K-best; a 64-lane lexicographic merge and the termination test after each window.  Pixels with K
+//            points within ~1.5 m finish here having touched a few dozen points;
+//   phase B: the rest (sparse neighbourhoods, pixels outside the camera frustum) walk rings of the COARSE site's own 8 x 8-cell
+//            blocks with bounding-box pruning, exactly as k_knn_search_wave does (on the fine grid the same pixels would walk
+//            ~8x as many rings: measured 115 us per launch against 64).
+// Termination of phase A is exact: the K-th best so far must be closer than the nearest OPEN edge of the scanned window (an edge
+// on the grid border is closed: points beyond the grid are clamped into the border cells, which the window then contains).
+// Same distance arithmetic, same (d2, index) order, same -1 padding as the other two kernels: bit-identical maps.
+constexpr int KNN_FINE_MIN_POINTS = 192;      // points in a pixel's 5 x 5 window of own cells above which the fine cells are searched instead
+
+__device__ __forceinline__ float open_edge_distance(const KnnGrid &gf, float X, float Y, int i0, int i1, int j0, int j1)
+{
+    const float s = (float)gf.stride;
+    float b = 3.0e38f;
+    if (i0 > 0) b = fminf(b, X - ((float)i0 * s - gf.xo) / gf.xs);
+    if (i1 < gf.h - 1) b = fminf(b, ((float)(i1 + 1) * s - gf.xo) / gf.xs - X);
+    if (j0 > 0) b = fminf(b, Y - ((float)j0 * s - gf.yo) / gf.ys);
+    if (j1 < gf.w - 1) b = fminf(b, ((float)(j1 + 1) * s - gf.yo) / gf.ys - Y);
+    return b - 1e-3f;                       // 1 mm margin for the fp32 rounding of the edges (as the other kernels)
+}
+
+template <int K>
+__global__ void __launch_bounds__(256) k_knn_search_fine(const int *count, int n_max, KnnGrid g, KnnGrid gf, const int *cellstart_c,
+                                                         const float4 *sorted_c, const int *cellstart, const float4 *sorted, float rmax2,
+                                                         int *out)
+{
+    // g: the coarse site (pixels, output, its own cells cellstart_c / sorted_c); gf: the fine site (cellstart / sorted)
+    count += blockIdx.y * g.fs_cnt; out += (size_t)blockIdx.y * g.fs_out;
+    cellstart_c += (size_t)blockIdx.y * g.fs_ws;
+    sorted_c = reinterpret_cast<const float4 *>(reinterpret_cast<const int *>(sorted_c) + (size_t)blockIdx.y * g.fs_ws);
+    cellstart += (size_t)blockIdx.y * gf.fs_ws;
+    sorted = reinterpret_cast<const float4 *>(reinterpret_cast<const int *>(sorted) + (size_t)blockIdx.y * gf.fs_ws);
+    const int lane = threadIdx.x & 63;
+    const int pix = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int hw = g.h * g.w;
+    if (pix >= hw) return;
+    const int i = pix / g.w, j = pix - i * g.w;
+    const float s = (float)g.stride;
+    const float X = __fdiv_rn(__fsub_rn(__fmul_rn((float)i + 0.5f, s), g.xo), g.xs);
+    const float Y = __fdiv_rn(__fsub_rn(__fmul_rn((float)j + 0.5f, s), g.yo), g.ys);
+    const int n = min(*count, n_max);
+    int ci, cj;
+    point_cell(X, Y, gf, ci, cj);           // fine cell of the pixel centre (clamped into the grid)
+
+    TopK<K> top;
+    top.clear();
+    float gd[K];
+    int gi[K];
+    int gcnt = 0;
+#pragma unroll
+    for (int q = 0; q < K; ++q) { gd[q] = 3.0e38f; gi[q] = 0x7fffffff; }
+    auto scan_own = [&](int b, int e) {     // this LANE's cell
+        for (int p = b; p < e; ++p) {
+            const float4 q = sorted[p];
+            const float dx = __fsub_rn(q.x, X), dy = __fsub_rn(q.y, Y);
+            const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+            if (!(rmax2 >= 0.0f && d2 > rmax2)) top.insert(d2, __float_as_int(q.z));
+        }
+    };
+    auto scan_range = [&](int b, int e) {   // the wave together, on the coarse site's own cells
+        for (int p = b + lane; p < e; p += 64) {
+            const float4 q = sorted_c[p];
+            const float dx = __fsub_rn(q.x, X), dy = __fsub_rn(q.y, Y);
+            const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+            if (!(rmax2 >= 0.0f && d2 > rmax2)) top.insert(d2, __float_as_int(q.z));
+        }
+    };
+    bool done = (n == 0);
+    // ---- phase 0: how many points does the 5 x 5 window of the site's OWN cells hold (the first thing k_knn_search_wave scans)?
+    // Few: scan them as that kernel does.  Many (a dense region: hundreds to thousands): take the fine site's cells instead.
+    bool dense = false;
+    if (!done) {
+        const int H8 = g.h8 * 8, W8 = g.w8 * 8;
+        const int row = lane >> 1, part = lane & 1;
+        const int wi = i - 2 + row;
+        const int cbeg = max(j - 2, 0), cend = min(j + 2, W8 - 1);
+        const int split = min(cend, (cbeg | 7));                  // last column of the first block
+        const int c0 = part == 0 ? cbeg : split + 1;
+        const int c1 = part == 0 ? split : cend;
+        int ps = 0, pe = 0;
+        if (lane < 10 && wi >= 0 && wi <= H8 - 1 && c0 <= c1) {
+            ps = cellstart_c[cell_key(wi, c0, g)];
+            pe = cellstart_c[cell_key(wi, c1, g) + 1];
+        }
+        const int total = wave_sum_i(pe - ps);
+        dense = total > KNN_FINE_MIN_POINTS;
+        if (!dense) {
+            unsigned long long live = __ballot(pe > ps);
+            while (live) {
+                const int l = __ffsll((long long)live) - 1;
+                live &= live - 1;
+                scan_range(__builtin_amdgcn_readlane(ps, l), __builtin_amdgcn_readlane(pe, l));
+            }
+            wave_merge<K>(top, gd, gi, gcnt);
+            const float cw = fminf(s / g.xs, s / g.ys);
+            const float bound = 2.5f * cw - 1e-3f;
+            if (gcnt >= K && gd[K - 1] < bound * bound) done = true;
+            if (rmax2 >= 0.0f && bound > 0.f && bound * bound > rmax2) done = true;
+        }
+    }
+    // ---- phase A (dense regions): windows of the FINE cells, radius 2, 4, 6, 8: window r adds the cells with max(|a|, |b|) in (r - 2, r]
+    int rprev = -1;
+    for (int r = 2; r <= 8 && !done && dense; r += 2) {
+        const int side = 2 * r + 1, ncell = side * side;
+        for (int t0 = 0; t0 < ncell; t0 += 64) {
+            const int t = t0 + lane;
+            const int a = t / side - r, b = t - (t / side) * side - r;
+            const int fi = ci + a, fj = cj + b;
+            if (t < ncell && max(abs(a), abs(b)) > rprev && fi >= 0 && fi < gf.h && fj >= 0 && fj < gf.w) {
+                const int key = cell_key(fi, fj, gf);
+                scan_own(cellstart[key], cellstart[key + 1]);
+            }
+        }
+        rprev = r;
+        wave_merge<K>(top, gd, gi, gcnt);
+        const float bound = open_edge_distance(gf, X, Y, ci - r, ci + r, cj - r, cj + r);
+        if (gcnt >= K && bound > 0.f && gd[K - 1] < bound * bound) done = true;
+        if (rmax2 >= 0.0f && bound > 0.f && bound * bound > rmax2) done = true;
+    }
+    // ---- phase B: block rings of the COARSE site's own cells, as in k_knn_search_wave (fresh start: the rings re-cover the windows)
+    if (!done) {
+        top.clear();
+        gcnt = 0;
+#pragma unroll
+        for (int q = 0; q < K; ++q) { gd[q] = 3.0e38f; gi[q] = 0x7fffffff; }
+        const float cwmin = fminf(s / g.xs, s / g.ys);
+        const int I = i >> 3, J = j >> 3;
+        const int Rmax = max(g.h8, g.w8);
+        for (int R = 0; R <= Rmax && !done; ++R) {
+            const int nblk = R == 0 ? 1 : 8 * R;
+            for (int t0 = 0; t0 < nblk; t0 += 64) {
+                const int t = t0 + lane;
+                int a = 0, b = 0;
+                if (R > 0) {
+                    if (t < 2 * R + 1) { a = -R; b = -R + t; }
+                    else if (t < 4 * R + 2) { a = R; b = -R + (t - (2 * R + 1)); }
+                    else if (t < 6 * R + 1) { b = -R; a = -R + 1 + (t - (4 * R + 2)); }
+                    else { b = R; a = -R + 1 + (t - (6 * R + 1)); }
+                }
+                const int bi = I + a, bj = J + b;
+                int ps = 0, pe = 0;
+                if (t < nblk && bi >= 0 && bi < g.h8 && bj >= 0 && bj < g.w8) {
+                    const int k0 = (bi * g.w8 + bj) << 6;
+                    ps = cellstart_c[k0];
+                    pe = cellstart_c[k0 + 64];
+                }
+                unsigned long long live = __ballot(pe > ps);
+                while (live) {
+                    const int l = __ffsll((long long)live) - 1;
+                    live &= live - 1;
+                    const int cbi = __builtin_amdgcn_readlane(bi, l), cbj = __builtin_amdgcn_readlane(bj, l);
+                    const int cps = __builtin_amdgcn_readlane(ps, l), cpe = __builtin_amdgcn_readlane(pe, l);
+                    bool visit = true;
+                    if (gcnt >= K) {   // prune with the (possibly stale, hence conservative) wave-wide K-th
+                        const float lox = ((float)(cbi * 8) * s - g.xo) / g.xs, hix = ((float)(cbi * 8 + 8) * s - g.xo) / g.xs;
+                        const float loy = ((float)(cbj * 8) * s - g.yo) / g.ys, hiy = ((float)(cbj * 8 + 8) * s - g.yo) / g.ys;
+                        const float ddx = fmaxf(0.f, fmaxf(lox - X, X - hix) - 1e-3f);
+                        const float ddy = fmaxf(0.f, fmaxf(loy - Y, Y - hiy) - 1e-3f);
+                        visit = (ddx * ddx + ddy * ddy) <= gd[K - 1];
+                    }
+                    if (visit) scan_range(cps, cpe);
+                }
+            }
+            wave_merge<K>(top, gd, gi, gcnt);
+            const float bound = (8.0f * (float)R + 0.5f) * cwmin - 1e-3f;
+            if (gcnt >= K && gd[K - 1] < bound * bound) done = true;
+            if (rmax2 >= 0.0f && bound > 0.f && bound * bound > rmax2) done = true;
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) out[q * hw + pix] = (q < gcnt) ? gi[q] : -1;
+    }
+}
+
 // ------------------------------------------------------------------ inverse of the KNN maps (for the fusion backward)
 // idx [K][h][w] says which points each BEV pixel gathers; the backward wants, per point, the pixels that gathered it.
 // All maps of a step (sites x frames) are inverted together: counting sort by key (map, point id):
@@ -971,8 +1152,15 @@ extern "C" size_t dcf_knn_workspace_bytes(int n_max, int h, int w)
     return ints * sizeof(int) + sizeof(float4) * (size_t)n_max + 64;
 }
 
+struct KnnFine {                 // a finer site of the same batch whose cells are already built (dcf_knn_bev_batch_shared)
+    int h, w, stride;
+    const void *ws;
+    size_t ws_stride_bytes;
+};
+
 static int knn_bev_impl(const char *who, const float *xyz, const int32_t *count_dev, int B, int n_max, int K, int h, int w, int stride,
-                        float xs, float xo, float ys, float yo, float rmax2, int32_t *idx_out, void *ws, size_t ws_stride_bytes, hipStream_t s)
+                        float xs, float xo, float ys, float yo, float rmax2, int32_t *idx_out, void *ws, size_t ws_stride_bytes, hipStream_t s,
+                        const KnnFine *fine = nullptr)
 {
     DCF_REQUIRE(xyz && count_dev && idx_out && ws, "%s: null pointer", who);
     DCF_REQUIRE(K >= 1 && K <= 8, "%s: K must be 1..8 (got %d)", who, K);
@@ -1015,6 +1203,30 @@ static int knn_bev_impl(const char *who, const float *xyz, const int32_t *count_
     static DcfOpt force_o("KNN_KERNEL"); const char *force = force_o.str();
     const bool per_wave = force && force[0] == 'w' ? true : (force && force[0] == 't' ? false : (h * w <= 20000));
     const int nbw = cdiv(h * w, 4);
+    if (fine) {
+        // dense pixels on the fine site's cells, the rest on this site's own blocks (k_knn_search_fine)
+        KnnGrid gf = g;
+        gf.h = fine->h; gf.w = fine->w; gf.stride = fine->stride;
+        int ncf;
+        knn_dims(fine->h, fine->w, gf.h8, gf.w8, ncf);
+        gf.fs_ws = B > 1 ? (int)(fine->ws_stride_bytes / 4) : 0;
+        const int nscf = ncf + 1, nsbf = cdiv(nscf, CP_TILE);
+        const int *cellstart_f = (const int *)fine->ws + nscf;
+        size_t intsf = 3 * (size_t)nscf + (size_t)nsbf + 8 + (size_t)n_max;
+        intsf = (intsf + 3) & ~(size_t)3;
+        const float4 *sorted_f = (const float4 *)((const char *)fine->ws + intsf * sizeof(int));
+#define KNN_FCASE(KK)                                                                                                                       \
+    case KK:                                                                                                                                \
+        DCF_LAUNCH_B("knn_search_fine", fB * ((double)h * w * K * 4.0 + (double)n_max * 16.0), s,                                           \
+                     hipLaunchKernelGGL(k_knn_search_fine<KK>, dim3(nbw, B), dim3(256), 0, s, count_dev, n_max, g, gf, cellstart, sorted,   \
+                                        cellstart_f, sorted_f, rmax2, idx_out));                                                            \
+        break;
+        switch (K) {
+            KNN_FCASE(1) KNN_FCASE(2) KNN_FCASE(3) KNN_FCASE(4) KNN_FCASE(5) KNN_FCASE(6) KNN_FCASE(7) KNN_FCASE(8)
+        }
+#undef KNN_FCASE
+        return DCF_OK;
+    }
 #define KNN_CASE(KK)                                                                                                     \
     case KK:                                                                                                             \
         if (per_wave)                                                                                                    \
@@ -1045,6 +1257,24 @@ extern "C" int dcf_knn_bev_batch(const float *xyz, const int32_t *count_dev, int
                                  dcf_stream_t stream)
 {
     return knn_bev_impl("dcf_knn_bev_batch", xyz, count_dev, B, n_max, K, h, w, stride, xs, xo, ys, yo, rmax2, idx_out, ws, ws_stride_bytes, S(stream));
+}
+
+// A coarser site of the same batch: its own cell sort as dcf_knn_bev_batch, but the search (k_knn_search_fine) serves the pixels in
+// dense regions from the cells a FINER site's call has already built.  ws_fine = the workspace that call filled (same xyz, count,
+// n_max, B), untouched since.
+extern "C" int dcf_knn_bev_batch_shared(const float *xyz, const int32_t *count_dev, int B, int n_max, int K, int h, int w, int stride,
+                                        int fine_h, int fine_w, int fine_stride, float xs, float xo, float ys, float yo, float rmax2,
+                                        int32_t *idx_out, void *ws, size_t ws_stride_bytes, const void *ws_fine, size_t ws_fine_stride_bytes,
+                                        dcf_stream_t stream)
+{
+    const char *who = "dcf_knn_bev_batch_shared";
+    DCF_REQUIRE(ws_fine && fine_h > 0 && fine_w > 0 && fine_stride > 0, "%s: bad fine-site arguments", who);
+    DCF_REQUIRE(stride % fine_stride == 0 && h * stride <= fine_h * fine_stride && w * stride <= fine_w * fine_stride,
+                "%s: the coarse site must lie on the fine site's grid", who);
+    DCF_REQUIRE(B == 1 || (ws_fine_stride_bytes % 16 == 0 && ws_fine_stride_bytes >= dcf_knn_workspace_bytes(n_max, fine_h, fine_w) &&
+                           ws_fine_stride_bytes / 4 < (1ull << 31)), "%s: fine workspace stride must be that of the fine site's call", who);
+    const KnnFine fine = {fine_h, fine_w, fine_stride, ws_fine, ws_fine_stride_bytes};
+    return knn_bev_impl(who, xyz, count_dev, B, n_max, K, h, w, stride, xs, xo, ys, yo, rmax2, idx_out, ws, ws_stride_bytes, S(stream), &fine);
 }
 
 extern "C" size_t dcf_fusion_invert_workspace_bytes(int n_max, int nmaps)

@@ -402,6 +402,9 @@ class ObjectDetection_DCF(_FlatParamModule):
                                        fp8_min_blocks=int(self.config.get("fp8_min_blocks", 512)))
         return self._backend
 
+    KNN_SHARED_MAX_PIXELS = 20000      # sites up to this many pixels (stride 8 and 16 at cfg2) are searched on the finest site's cells
+    knn_shared = True
+
     def fusion_geometry(self, points, uv, n_valid, bufs=None):
         """KNN indices of every fusion site for a batch: points [B,n_max,3], uv [B,n_max,2], n_valid [B] (int).
         bufs: optional persistent buffers dict(idx=[4 x int32 [B,K,h,w]], ws=[4 x workspace]) to write into."""
@@ -412,19 +415,29 @@ class ObjectDetection_DCF(_FlatParamModule):
             torch.tensor([int(v) for v in n_valid], dtype=torch.int32, device=dev)
         L, W = self.config["voxel_length"], self.config["voxel_width"]
         idx = []
+        batched = points.is_contiguous() and cnt.is_contiguous()
+        fine = None                     # (h, w, stride, workspace) of the finest site: the coarse sites search ITS cells
         for si in range(1, 5):
             s = 2 ** si
+            h, w = L // s, W // s
             if bufs is not None:            # frames land side by side in the batch tensor: no per-frame allocation, no stack copy
                 site = bufs["idx"][si - 1]
             else:
-                site = torch.empty((B, self.K, L // s, W // s), dtype=torch.int32, device=dev)
+                site = torch.empty((B, self.K, h, w), dtype=torch.int32, device=dev)
             ws = None if bufs is None else bufs["ws"][si - 1]
-            if B > 1 and points.is_contiguous() and cnt.is_contiguous():
+            if batched and fine is not None and h * w <= self.KNN_SHARED_MAX_PIXELS and self.knn_shared:
+                # coarse site: own cell sort, but the pixels of dense regions are served from the finest site's cells
+                ops.knn_bev_batch_shared(points, cnt, self.K, h, w, s, fine[:3], fine[3], self._grid.aff, self.r_max, ws=ws, out=site)
+            elif batched and (B > 1 or self.knn_shared):
                 # every phase once for the whole batch (grid.y = frame): half the launches, and the coarse sites' searches fill the chip
-                ops.knn_bev_batch(points, cnt, self.K, L // s, W // s, s, self._grid.aff, self.r_max, ws=ws, out=site)
+                if ws is None:
+                    ws = torch.empty((B, ops.knn_ws_stride(points.shape[1], h, w)), dtype=torch.uint8, device=dev)
+                ops.knn_bev_batch(points, cnt, self.K, h, w, s, self._grid.aff, self.r_max, ws=ws, out=site)
+                if fine is None:
+                    fine = (h, w, s, ws)
             else:
                 for b in range(B):
-                    ops.knn_bev(points[b], cnt[b:b + 1], self.K, L // s, W // s, s, self._grid.aff, self.r_max, ws=None if ws is None else ws[0], out=site[b])
+                    ops.knn_bev(points[b], cnt[b:b + 1], self.K, h, w, s, self._grid.aff, self.r_max, ws=None if ws is None else ws[0], out=site[b])
             idx.append(site)
         return dict(xyz=points.contiguous(), uv=uv.contiguous(), cnt=cnt, idx=idx, aff=self._grid.aff)
 

@@ -349,6 +349,27 @@ def knn_bev_batch(xyz, cnt, K, h, w, stride, aff, rmax=None, ws=None, out=None):
     return idx
 
 
+def knn_bev_batch_shared(xyz, cnt, K, h, w, stride, fine, ws_fine, aff, rmax=None, ws=None, out=None):
+    """A coarser site of the same batch: own cell sort (ws) + a search that serves dense regions from the cells of a finer site:
+    fine = (h, w, stride) of the knn_bev_batch call whose workspace ws_fine ([B, knn_ws_stride(n_max, fine_h, fine_w)] bytes,
+    untouched since) is read.  Same indices as knn_bev_batch."""
+    B, n_max = xyz.shape[0], xyz.shape[1]
+    fh, fw, fs = fine
+    stf = knn_ws_stride(n_max, fh, fw)
+    if ws_fine.shape[0] < B or ws_fine.stride(0) != stf:
+        raise H.DcfError("knn_bev_batch_shared: the fine site's workspace must be [B, %d] bytes" % stf)
+    st = knn_ws_stride(n_max, h, w)
+    if ws is None:
+        ws = torch.empty((B, st), dtype=torch.uint8, device=xyz.device)
+    if ws.shape[0] < B or ws.stride(0) != st:
+        raise H.DcfError("knn_bev_batch_shared: workspace must be [B, %d] bytes" % st)
+    idx = torch.empty((B, K, h, w), dtype=torch.int32, device=xyz.device) if out is None else _chk(out, "out")
+    r2 = -1.0 if rmax is None else float(np.float32(rmax) * np.float32(rmax))
+    H.call("dcf_knn_bev_batch_shared", _chk(xyz, "xyz"), _chk(cnt, "cnt"), B, n_max, K, h, w, stride, fh, fw, fs, float(aff[0]), float(aff[1]),
+           float(aff[2]), float(aff[3]), r2, idx, ws, st, ws_fine, stf, H.stream_ptr())
+    return idx
+
+
 # ------------------------------------------------------------------ fusion
 def point_sample_fwd(dtype, fmap, uv, cnt, n_max, out=None):
     """out: optional ZEROED [n_max, Cf] tensor to write into (a frame's slice of a batch tensor)."""

@@ -107,6 +107,15 @@ int dcf_knn_bev_batch(const float *xyz, const int32_t *count_dev, int B, int n_m
                       float xs, float xo, float ys, float yo, float rmax2, int32_t *idx_out, void *ws, size_t ws_stride_bytes,
                       dcf_stream_t stream);
 
+/* A coarser site of the same batch (stride a multiple of fine_stride): its own cell sort as dcf_knn_bev_batch (ws), and a search
+ * that serves the pixels of dense regions from the cells a FINER site's dcf_knn_bev_batch call has already built (ws_fine = that
+ * call's workspace, untouched since; same xyz / count_dev / n_max / B) -- a few dozen candidates per pixel instead of the
+ * hundreds to thousands a coarse cell window holds near the sensor.  Same indices as dcf_knn_bev_batch. */
+int dcf_knn_bev_batch_shared(const float *xyz, const int32_t *count_dev, int B, int n_max, int K, int h, int w, int stride,
+                             int fine_h, int fine_w, int fine_stride, float xs, float xo, float ys, float yo, float rmax2,
+                             int32_t *idx_out, void *ws, size_t ws_stride_bytes, const void *ws_fine, size_t ws_fine_stride_bytes,
+                             dcf_stream_t stream);
+
 /* Inverse of the KNN maps of a step (sites x frames) for the fusion backward: the (pixel, point) pairs of every
  * idx [K][h][w] counting-sorted by (map, point).  start int32 [nmaps*(n_max+1)]: pairs of point q of map g are
  * [start[g*(n_max+1)+q], start[g*(n_max+1)+q+1]); ent_pix / ent_pt int32 [sum K*h*w] (pixel packed (i<<16)|j).

@@ -391,3 +391,81 @@ def test_knn_batch_equals_per_frame(stride, K):
     got2 = ops.knn_bev_batch(pts, cnt, K, h, w, stride, g.aff, rmax=2.0)
     for b in range(B):
         assert torch.equal(got2[b], ops.knn_bev(pts[b], cnt[b:b + 1], K, h, w, stride, g.aff, rmax=2.0))
+
+
+def _coarse_on_fine(ops, d, cnt, K, stride, aff, rmax=None, fine_stride=2):
+    """Maps of one coarse site two ways: its own cell sort alone (dcf_knn_bev_batch: wave / tile kernel) and with the dense
+    regions served from the finer site's cells (dcf_knn_bev_batch_shared: k_knn_search_fine)."""
+    B, n_max = d.shape[0], d.shape[1]
+    fh, fw = 704 // fine_stride, 800 // fine_stride
+    h, w = 704 // stride, 800 // stride
+    ws = torch.empty((B, ops.knn_ws_stride(n_max, fh, fw)), dtype=torch.uint8, device="cuda")
+    ops.knn_bev_batch(d, cnt, K, fh, fw, fine_stride, aff, rmax, ws=ws)
+    own = ops.knn_bev_batch(d, cnt, K, h, w, stride, aff, rmax)
+    shared = ops.knn_bev_batch_shared(d, cnt, K, h, w, stride, (fh, fw, fine_stride), ws, aff, rmax)
+    return own, shared
+
+
+@pytest.mark.parametrize("stride,K", [(8, 3), (16, 3), (16, 5), (4, 1), (8, 8)])
+def test_knn_coarse_site_on_fine_cells_equals_own_sort(stride, K):
+    """dcf_knn_bev_batch_shared (round 3: coarse sites searched on the stride-2 site's cells, k_knn_search_fine: windows of fine
+    cells, then block rings, exact open-edge termination) against the site's own sort + wave / tile kernel: whole-site equality
+    on two cfg2 frames of different density, with and without a radius cut."""
+    ops = pkg("ops")
+    g, a = _cfg2_cloud(seed=9)
+    _, b = _cfg2_cloud(seed=10, npts=30000)
+    n_max = max(a.shape[0], b.shape[0])
+    d = torch.zeros(2, n_max, 3)
+    d[0, :a.shape[0]] = torch.from_numpy(a); d[1, :b.shape[0]] = torch.from_numpy(b)
+    d = d.cuda()
+    cnt = torch.tensor([a.shape[0], b.shape[0]], dtype=torch.int32, device="cuda")
+    own, shared = _coarse_on_fine(ops, d, cnt, K, stride, g.aff)
+    assert torch.equal(own, shared) and int(own.min()) >= 0
+    own, shared = _coarse_on_fine(ops, d, cnt, K, stride, g.aff, rmax=1.5)
+    assert torch.equal(own, shared) and int((own < 0).sum()) > 0
+    # brute-force spot check of the shared result itself (sampled pixels of frame 0)
+    h, w = 704 // stride, 800 // stride
+    rng = np.random.default_rng(77)
+    pi = rng.integers(0, h, 1500).astype(np.int32); pj = rng.integers(0, w, 1500).astype(np.int32)
+    _knn_check_pixels(_coarse_on_fine(ops, d, cnt, K, stride, g.aff)[1][0].cpu().numpy(), a, K, pi, pj, stride, g.aff)
+
+
+@pytest.mark.parametrize("where", ["far_corner", "near_corner", "two_clusters", "few", "none", "on_borders"])
+def test_knn_coarse_site_on_fine_cells_sparse_clouds(where):
+    """The block-ring phase and the closed-edge logic of k_knn_search_fine: clusters far from most pixels, fewer points than K,
+    no points at all, points sitting on the grid's border cells."""
+    ops = pkg("ops")
+    g, _ = _cfg2_cloud()
+    rng = np.random.default_rng(5)
+    if where == "far_corner":
+        xyz = np.stack([rng.uniform(66.0, 70.3, 400), rng.uniform(36.0, 39.9, 400), rng.uniform(-1, 1, 400)], 1)
+    elif where == "near_corner":
+        xyz = np.stack([rng.uniform(0.0, 1.5, 300), rng.uniform(-39.9, -38.0, 300), rng.uniform(-1, 1, 300)], 1)
+    elif where == "two_clusters":
+        a = np.stack([rng.uniform(10.0, 11.0, 200), rng.uniform(-30.0, -29.0, 200), rng.uniform(-1, 1, 200)], 1)
+        b = np.stack([rng.uniform(60.0, 61.0, 5), rng.uniform(30.0, 31.0, 5), rng.uniform(-1, 1, 5)], 1)
+        xyz = np.concatenate([a, b])
+    elif where == "few":
+        xyz = np.array([[35.0, 0.0, 0.0], [35.05, 0.01, 0.0]])
+    elif where == "none":
+        xyz = np.zeros((0, 3))
+    else:
+        t = np.linspace(0.0, 1.0, 150)
+        xyz = np.concatenate([np.stack([np.full(150, 0.001), -39.99 + 79.98 * t, t], 1), np.stack([70.39 * t, np.full(150, 39.99), t], 1),
+                              np.stack([np.full(150, 70.39), -39.99 + 79.98 * t, t], 1)])
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    n = xyz.shape[0]
+    d = torch.zeros(1, max(n, 4), 3)
+    d[0, :n] = torch.from_numpy(xyz)
+    d = d.cuda()
+    cnt = torch.tensor([n], dtype=torch.int32, device="cuda")
+    for stride in (8, 16):
+        for K in (3, 5):
+            own, shared = _coarse_on_fine(ops, d, cnt, K, stride, g.aff)
+            assert torch.equal(own, shared), (where, stride, K)
+            own, shared = _coarse_on_fine(ops, d, cnt, K, stride, g.aff, rmax=3.0)
+            assert torch.equal(own, shared), (where, stride, K, "rmax")
+    if n >= 1:
+        h, w = 704 // 16, 800 // 16
+        ii, jj = np.meshgrid(np.arange(0, h, 3), np.arange(0, w, 3), indexing="ij")
+        _knn_check_pixels(_coarse_on_fine(ops, d, cnt, 3, 16, g.aff)[1][0].cpu().numpy(), xyz, 3, ii.ravel().astype(np.int32), jj.ravel().astype(np.int32), 16, g.aff)
