@@ -793,7 +793,7 @@ __device__ __forceinline__ float open_edge_distance(const KnnGrid &gf, float X, 
 template <int K>
 __global__ void __launch_bounds__(256) k_knn_search_fine(const int *count, int n_max, KnnGrid g, KnnGrid gf, const int *cellstart_c,
                                                          const float4 *sorted_c, const int *cellstart, const float4 *sorted, float rmax2,
-                                                         int *out)
+                                                         int *out, int dense_min)
 {
     // g: the coarse site (pixels, output, its own cells cellstart_c / sorted_c); gf: the fine site (cellstart / sorted)
     count += blockIdx.y * g.fs_cnt; out += (size_t)blockIdx.y * g.fs_out;
@@ -854,7 +854,7 @@ __global__ void __launch_bounds__(256) k_knn_search_fine(const int *count, int n
             pe = cellstart_c[cell_key(wi, c1, g) + 1];
         }
         const int total = wave_sum_i(pe - ps);
-        dense = total > KNN_FINE_MIN_POINTS;
+        dense = total > dense_min;
         if (!dense) {
             unsigned long long live = __ballot(pe > ps);
             while (live) {
@@ -1215,11 +1215,13 @@ static int knn_bev_impl(const char *who, const float *xyz, const int32_t *count_
         size_t intsf = 3 * (size_t)nscf + (size_t)nsbf + 8 + (size_t)n_max;
         intsf = (intsf + 3) & ~(size_t)3;
         const float4 *sorted_f = (const float4 *)((const char *)fine->ws + intsf * sizeof(int));
+        static DcfOpt dm_o("KNN_FINE_MIN"); const char *dm = dm_o.str();
+        const int dense_min = dm ? atoi(dm) : KNN_FINE_MIN_POINTS;
 #define KNN_FCASE(KK)                                                                                                                       \
     case KK:                                                                                                                                \
         DCF_LAUNCH_B("knn_search_fine", fB * ((double)h * w * K * 4.0 + (double)n_max * 16.0), s,                                           \
                      hipLaunchKernelGGL(k_knn_search_fine<KK>, dim3(nbw, B), dim3(256), 0, s, count_dev, n_max, g, gf, cellstart, sorted,   \
-                                        cellstart_f, sorted_f, rmax2, idx_out));                                                            \
+                                        cellstart_f, sorted_f, rmax2, idx_out, dense_min));                                                 \
         break;
         switch (K) {
             KNN_FCASE(1) KNN_FCASE(2) KNN_FCASE(3) KNN_FCASE(4) KNN_FCASE(5) KNN_FCASE(6) KNN_FCASE(7) KNN_FCASE(8)
