@@ -396,6 +396,8 @@ def main():
     ap.add_argument("--from-host", action="store_true", help="feed the timed steps from host memory through FrameLoader "
                     "(pinned staging + H2D on a copy stream): the PCIe-inclusive rate")
     ap.add_argument("--no-from-host", action="store_true", help="skip the short PCIe-inclusive leg reported as `from_host`")
+    ap.add_argument("--loss-sampling", default="compat", help="compat = host target assignment on numpy's generator exactly like the reference's "
+                    "loss.py:74-127 (default, the mode pinned to the reference); device = assignment + loss in one launch (csrc/loss.hip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -408,6 +410,7 @@ def main():
     image_wh = tuple(int(v) for v in args.image.lower().split("x"))
     cfg = kitti_config(args.batch, args.dtype, args.points, args.knn, args.image_stream, image_wh)
     cfg["bn_mode"] = args.bn_mode
+    cfg["loss_sampling"] = args.loss_sampling
     global PMC_TAG
     key = (args.points, args.knn, args.image_stream, args.batch, args.dtype, args.image.lower())
     PMC_TAG = {(100000, 3, "resnet18", 2, "bf16", "1242x375"): "", (300000, 3, "resnet18", 1, "bf16", "1920x1080"): "cfg5shape_bf16_"}.get(key)
@@ -500,7 +503,8 @@ def main():
                                           args.points, args.image.lower(), {"resnet18": "ResNet-18", "resnet34": "ResNet-34", "resnet50": "ResNet-50"}.get(args.image_stream, args.image_stream),
                                           args.knn, args.bn_mode, " (reference F4)" if args.bn_mode == "eval" else "", args.batch),
                           "global_batch": args.batch * ws, "parallelism": "dp%d" % ws, "final_loss": round(loss, 4),
-                          "input": "host memory through FrameLoader (PCIe-inclusive)" if args.from_host else "resident in HBM"},
+                          "input": "host memory through FrameLoader (PCIe-inclusive)" if args.from_host else "resident in HBM",
+                          "loss_sampling": args.loss_sampling},
                "roofline": roof, "cpu_baseline": cpu, "from_host": from_host, "kernel_classes": classes, "kernel_breakdown": breakdown}
         print(json.dumps(out))
     if ws > 1:
