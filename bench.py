@@ -233,7 +233,8 @@ def rocprof_kernel(name):
     if kind.startswith("conv_wgrad") or kind.startswith("stem_wgrad"):
         return ("k_conv_wgrad", [dt] + t) if t else None
     if t and t[0].startswith("sp"):                          # spatial-tile streaming kernel: 'conv_fwd_bf16<sp32>'
-        return "k_conv3x3_sp", [dt, t[0][2:], "8" if t[0][2:] == "32" else "4", "3"]
+        c = t[0][2:]                                         # instantiations: <T, 32, 8, 2> (default) and <T, 64, 4, 3>
+        return "k_conv3x3_sp", [dt, c, "8" if c == "32" else "4", "2" if c == "32" else "3"]
     if t and t[0].startswith("rs"):                          # row-sharing kernel: 'conv_fwd_bf16<rs0,9>' = tile kind 0, 9 position tiles
         return "k_conv3x3_rs", [dt] + {0: ["1", "5", "4", "2", "2", "1", "false"], 1: ["1", "3", "2", "4", "2", "1", "false"],
                                        2: ["1", "1", "2", "4", "6", "2", "true"]}[int(t[0][2:])]

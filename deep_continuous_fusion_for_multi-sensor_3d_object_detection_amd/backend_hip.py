@@ -295,6 +295,17 @@ class HipBackend(object):
             raise H.DcfError("layer %s was planned without an input gradient" % L.name)
         return ops.conv2d_dgrad(self.dtype, gy, self._w(L, True), res, in_shape, L.kh, L.kw, L.stride, L.pad, mask)
 
+    def shortcut_dgrad(self, Ld, dd, L1, g1, in_shape, mask=None):
+        """Input gradient of a strided block whose shortcut is a 1x1 / stride-2 conv Ld and whose main path starts with the
+        3x3 / stride-2 conv L1: the shortcut's gradient touches only the even pixels of x, so it is computed as a dense 1x1 GEMM
+        on dd's own grid (a quarter of the pixels, no zero stores) and joins L1's input gradient in that launch's epilogue.
+        Values are those of dgrad(L1, g1, res=dgrad(Ld, dd)): the shortcut's term is rounded to the compute dtype first in both."""
+        if L1.wdgrad_off < 0 or Ld.wdgrad_off < 0:
+            raise H.DcfError("layer %s was planned without an input gradient" % L1.name)
+        B, Hq, Wq, _ = dd.shape
+        gq = ops.conv2d_dgrad(self.dtype, dd, self._w(Ld, True), None, (B, Hq, Wq, in_shape[3]), 1, 1, 1, 0)
+        return ops.conv2d_dgrad_halfres(self.dtype, g1, self._w(L1, True), None, gq, in_shape, L1.kh, L1.kw, L1.stride, L1.pad, mask)
+
     def _gs(self, L):
         return self._gsbase + 4 * L.gsum_off if (L.bn is not None and not self.bn_train) else None
 

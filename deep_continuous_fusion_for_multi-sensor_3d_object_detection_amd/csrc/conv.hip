@@ -45,6 +45,8 @@ struct ConvArgs {
     int pixbytes;        // byte pitch between adjacent input pixels (= Ck*esize except for the stem)
     unsigned xbytes, wbytes;  // sizes of the gathered tensor and of the weight image (buffer descriptors)
     const char *mask;         // [M][Cn] or null: output *= (mask > 0)
+    const char *resq = nullptr;   // stride-2 dgrad with parity classes only: residual living on the (2i, 2j) sub-grid of the
+                              // output, [B][ceil(Ho/2)][ceil(Wo/2)][Cn] (the input gradient of a 1x1 / stride-2 shortcut)
     // stride-2 dgrad only: output pixels are enumerated parity class by parity class ((oh+pad)&1, (ow+pad)&1),
     // each class padded to whole pixel tiles, so a tile only walks the taps that can hit a real gy pixel
     int parity;               // 1 = class-major enumeration in use
@@ -289,6 +291,14 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
     int mpix[TM];
 #pragma unroll
     for (int j = 0; j < TM; ++j) mpix[j] = out_pixel(m0 + (wm * TM + j) * 32 + r);
+    if (PAR && a.resq && ph == (a.pad & 1) && pw == (a.pad & 1)) {
+        // half-resolution residual: the class whose rows / columns start at 0 is the (2i, 2j) sub-grid, and the class-local
+        // pixel index is that tensor's own linear index
+        int mq[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) { const int m = m0 + (wm * TM + j) * 32 + r; mq[j] = m < clsM ? m : -1; }
+        conv_epilogue_add<T, TN, TM>(acc, mq, n0 + wn * TN * 32 + 8 * h, a.Cn, reinterpret_cast<const T *>(a.resq));
+    }
     conv_epilogue_phases<T, TN, TM>(acc, mpix, n0 + wn * TN * 32 + 8 * h, a.Cn, a.shift, res, mask, a.relu, y);
     DCF_STAMP(4);
     DCF_WEND();
@@ -491,6 +501,14 @@ __global__ void __launch_bounds__(256) k_conv_igemm_dma(ConvArgs a)
     int mpix[TM];
 #pragma unroll
     for (int j = 0; j < TM; ++j) mpix[j] = out_pixel(m0 + (wm * TM + j) * 32 + r);
+    if (PAR && a.resq && ph == (a.pad & 1) && pw == (a.pad & 1)) {
+        // half-resolution residual: the class whose rows / columns start at 0 is the (2i, 2j) sub-grid, and the class-local
+        // pixel index is that tensor's own linear index
+        int mq[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) { const int m = m0 + (wm * TM + j) * 32 + r; mq[j] = m < clsM ? m : -1; }
+        conv_epilogue_add<T, TN, TM>(acc, mq, n0 + wn * TN * 32 + 8 * h, a.Cn, reinterpret_cast<const T *>(a.resq));
+    }
     conv_epilogue_phases<T, TN, TM>(acc, mpix, n0 + wn * TN * 32 + 8 * h, a.Cn, a.shift, res, mask, a.relu, y);
     DCF_STAMP(4);
     DCF_WEND();
@@ -1498,9 +1516,9 @@ extern "C" int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const flo
     return launch_igemm<bf16_t, false>(a, S(stream), "conv_fwd_bf16", flops);
 }
 
-extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const void *res, const void *mask, void *gx,
-                                int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
-                                dcf_stream_t stream)
+static int conv2d_dgrad_impl(int dtype, const void *gy, const void *wt, const void *res, const void *resq, const void *mask, void *gx,
+                             int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                             dcf_stream_t stream)
 {
     // roles swap: reduction channels = Cout, produced channels = Cin
     int rc = check_conv("dcf_conv2d_dgrad", dtype, Cout, Cin, kh, kw, stride);
@@ -1508,7 +1526,7 @@ extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const
     DCF_REQUIRE(gy && wt && gx, "dcf_conv2d_dgrad: null pointer");
     ConvArgs a;
     a.x = (const char *)gy; a.w = (const char *)wt; a.shift = nullptr; a.res = (const char *)res; a.y = (char *)gx;
-    a.mask = (const char *)mask;
+    a.mask = (const char *)mask; a.resq = (const char *)resq;
     static DcfOpt par_env_o("DGRAD_PARITY"); const char *par_env = par_env_o.str();     // experiments: 0 = off, 1 = all stride-2 layers, 2 = full-line pixels only
     const int par_mode = par_env ? atoi(par_env) : 1;
     // (a 1x1 stride-2 layer has one live class and three that only store zeros: one plain pass is cheaper)
@@ -1517,6 +1535,7 @@ extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const
         a.cls_h0[p] = (p + pad) & 1; a.cls_w0[p] = (p + pad) & 1;
         a.cls_h[p] = (H - a.cls_h0[p] + 1) / 2; a.cls_w[p] = (W - a.cls_w0[p] + 1) / 2;
     }
+    DCF_REQUIRE(!resq || a.parity, "dcf_conv2d_dgrad_halfres: needs a stride-2 layer with a kernel wider than 1x1 (and DGRAD_PARITY on)");
     a.B = B; a.Hi = Ho; a.Wi = Wo; a.Ck = Cout; a.Ho = H; a.Wo = W; a.Cn = Cin;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.relu = 0; a.M = B * H * W;
     a.pixbytes = Cout * (dtype == DCF_F32 ? 4 : 2);
@@ -1533,6 +1552,25 @@ extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const
     if (dtype == DCF_F32) return launch_igemm<float, true>(a, S(stream), "conv_dgrad_f32", flops);
     if (dtype == DCF_F16) return launch_igemm<f16_t, true>(a, S(stream), "conv_dgrad_f16", flops);
     return launch_igemm<bf16_t, true>(a, S(stream), "conv_dgrad_bf16", flops);
+}
+
+extern "C" int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const void *res, const void *mask, void *gx,
+                                int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                                dcf_stream_t stream)
+{
+    return conv2d_dgrad_impl(dtype, gy, wt, res, nullptr, mask, gx, B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, stream);
+}
+
+// Input gradient of a stride-2 layer (kernel wider than 1x1) that also takes a residual living on the (2i, 2j) sub-grid of
+// gx: resq = [B][ceil(H/2)][ceil(W/2)][Cin], zero everywhere else by construction.  That is what a 1x1 / stride-2 shortcut
+// (model.py:27-30 `down_conv`) sends back to the block input: computed there as a dense GEMM on its own grid instead of a
+// full-resolution tensor that is three quarters zeros.  gx = (dgrad + res + scatter(resq)) * (mask > 0).
+extern "C" int dcf_conv2d_dgrad_halfres(int dtype, const void *gy, const void *wt, const void *res, const void *resq, const void *mask,
+                                        void *gx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride,
+                                        int pad, dcf_stream_t stream)
+{
+    DCF_REQUIRE(resq, "dcf_conv2d_dgrad_halfres: null resq");
+    return conv2d_dgrad_impl(dtype, gy, wt, res, resq, mask, gx, B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, stream);
 }
 
 static void wgrad_tiles(int Cin, int Cout, int &TM, int &TN) { TM = Cout >= 64 ? 2 : 1; TN = Cin >= 64 ? 2 : 1; }

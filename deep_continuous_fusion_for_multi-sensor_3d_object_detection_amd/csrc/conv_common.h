@@ -66,23 +66,27 @@ template <> struct Mma<float> {
 // phase are independent of each other (behind a store that may alias them, each used to pay its own latency).
 // m[j] = output pixel of this lane in position tile j, or < 0; channel of (i, p) = c0 + 32 i + 16 p.
 template <typename T, int TN, int TM>
+__device__ __forceinline__ void conv_epilogue_add(f32x16 (&acc)[TN][TM], const int (&m)[TM], int c0, int Cn, const T *res)
+{
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                if (m[j] >= 0) {
+                    float rr[8];
+                    ld8(res + (size_t)m[j] * Cn + c0 + i * 32 + 16 * p, rr);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[i][j][8 * p + k] += rr[k];
+                }
+}
+
+template <typename T, int TN, int TM>
 __device__ __forceinline__ void conv_epilogue_phases(f32x16 (&acc)[TN][TM], const int (&m)[TM], int c0, int Cn, const float *shift,
                                                      const T *res, const T *mask, int relu, T *y)
 {
-    if (res) {
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-                    if (m[j] >= 0) {
-                        float rr[8];
-                        ld8(res + (size_t)m[j] * Cn + c0 + i * 32 + 16 * p, rr);
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) acc[i][j][8 * p + k] += rr[k];
-                    }
-    }
+    if (res) conv_epilogue_add<T, TN, TM>(acc, m, c0, Cn, res);
     if (shift) {
 #pragma unroll
         for (int i = 0; i < TN; ++i)

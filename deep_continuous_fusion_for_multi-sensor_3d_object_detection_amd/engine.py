@@ -25,6 +25,8 @@ import torch
 
 # experiments (read once per process): "0" = no inverse KNN maps at all, "2" = build them but run the pixel-run backward
 FUSION_INV = os.environ.get("DCF_FUSION_INV", "1")
+# "0" = the 1x1 / stride-2 shortcut's input gradient as a full-resolution tensor again (A/B runs; same values)
+HALFRES_SHORTCUT = os.environ.get("DCF_HALFRES_SHORTCUT", "1") != "0"
 
 
 class ConvLayer(object):
@@ -122,6 +124,10 @@ class Block(object):
             K.conv_wgrad(self.down, x, dd)
             if not need_gx:
                 return None
+            d, c = self.down, self.conv1
+            if (extra is None and HALFRES_SHORTCUT and d.kh == 1 and d.kw == 1 and d.stride == 2 and d.pad == 0
+                    and c.kh == 3 and c.stride == 2 and c.pad == 1):
+                return K.shortcut_dgrad(d, dd, c, g1, tuple(x.shape), pm)
             gx = K.conv_dgrad(self.down, dd, tuple(x.shape), extra)
             return K.conv_dgrad(self.conv1, g1, tuple(x.shape), gx, pm)
         if not need_gx:

@@ -93,6 +93,17 @@ def conv2d_dgrad(dtype, gy, wt, res, in_shape, kh, kw, stride, pad, mask=None):
     return gx
 
 
+def conv2d_dgrad_halfres(dtype, gy, wt, res, resq, in_shape, kh, kw, stride, pad, mask=None):
+    """conv2d_dgrad of a stride-2 layer plus resq [B, ceil(H/2), ceil(W/2), Cin] added on the (2i, 2j) sub-grid of gx."""
+    B, Hh, W, Cin = in_shape
+    _, Ho, Wo, Cout = gy.shape
+    if tuple(resq.shape) != (B, (Hh + 1) // 2, (W + 1) // 2, Cin):
+        raise H.DcfError("conv2d_dgrad_halfres: resq %s does not sit on the even sub-grid of %s" % (tuple(resq.shape), tuple(in_shape)))
+    gx = torch.empty((B, Hh, W, Cin), dtype=gy.dtype, device=gy.device)
+    H.call("dcf_conv2d_dgrad_halfres", dtype, gy, wt, res, resq, mask, gx, B, Hh, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, H.stream_ptr())
+    return gx
+
+
 def conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, kh, kw, stride=1):
     return H.lib().dcf_conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, kh, kw, stride)
 

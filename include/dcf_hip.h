@@ -150,6 +150,13 @@ int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const float *shift, 
 int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const void *res, const void *mask, void *gx,
                      int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
                      dcf_stream_t stream);
+/* The same for a stride-2 layer with a kernel wider than 1x1, plus a residual that lives on the (2i, 2j)
+ * sub-grid of gx: resq [B,ceil(H/2),ceil(W/2),Cin] (dtype).  gx = (dgrad + res + scatter(resq)) * (mask > 0).
+ * resq is the input gradient of the block's 1x1 / stride-2 shortcut (reference model.py:27-30, 38-40),
+ * computed on its own grid by dcf_conv2d_dgrad(..., H = ceil(H/2), W = ceil(W/2), stride = 1). */
+int dcf_conv2d_dgrad_halfres(int dtype, const void *gy, const void *wt, const void *res, const void *resq,
+                             const void *mask, void *gx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                             int kh, int kw, int stride, int pad, dcf_stream_t stream);
 /* Weight gradient, split over pixel ranges: slabs fp32 [nsplit][Cout][kh][kw][Cin] (plain stores,
  * reduced in fixed order by dcf_wgrad_finalize => bitwise reproducible).
  * gsum (optional) fp32 [4*nsplit][Cout]: per-wave sums over pixels of gy (dL/dbeta of a folded BN),

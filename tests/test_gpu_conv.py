@@ -285,6 +285,57 @@ def test_conv_dgrad_big_launch(shape, dtype):
     assert float((got3 * (mask <= 0)).abs().max()) == 0.0
 
 
+HALFRES_SHAPES = [
+    (2, 17, 13, 32, 64, 3, 2),       # odd sizes: the even sub-grid is the larger class
+    (2, 10, 10, 128, 192, 3, 2),
+    (3, 24, 40, 64, 128, 3, 2),
+    (1, 704, 800, 32, 64, 3, 2),     # stage-2 entry block at full size (register-staged kernel, 64-byte pixels)
+    (1, 353, 399, 128, 192, 3, 2),   # odd sizes, unequal parity classes
+]
+
+
+@pytest.mark.parametrize("dtype", [1, 0, 2])
+@pytest.mark.parametrize("shape", HALFRES_SHAPES)
+def test_conv_dgrad_halfres_residual(shape, dtype):
+    """dcf_conv2d_dgrad_halfres: the residual given on the (2i, 2j) sub-grid is bit-for-bit the full-resolution residual that
+    is zero elsewhere (same kernel, same accumulation order), also next to a full-resolution residual and a mask."""
+    ops = pkg("ops")
+    H = pkg("_hip")
+    B, Hh, W, Cin, Cout, k, s = shape
+    pad = k // 2
+    x, w = _mk(shape, dtype, 71)
+    x.requires_grad_(True)
+    y = F.conv2d(x, w, None, s, pad)
+    gy = q(rnd(tuple(y.shape), 72), dtype)
+    y.backward(gy)
+    wt = w.permute(1, 2, 3, 0).contiguous().cuda().to(TORCH_DT[dtype])
+    gyd = to_dev(gy, dtype)
+    Hq, Wq = (Hh + 1) // 2, (W + 1) // 2
+    rq = q(rnd((B, Cin, Hq, Wq), 73), dtype)
+    full = torch.zeros((B, Cin, Hh, W))
+    full[:, :, ::2, ::2] = rq
+    res = q(rnd((B, Cin, Hh, W), 74), dtype)
+    mask = q(rnd((B, Cin, Hh, W), 75), dtype)
+    a = ops.conv2d_dgrad_halfres(dtype, gyd, wt, None, to_dev(rq, dtype), (B, Hh, W, Cin), k, k, s, pad, to_dev(mask, dtype))
+    b = ops.conv2d_dgrad(dtype, gyd, wt, to_dev(full, dtype), (B, Hh, W, Cin), k, k, s, pad, to_dev(mask, dtype))
+    assert torch.equal(a, b)
+    _assert_quantised_close(from_dev(a), (x.grad + full) * (mask > 0), dtype, "dgrad+resq+mask")
+    c = ops.conv2d_dgrad_halfres(dtype, gyd, wt, to_dev(res, dtype), to_dev(rq, dtype), (B, Hh, W, Cin), k, k, s, pad)
+    _assert_quantised_close(from_dev(c), x.grad + res + full, dtype, "dgrad+res+resq")
+    with pytest.raises(H.DcfError):      # wrong grid
+        ops.conv2d_dgrad_halfres(dtype, gyd, wt, None, to_dev(res, dtype), (B, Hh, W, Cin), k, k, s, pad)
+
+
+def test_conv_dgrad_halfres_rejects_layers_without_parity_classes():
+    ops = pkg("ops")
+    H = pkg("_hip")
+    gy = torch.zeros((1, 8, 8, 32), dtype=torch.bfloat16, device="cuda")
+    wt = torch.zeros((32, 3, 3, 32), dtype=torch.bfloat16, device="cuda")
+    rq = torch.zeros((1, 4, 4, 32), dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(H.DcfError):
+        ops.conv2d_dgrad_halfres(1, gy, wt, None, rq, (1, 8, 8, 32), 3, 3, 1, 1)
+
+
 @pytest.mark.parametrize("dtype", [1, 0])
 @pytest.mark.parametrize("shape", [BIG_SHAPES[0], BIG_SHAPES[5], BIG_SHAPES[3], BIG_SHAPES[9], BIG_SHAPES[10], BIG_SHAPES[12]])
 def test_conv_wgrad_big_launch(shape, dtype):

@@ -226,3 +226,28 @@ def test_assign_arrays_equals_assign_lists_and_generator_state():
             assert np.allclose(row_w, np.array(want_w, np.float32), rtol=0, atol=0)
             if trial == 5:
                 assert len(pos) == cfg["pos_sample_threshold"]
+
+
+def test_profile_names_map_to_kernels_of_the_committed_pmc_summary():
+    """bench.rocprof_kernel turns the runtime's launch names into rocprofv3's (function, template arguments); a name it maps
+    wrongly silently loses its `traffic` figure, so the families of the cfg2 step are pinned to the committed summary."""
+    import csv
+    import glob
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r03*_pmc_traffic.csv")))
+    assert files
+    have = set()
+    for row in csv.DictReader(open(files[-1])):
+        k = row["kernel"]
+        if ">(" not in k:
+            continue
+        head = k.split(">(")[0]
+        have.add((head[:head.index("<")].split("::")[-1].split()[-1], tuple(head[head.index("<") + 1:].replace(" ", "").split(","))))
+    for name in ["conv_fwd_bf16<sp32>", "conv_dgrad_bf16<sp32>", "conv_fwd_bf16<sp64>", "conv_fwd_bf16<rs1,9>", "conv_fwd_bf16<rs0,9>",
+                 "conv_fwd_bf16<rs2,5>"]:
+        func, args = bench.rocprof_kernel(name)
+        assert (func, tuple(args)) in have, (name, func, args)
