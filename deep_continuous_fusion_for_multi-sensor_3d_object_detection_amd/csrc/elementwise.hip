@@ -174,26 +174,65 @@ __global__ void __launch_bounds__(256) k_resize_fwd(const T *x, const T *add, T 
 // gather-form transpose: input pixel (ih,iw) sums every output pixel that sampled it.
 // Candidate output rows form a contiguous window around ih/scale; each is re-derived
 // exactly with src_index, so the result is deterministic (no atomics).
-template <typename T>
-__global__ void __launch_bounds__(256) k_resize_bwd(const T *gy, T *gx, int B, int Hi, int Wi, int Ho, int Wo, int C4, int align,
+template <int V, typename T>
+__device__ __forceinline__ void ldv(const T *p, float (&v)[V])
+{
+    if constexpr (V == 8) ld8(p, v);
+    else { const float4 t = ld4(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+}
+
+template <int V, typename T>
+__device__ __forceinline__ void stv(T *p, const float (&v)[V])
+{
+    if constexpr (V == 8) st8(p, v);
+    else st4(p, make_float4(v[0], v[1], v[2], v[3]));
+}
+
+// V channels per thread (8 when the channel count allows: 16-byte accesses in the 16-bit types, half the index arithmetic
+// per byte -- the search below, not the memory system, is what this kernel waits for)
+template <typename T, int V>
+__global__ void __launch_bounds__(256) k_resize_bwd(const T *gy, T *gx, int B, int Hi, int Wi, int Ho, int Wo, int CV, int align,
                                                     float sh, float sw)
 {
-    const int64_t total = (int64_t)B * Hi * Wi * C4;
+    const int64_t total = (int64_t)B * Hi * Wi * CV;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
-    const int c = (int)(e % C4);
-    int64_t p = e / C4;
+    const int c = (int)(e % CV);
+    int64_t p = e / CV;
     const int iw = (int)(p % Wi); p /= Wi;
     const int ih = (int)(p % Hi);
     const int b = (int)(p / Hi);
-    const int C = C4 * 4;
+    const int C = CV * V;
     const float inv_h = sh > 0.f ? 1.f / sh : (float)Ho, inv_w = sw > 0.f ? 1.f / sw : (float)Wo;
     int oh_lo = (int)floorf(((float)ih - 1.f) * inv_h) - 2, oh_hi = (int)ceilf(((float)ih + 1.f) * inv_h) + 2;
     int ow_lo = (int)floorf(((float)iw - 1.f) * inv_w) - 2, ow_hi = (int)ceilf(((float)iw + 1.f) * inv_w) + 2;
     oh_lo = max(oh_lo, 0); oh_hi = min(oh_hi, Ho - 1);
     ow_lo = max(ow_lo, 0); ow_hi = min(ow_hi, Wo - 1);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const T *base = gy + (int64_t)b * Ho * Wo * C + c * 4;
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    const T *base = gy + (int64_t)b * Ho * Wo * C + c * V;
+    // the columns that sampled iw are the same for every row: found once (up to MAXM of them, in ascending order, so the
+    // sum keeps the order of the plain double loop below, which stays as the path for larger scale factors)
+    constexpr int MAXM = 6;
+    int mcol[MAXM];
+    float mw[MAXM];
+    int nm = 0;
+    for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        int x0, x1;
+        float lx;
+        src_index(ow, sw, align, Wi, x0, x1, lx);
+        float wx = 0.f;
+        if (x0 == iw) wx += 1.f - lx;
+        if (x1 == iw) wx += lx;
+        if (wx == 0.f) continue;
+        if (nm < MAXM) {
+#pragma unroll
+            for (int k = 0; k < MAXM; ++k)
+                if (k == nm) { mcol[k] = ow; mw[k] = wx; }
+        }
+        ++nm;
+    }
     for (int oh = oh_lo; oh <= oh_hi; ++oh) {
         int y0, y1;
         float ly;
@@ -202,6 +241,19 @@ __global__ void __launch_bounds__(256) k_resize_bwd(const T *gy, T *gx, int B, i
         if (y0 == ih) wy += 1.f - ly;
         if (y1 == ih) wy += ly;
         if (wy == 0.f) continue;
+        const T *row = base + (int64_t)oh * Wo * C;
+        if (nm <= MAXM) {
+#pragma unroll
+            for (int k = 0; k < MAXM; ++k)
+                if (k < nm) {
+                    float g[V];
+                    ldv<V>(row + (int64_t)mcol[k] * C, g);
+                    const float wgt = wy * mw[k];
+#pragma unroll
+                    for (int q = 0; q < V; ++q) acc[q] += wgt * g[q];
+                }
+            continue;
+        }
         for (int ow = ow_lo; ow <= ow_hi; ++ow) {
             int x0, x1;
             float lx;
@@ -210,12 +262,14 @@ __global__ void __launch_bounds__(256) k_resize_bwd(const T *gy, T *gx, int B, i
             if (x0 == iw) wx += 1.f - lx;
             if (x1 == iw) wx += lx;
             if (wx == 0.f) continue;
-            const float4 g = ld4(base + ((int64_t)oh * Wo + ow) * C);
+            float g[V];
+            ldv<V>(row + (int64_t)ow * C, g);
             const float wgt = wy * wx;
-            acc.x += wgt * g.x; acc.y += wgt * g.y; acc.z += wgt * g.z; acc.w += wgt * g.w;
+#pragma unroll
+            for (int q = 0; q < V; ++q) acc[q] += wgt * g[q];
         }
     }
-    st4(gx + e * 4, acc);
+    stv<V>(gx + e * V, acc);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1026,11 +1080,15 @@ extern "C" int dcf_resize_bilinear_bwd(int dtype, const void *gy, void *gx, int 
                                        int align_corners, dcf_stream_t stream)
 {
     DCF_REQUIRE(gy && gx && C % 4 == 0, "dcf_resize_bilinear_bwd: bad arguments");
-    const int64_t total = (int64_t)B * Hi * Wi * (C / 4);
+    const int V = C % 8 == 0 ? 8 : 4;
+    const int64_t total = (int64_t)B * Hi * Wi * (C / V);
     const float sh = resize_scale(Hi, Ho, align_corners), sw = resize_scale(Wi, Wo, align_corners);
     hipStream_t s = S(stream);
     DCF_DISPATCH_DTYPE(dtype, {
-        DCF_LAUNCH_B("resize_bwd", ((double)B * Ho * Wo * C + (double)total * 4) * sizeof(T), s, hipLaunchKernelGGL(k_resize_bwd<T>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)gy, (T *)gx, B, Hi, Wi, Ho, Wo, C / 4,
+        const double bytes = ((double)B * Ho * Wo * C + (double)B * Hi * Wi * C) * sizeof(T);
+        if (V == 8) DCF_LAUNCH_B("resize_bwd", bytes, s, hipLaunchKernelGGL((k_resize_bwd<T, 8>), dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)gy, (T *)gx, B, Hi, Wi, Ho, Wo, C / 8,
+                                                        align_corners, sh, sw));
+        else DCF_LAUNCH_B("resize_bwd", bytes, s, hipLaunchKernelGGL((k_resize_bwd<T, 4>), dim3(cdiv(total, 256)), dim3(256), 0, s, (const T *)gy, (T *)gx, B, Hi, Wi, Ho, Wo, C / 4,
                                                         align_corners, sh, sw));
     })
     return DCF_OK;

@@ -40,7 +40,9 @@ def test_relu_bwd_chansum(dtype):
 
 
 @pytest.mark.parametrize("dtype", [0, 1, 2])
-@pytest.mark.parametrize("case", [((6, 4), (12, 8), True), ((12, 39), (24, 78), False), ((24, 78), (47, 156), False), ((5, 7), (5, 7), False)])
+@pytest.mark.parametrize("case", [((6, 4), (12, 8), True), ((12, 39), (24, 78), False), ((24, 78), (47, 156), False), ((5, 7), (5, 7), False),
+                                  ((44, 50), (88, 100), True), ((5, 6), (23, 31), True), ((4, 5), (19, 26), False),      # x4-5: more matches than the register list holds
+                                  ((20, 30), (9, 13), False), ((21, 17), (8, 6), True)])                                # downsampling
 def test_resize_bilinear(case, dtype):
     ops = pkg("ops")
     (hi, wi), (ho, wo), ac = case
@@ -52,6 +54,18 @@ def test_resize_bilinear(case, dtype):
     gy = q(rnd((2, 64, ho, wo), 9), dtype)
     ref.backward(gy)
     gx = ops.resize_bilinear_bwd(dtype, to_dev(gy, dtype), (hi, wi), ac)
+    assert rel_err(from_dev(gx), x.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_resize_bilinear_bwd_four_channel_granularity(dtype):
+    """Channel counts that are multiples of 4 but not of 8 take the 4-wide instantiation."""
+    ops = pkg("ops")
+    x = q(rnd((2, 36, 9, 11), 17), dtype).requires_grad_(True)
+    ref = F.interpolate(x, size=(18, 22), mode="bilinear", align_corners=True)
+    gy = q(rnd((2, 36, 18, 22), 19), dtype)
+    ref.backward(gy)
+    gx = ops.resize_bilinear_bwd(dtype, to_dev(gy, dtype), (9, 11), True)
     assert rel_err(from_dev(gx), x.grad) < TOL[dtype]
 
 
