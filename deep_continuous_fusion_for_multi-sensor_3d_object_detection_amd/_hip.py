@@ -90,6 +90,8 @@ SIGNATURES = {
     "dcf_fusion_invert": (c_int, [P, c_int, c_int, c_int, P, P, P, P, P]),
     "dcf_fusion_gather_bwd_pts": (c_int, [c_int, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P, P, c_int, P, P, P, P, P]),
     "dcf_fusion_gather_bwd_workspace_bytes": (c_size_t, [c_int]),
+    "dcf_fusion_gather_bwd_direct_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dcf_fusion_gather_bwd_direct_batch": (c_int, [c_int, P, c_i64, P, c_i64, P, P, c_i64, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P, P, c_int, P, P, P, P, P, P, c_int, P]),
     "dcf_fusion_gather_bwd_inv": (c_int, [c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P, P, c_int, P, P, P, P, P, P]),
     "dcf_rowscale_bias_fwd": (c_int, [c_int, P, P, P, c_i64, c_int, P]),
     "dcf_rowscale_bias_bwd": (c_int, [c_int, P, P, P, c_i64, c_int, P]),

@@ -30,6 +30,7 @@ class HipBackend(object):
         self.tdtype = H.torch_dtype(self.dtype)
         self.es = 4 if self.dtype == H.F32 else 2
         self.dev = params.device
+        self._fus_dws = {}                 # fusion backward: boundary-row workspaces per (pairs, channels, frames)
         self.bn_train = False          # batch statistics instead of running statistics (train-mode BatchNorm)
         # fp8 forward path (0 = off): convolutions with cin >= fp8_min_cin (and cin % 64 == 0) read e4m3 images
         self.fp8_min_cin = int(os.environ.get("DCF_FP8_MIN_CIN", fp8_min_cin))
@@ -328,6 +329,8 @@ class HipBackend(object):
     # one-writer-per-point fusion backward (dcf_fusion_gather_bwd_pts: no zero-fill, no atomics on dP, no cast): correct, but a
     # point that thousands of pixels chose is then one wave's serial work -- measured 1.07 vs 0.30 ms per step at cfg2, so off
     _fusion_pts = os.environ.get("DCF_FUSION_PTS", "0") == "1"
+    # "0" = the fp32 accumulator + cast form of the inverse-map backward again (A/B runs)
+    _fusion_direct = os.environ.get("DCF_FUSION_DIRECT", "1") != "0"
 
     def conv_wgrad(self, L, x, gy, defer=True):
         """defer=False: gy (or x) is modified in place later in the backward (e.g. masked by a ReLU) -- launch now."""
@@ -443,11 +446,24 @@ class HipBackend(object):
                 ops.fusion_gather_bwd_pts(self.dtype, P[b], xyz[b], inv, inv_nmax or P.shape[1], site * P.shape[0] + b, tuple(idx.shape[-3:]), stride, aff,
                                           self.params[w1d_off:], self.params[b1_off:], ghsum[b], gP[b], self.grads[w1d_off:], self.grads[b1_off:])
             return gP
+        batched = use_inv and P.is_contiguous() and xyz.is_contiguous() and ghsum.is_contiguous() and P.shape[0] <= 64
+        if use_inv and self._fus_ws is None:
+            self._fus_ws = ops.fusion_bwd_workspace(self.dev)             # zeroed once: the kernel leaves it zero
+        if batched and self._fusion_direct:
+            # gP in the compute dtype, one (half-size) fill for the four sites, no cast: see dcf_fusion_gather_bwd_direct_batch
+            gP = self._gp_zeros(P.shape, P.dtype)
+            me = idx.shape[-3] * idx.shape[-2] * idx.shape[-1]
+            key = (me, P.shape[2], P.shape[0])
+            dws = self._fus_dws.get(key)
+            if dws is None:
+                dws = self._fus_dws[key] = ops.fusion_bwd_direct_workspace(self.dev, *key)
+            ops.fusion_gather_bwd_direct_batch(self.dtype, P, xyz, inv, inv_nmax or P.shape[1], site * P.shape[0], tuple(idx.shape[-3:]), stride, aff,
+                                               self.params[w1d_off:], self.params[b1_off:], ghsum, gP, self.grads[w1d_off:], self.grads[b1_off:],
+                                               self._fus_ws, dws)
+            return gP
         gP = self._gp_zeros(P.shape)
         if use_inv:
-            if self._fus_ws is None:
-                self._fus_ws = ops.fusion_bwd_workspace(self.dev)             # zeroed once: the kernel leaves it zero
-            if P.is_contiguous() and xyz.is_contiguous() and ghsum.is_contiguous() and P.shape[0] <= 64:
+            if batched:
                 ops.fusion_gather_bwd_inv_batch(self.dtype, P, xyz, inv, inv_nmax or P.shape[1], site * P.shape[0], tuple(idx.shape[-3:]), stride, aff,
                                                 self.params[w1d_off:], self.params[b1_off:], ghsum, gP, self.grads[w1d_off:], self.grads[b1_off:], self._fus_ws)
                 return gP
@@ -460,15 +476,15 @@ class HipBackend(object):
                                       ghsum[b], gP[b], self.grads[w1d_off:], self.grads[b1_off:])
         return gP
 
-    def _gp_zeros(self, shape):
-        """Zeroed fp32 [B, rows, Cb] accumulator of a site's fusion backward.  The sites of one backward (same B and rows) are carved
-        out of ONE buffer zeroed by one fill when the first of them asks: four fills per step become one."""
+    def _gp_zeros(self, shape, dtype=torch.float32):
+        """Zeroed [B, rows, Cb] gradient / accumulator of a site's fusion backward.  The sites of one backward (same B and rows) are
+        carved out of ONE buffer zeroed by one fill when the first of them asks: four fills per step become one."""
         B, rows, cb = shape
         pool = self._gp_pool
         need = B * rows * cb
-        if pool is None or pool[1] != (B, rows) or pool[2] + need > pool[0].numel():
+        if pool is None or pool[1] != (B, rows, dtype) or pool[2] + need > pool[0].numel():
             total = B * rows * sum(f["cb"] for f in self.plan.fusion) if getattr(self.plan, "fusion", None) else need
-            pool = self._gp_pool = [torch.zeros(max(total, need), dtype=torch.float32, device=self.dev), (B, rows), 0]
+            pool = self._gp_pool = [torch.zeros(max(total, need), dtype=dtype, device=self.dev), (B, rows, dtype), 0]
         off = pool[2]
         pool[2] = off + need
         return pool[0][off:off + need].view(B, rows, cb)

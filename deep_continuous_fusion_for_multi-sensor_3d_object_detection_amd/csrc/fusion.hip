@@ -316,12 +316,20 @@ __global__ void __launch_bounds__(CJ >= 4 ? FGI_THREADS / 2 : FGI_THREADS) k_fus
                                                                const int *__restrict__ ent_pix, const int *__restrict__ ent_pt, FuseGeom g,
                                                                const float *__restrict__ w1d, const float *__restrict__ b1, int C,
                                                                const T *__restrict__ ghsum, void *gPv, float *gw1d, float *gb1, int SL, float *part,
-                                                               FrameStride fs)
+                                                               FrameStride fs, float *bws = nullptr, int nslots = 0)
 {
     // batched launch: frame blockIdx.y -- P / gP rows (a), xyz (b), the map's start segment (c: e_begin and e_end), ghsum (d)
     P += blockIdx.y * fs.a; xyz += blockIdx.y * fs.b; e_begin += blockIdx.y * fs.c; e_end += blockIdx.y * fs.c; ghsum += blockIdx.y * fs.d;
-    float *gP = reinterpret_cast<float *>(gPv) + (EXCL ? 0 : blockIdx.y * fs.a);
-    T *gPt = reinterpret_cast<T *>(gPv) + (EXCL ? blockIdx.y * fs.a : 0);
+    // DIRECT (bws != null, not EXCL): gP is in the compute type and zero on entry.  A point whose pairs all sit in one slice has one
+    // writer: its row is stored whole.  A point whose run crosses slice boundaries is summed in an fp32 row of the workspace
+    // (row = the slice its run starts in -- that slice's last point, so a row serves one point) by the slices of its run; each
+    // takes a ticket once its atomics are acknowledged and the last one reads the row back (atomic exchanges, which also leave
+    // it zero for the next launch) and stores it.  No fp32 accumulator the size of gP to zero before and to cast after.
+    const bool direct = !EXCL && bws != nullptr;
+    float *gP = reinterpret_cast<float *>(gPv) + ((EXCL || direct) ? 0 : blockIdx.y * fs.a);
+    T *gPt = reinterpret_cast<T *>(gPv) + ((EXCL || direct) ? blockIdx.y * fs.a : 0);
+    float *bslot = bws + (size_t)blockIdx.y * nslots * (C + 1);
+    unsigned *bcnt = reinterpret_cast<unsigned *>(bslot + (size_t)nslots * C);
     constexpr int U = 8;
     extern __shared__ float sm[];  // [C][4]: gw1d x3, gb1
     for (int i = threadIdx.x; i < C * 4; i += blockDim.x) sm[i] = 0.f;
@@ -337,6 +345,25 @@ __global__ void __launch_bounds__(CJ >= 4 ? FGI_THREADS / 2 : FGI_THREADS) k_fus
     auto store_row = [&](int pt, const float (&acc)[CJ]) {
 #pragma unroll
         for (int j = 0; j < CJ; ++j) DT<T>::st(gPt + (int64_t)pt * C + lane + 64 * j, acc[j]);
+    };
+    auto shared_row = [&](int pt, const float (&acc)[CJ], int e0) {
+        const int rs = e_begin[pt], re = e_begin[pt + 1];             // the point's run of pairs
+        const int s_first = (rs - e0) / SL, s_last = (re - 1 - e0) / SL;
+        float *row = bslot + (size_t)s_first * C;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j)
+            if (acc[j] != 0.f) atomicAdd(row + lane + 64 * j, acc[j]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(&bcnt[s_first], 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t == (unsigned)(s_last - s_first)) {                      // the last of the run's s_last - s_first + 1 slices
+            float tot[CJ];
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) tot[j] = atomicExch(row + lane + 64 * j, 0.f);
+            store_row(pt, tot);
+            if (lane == 0) atomicExch(&bcnt[s_first], 0u);
+        }
     };
     auto zero_rows = [&](int a, int b) {
         for (int rr = a; rr < b; ++rr)
@@ -354,6 +381,7 @@ __global__ void __launch_bounds__(CJ >= 4 ? FGI_THREADS / 2 : FGI_THREADS) k_fus
       for (int sidx = EXCL ? 0 : wave; EXCL ? (sidx == 0) : (E0 + sidx * SL < E); sidx += nwaves) {
         const int lo = E0 + sidx * SLICE, hi = EXCL ? E : min(E, lo + SLICE);
         int cur_pt = -1;
+        bool first_shared = direct && lo > E0 && ent_pt[lo - 1] == ent_pt[lo];   // the slice's first point began in an earlier slice
         auto bcast_i = [](int v, int i) { return __builtin_amdgcn_readlane(v, i); };
         auto bcast_f = [](float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); };
         for (int base = lo; base < hi; base += 64) {
@@ -391,6 +419,9 @@ __global__ void __launch_bounds__(CJ >= 4 ? FGI_THREADS / 2 : FGI_THREADS) k_fus
                             if (EXCL) {
                                 store_row(cur_pt, cur_acc);
                                 next_row = cur_pt + 1;
+                            } else if (direct) {
+                                if (first_shared) shared_row(cur_pt, cur_acc, E0); else store_row(cur_pt, cur_acc);
+                                first_shared = false;
                             } else {
 #pragma unroll
                                 for (int j = 0; j < CJ; ++j)
@@ -416,6 +447,9 @@ __global__ void __launch_bounds__(CJ >= 4 ? FGI_THREADS / 2 : FGI_THREADS) k_fus
             if (EXCL) {
                 store_row(cur_pt, cur_acc);
                 next_row = cur_pt + 1;
+            } else if (direct) {
+                const bool last_shared = hi < E && ent_pt[hi] == cur_pt;
+                if (first_shared || last_shared) shared_row(cur_pt, cur_acc, E0); else store_row(cur_pt, cur_acc);
             } else {
 #pragma unroll
                 for (int j = 0; j < CJ; ++j)
@@ -583,22 +617,29 @@ extern "C" int dcf_fusion_gather_bwd(int dtype, const void *P, const float *xyz,
     return DCF_OK;
 }
 
+// pairs per wave ("slice"): 128 on the big sites; the coarse sites have few pairs (6.6 k at stride 16) and would otherwise run on
+// a few dozen waves, one exposed latency after the other
+static int fgi_slice(int max_entries)
+{
+    int sl = cdiv(cdiv(max_entries, 4096), 16) * 16;
+    return sl < 16 ? 16 : (sl > 128 ? 128 : sl);
+}
+
 static int fusion_gather_bwd_inv_impl(const char *who, int dtype, const void *P, int64_t p_rows, const float *xyz, int64_t xyz_fstride, const int32_t *e_begin,
                                       const int32_t *e_end, int64_t seg_fstride, const int32_t *ent_pix, const int32_t *ent_pt, int max_entries, int h,
                                       int w, int stride, float xs, float xo, float ys, float yo, const float *w1d, const float *b1, int Cb,
-                                      const void *ghsum, float *gP, float *gw1d, float *gb1, void *workspace, int B, hipStream_t s)
+                                      const void *ghsum, void *gP, float *gw1d, float *gb1, void *workspace, int B, hipStream_t s,
+                                      void *direct_ws = nullptr)
 {
     float *ws = reinterpret_cast<float *>(workspace);
+    float *bws = reinterpret_cast<float *>(direct_ws);
     DCF_REQUIRE(P && xyz && e_begin && e_end && ent_pix && ent_pt && w1d && b1 && ghsum && gP && gw1d && gb1, "%s: null pointer", who);
     DCF_REQUIRE(Cb % 64 == 0 && Cb >= 64 && Cb <= 256, "%s: Cb must be 64, 128, 192 or 256 (got %d)", who, Cb);
     DCF_REQUIRE(B >= 1 && B <= 64, "%s: 1..64 frames", who);
     if (max_entries <= 0) return DCF_OK;
     FuseGeom g;
     g.h = h; g.w = w; g.stride = stride; g.K = 0; g.xs = xs; g.xo = xo; g.ys = ys; g.yo = yo;
-    // pairs per wave: 128 on the big sites; the coarse sites have few pairs (6.6 k at stride 16) and would otherwise run on
-    // a few dozen waves, one exposed latency after the other
-    int sl = cdiv(cdiv(max_entries, 4096), 16) * 16;
-    sl = sl < 16 ? 16 : (sl > 128 ? 128 : sl);
+    const int sl = fgi_slice(max_entries);
     const int waves = cdiv(max_entries, sl);
     static DcfOpt cap_env_o("FUSION_BWD_BLOCKS"); const char *cap_env = cap_env_o.str();
     // swept (one frame per launch): 128 / 256 / 512 / uncapped = 0.52 / 0.34 / 0.36 / 0.44 ms per step; a batched launch shares the cap
@@ -608,7 +649,7 @@ static int fusion_gather_bwd_inv_impl(const char *who, int dtype, const void *P,
     const int blocks = std::min(cdiv(waves, thr / 64), cap);
     const FrameStride fs = {p_rows * Cb, xyz_fstride, seg_fstride, (int64_t)h * w * Cb, 0};
     // (one profile name per instantiation, as rocprofv3 lists them: the four sites run four different kernels)
-#define DCF_FGI(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_inv<" #CJ_ ">", (double)B * max_entries * (8.0 + 2.0 * Cb * sizeof(T)), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_, false>), dim3(blocks, B), dim3(thr), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, sl, ws, fs))
+#define DCF_FGI(CJ_) DCF_LAUNCH_B("fusion_gather_bwd_inv<" #CJ_ ">", (double)B * max_entries * (8.0 + 2.0 * Cb * sizeof(T)), s, hipLaunchKernelGGL((k_fusion_gather_bwd_inv<T, CJ_, false>), dim3(blocks, B), dim3(thr), sizeof(float) * Cb * 4, s, (const T *)P, xyz, e_begin, e_end, ent_pix, ent_pt, g, w1d, b1, Cb, (const T *)ghsum, gP, gw1d, gb1, sl, ws, fs, bws, waves))
     DCF_DISPATCH_DTYPE(dtype, {
         if (Cb == 64) DCF_FGI(1);
         else if (Cb == 128) DCF_FGI(2);
@@ -638,6 +679,26 @@ extern "C" int dcf_fusion_gather_bwd_inv_batch(int dtype, const void *P, int64_t
 {
     return fusion_gather_bwd_inv_impl("dcf_fusion_gather_bwd_inv_batch", dtype, P, p_rows, xyz, xyz_fstride, e_begin, e_end, seg_fstride, ent_pix, ent_pt,
                                       max_entries, h, w, stride, xs, xo, ys, yo, w1d, b1, Cb, ghsum, gP, gw1d, gb1, workspace, B, S(stream));
+}
+
+// The same sums with gP in the COMPUTE type (dtype), zero on entry: rows whose pairs sit in one slice are stored whole, rows that
+// cross slices are summed in `direct_ws` (dcf_fusion_gather_bwd_direct_workspace_bytes; zero on entry, left zero) and stored by
+// the last slice of the run -- no fp32 accumulator the size of gP to fill before the launch and to cast after it.
+extern "C" size_t dcf_fusion_gather_bwd_direct_workspace_bytes(int max_entries, int Cb, int B)
+{
+    if (max_entries <= 0 || B <= 0) return 0;
+    return (size_t)B * cdiv(max_entries, fgi_slice(max_entries)) * (Cb + 1) * sizeof(float);
+}
+
+extern "C" int dcf_fusion_gather_bwd_direct_batch(int dtype, const void *P, int64_t p_rows, const float *xyz, int64_t xyz_fstride, const int32_t *e_begin,
+                                                  const int32_t *e_end, int64_t seg_fstride, const int32_t *ent_pix, const int32_t *ent_pt,
+                                                  int max_entries, int h, int w, int stride, float xs, float xo, float ys, float yo, const float *w1d,
+                                                  const float *b1, int Cb, const void *ghsum, void *gP, float *gw1d, float *gb1, void *workspace,
+                                                  void *direct_ws, int B, dcf_stream_t stream)
+{
+    DCF_REQUIRE(direct_ws, "dcf_fusion_gather_bwd_direct_batch: null direct_ws");
+    return fusion_gather_bwd_inv_impl("dcf_fusion_gather_bwd_direct_batch", dtype, P, p_rows, xyz, xyz_fstride, e_begin, e_end, seg_fstride, ent_pix, ent_pt,
+                                      max_entries, h, w, stride, xs, xo, ys, yo, w1d, b1, Cb, ghsum, gP, gw1d, gb1, workspace, B, S(stream), direct_ws);
 }
 
 // Same sums with one writer per point row (see k_fusion_gather_bwd_inv<.., EXCL>): gP [n_rows][Cb] in the COMPUTE type, every row

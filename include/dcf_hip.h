@@ -354,6 +354,19 @@ int dcf_fusion_gather_bwd_inv_batch(int dtype, const void *P, int64_t p_rows, co
                                     int h, int w, int stride, float xs, float xo, float ys, float yo, const float *w1d, const float *b1, int Cb,
                                     const void *ghsum, float *gP, float *gw1d, float *gb1, void *workspace, int B, dcf_stream_t stream);
 
+/* The same sums with gP [B][p_rows][Cb] in the COMPUTE dtype and ZERO on entry (rows of points no pixel chose stay zero): a
+ * point whose pairs all sit in one 16..128-pair slice of the sorted list has one writer and its row is stored whole; a point
+ * whose run crosses slices is summed in an fp32 row of direct_ws by the slices of its run, and the last of them (a ticket per
+ * row) stores it.  direct_ws: dcf_fusion_gather_bwd_direct_workspace_bytes(max_entries, Cb, B) bytes, zero on entry, left zero.
+ * No fp32 accumulator the size of gP to fill before the launch and to cast after it.  (Reference: the autograd of
+ * model.py:210-219 -- index_select / cat / Linear / ReLU / sum -- for dL/d(point features).) */
+size_t dcf_fusion_gather_bwd_direct_workspace_bytes(int max_entries, int Cb, int B);
+int dcf_fusion_gather_bwd_direct_batch(int dtype, const void *P, int64_t p_rows, const float *xyz, int64_t xyz_fstride,
+                                       const int32_t *e_begin, const int32_t *e_end, int64_t seg_fstride, const int32_t *ent_pix,
+                                       const int32_t *ent_pt, int max_entries, int h, int w, int stride, float xs, float xo, float ys,
+                                       float yo, const float *w1d, const float *b1, int Cb, const void *ghsum, void *gP, float *gw1d,
+                                       float *gb1, void *workspace, void *direct_ws, int B, dcf_stream_t stream);
+
 /* The same sums with ONE writer per point row (a wave owns a range of points and all their pairs): gP [n_rows][Cb] in the compute
  * dtype, every row written (zeros where no pixel chose the point) -- no zero-filled fp32 accumulator, no float atomics on gP, no
  * cast afterwards.  start = the map's slice of dcf_fusion_invert's start array (n_rows + 1 entries are read, n_rows <= n_max). */

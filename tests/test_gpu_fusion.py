@@ -447,3 +447,53 @@ def test_batched_fusion_kernels_equal_per_frame_calls(dtype):
     for a_, b_ in ((gw_b, gw_1), (gb_b, gb_1)):
         assert float((a_ - b_).abs().max()) <= 1e-4 * float(b_.abs().max())
     assert float(ws.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("Cb,K,hw,ns", [(64, 3, (24, 40), (200, 1)), (128, 5, (24, 40), (300, 0)), (192, 1, (24, 40), (7, 150)),
+                                        (256, 3, (24, 40), (3, 299)), (64, 3, (176, 200), (3000, 40)), (128, 3, (88, 100), (2500, 2))])
+def test_fusion_backward_direct_rows_match_the_fp32_accumulator_form(Cb, K, hw, ns):
+    """dcf_fusion_gather_bwd_direct_batch (dP stored in the compute dtype by the single writer of a row; rows whose pairs cross a
+    slice boundary summed in the workspace and stored by the run's last slice) against dcf_fusion_gather_bwd_inv_batch (fp32
+    accumulator + atomics), two frames per launch: a dense frame and one with a handful of points / one point / none (runs far
+    longer than a slice).  The workspace must come back zero, and a second launch on it must give the same rows."""
+    ops, H = pkg("ops"), pkg("_hip")
+    g = torch.Generator().manual_seed(23)
+    h, w = hw
+    stride, n_max, B = 4, 3000 if max(ns) > 300 else 300, 2
+    aff = (10.0, 0.0, 10.0, 400.0)
+    xyz = torch.zeros(B, n_max, 3)
+    for b, n in enumerate(ns):
+        xyz[b, :n, 0] = torch.rand(n, generator=g) * (h * stride / aff[0])
+        xyz[b, :n, 1] = torch.rand(n, generator=g) * (w * stride / aff[2]) - aff[3] / aff[2]
+        xyz[b, :n, 2] = torch.rand(n, generator=g) * 2 - 1
+    xyz = xyz.cuda()
+    cnt = torch.tensor(list(ns), dtype=torch.int32, device="cuda")
+    idx = torch.stack([ops.knn_bev(xyz[b], cnt[b:b + 1], K, h, w, stride, aff, 1.0e4) for b in range(B)], 0)
+    inv = ops.fusion_invert([idx[b] for b in range(B)], n_max)
+    w1d = ((torch.rand(Cb, 3, generator=g) - 0.5) * 0.2).cuda().reshape(-1)
+    b1 = ((torch.rand(Cb, generator=g) - 0.5) * 0.2).cuda()
+    for dtype in (H.BF16, H.F32, H.F16):
+        tdt = H.torch_dtype(dtype)
+        P = (torch.rand(B, n_max, Cb, generator=g) - 0.5).cuda().to(tdt)
+        ghs = (torch.rand(B, h, w, Cb, generator=g) - 0.5).cuda().to(tdt)
+        ws = ops.fusion_bwd_workspace("cuda")
+        ref = [torch.zeros(B, n_max, Cb, device="cuda"), torch.zeros(Cb * 3, device="cuda"), torch.zeros(Cb, device="cuda")]
+        ops.fusion_gather_bwd_inv_batch(dtype, P, xyz, inv, n_max, 0, (K, h, w), stride, aff, w1d, b1, ghs, *ref, ws)
+        dws = ops.fusion_bwd_direct_workspace("cuda", K * h * w, Cb, B)
+        runs = []
+        for _ in range(2):
+            got = [torch.zeros(B, n_max, Cb, device="cuda", dtype=tdt), torch.zeros(Cb * 3, device="cuda"), torch.zeros(Cb, device="cuda")]
+            ops.fusion_gather_bwd_direct_batch(dtype, P, xyz, inv, n_max, 0, (K, h, w), stride, aff, w1d, b1, ghs, *got, ws, dws)
+            runs.append(got)
+            assert float(dws.abs().max()) == 0.0 and float(ws.abs().max()) == 0.0
+        got = runs[0]
+        # rows: one rounding to the storage type on top of the fp32 sums (whose order differs between the two kernels)
+        ulp = {H.F32: 2.0 ** -22, H.BF16: 2.0 ** -8, H.F16: 2.0 ** -11}[dtype]
+        scale = max(float(ref[0].abs().max()), 1e-6)
+        err = (got[0].float() - ref[0]).abs()
+        assert bool((err <= ulp * ref[0].abs() + 2e-5 * scale * max(1.0, (h * w) ** 0.5 / 8)).all()), (Cb, ns, dtype, float(err.max()), scale)
+        assert float((runs[1][0].float() - got[0].float()).abs().max()) <= 2 * ulp * scale + 1e-5 * scale * (h * w) ** 0.5 / 8
+        for a, b in ((got[1], ref[1]), (got[2], ref[2])):
+            assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1e-6)
+    with pytest.raises(H.DcfError):
+        ops.fusion_gather_bwd_direct_batch(dtype, P, xyz, inv, n_max, 0, (K, h, w), stride, aff, w1d, b1, ghs, *got, ws, dws[:8])
