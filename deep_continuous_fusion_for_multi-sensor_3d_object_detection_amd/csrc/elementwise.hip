@@ -79,37 +79,73 @@ __global__ void __launch_bounds__(256) k_image_to_nhwc4(const uint8_t *img, T *y
 // (ReLU: model.py:21,25,40; the channel sum is dL/d(beta) of the folded BatchNorm.)
 // Each thread owns one 4-channel group for its whole grid-stride loop.
 // ------------------------------------------------------------------------------------
-template <typename T>
+template <int V, typename T>
+__device__ __forceinline__ void ldv(const T *p, float (&v)[V])
+{
+    if constexpr (V == 8) ld8(p, v);
+    else { const float4 t = ld4(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+}
+
+template <int V, typename T>
+__device__ __forceinline__ void stv(T *p, const float (&v)[V])
+{
+    if constexpr (V == 8) st8(p, v);
+    else st4(p, make_float4(v[0], v[1], v[2], v[3]));
+}
+
+// V channels per thread (8 when the channel count allows); two elements per trip with both elements' loads issued before the
+// first store (the tensor is updated in place: behind a store that may alias it the next load would wait for its own trip).
+template <typename T, int V>
 __global__ void __launch_bounds__(256) k_relu_bwd_chansum(T *gy, const T *y, float *gsum, int64_t nvec, int cgroups, int relu,
                                                           int64_t stride)
 {
-    extern __shared__ float sm[];  // [cgroups*4]
-    for (int i = threadIdx.x; i < cgroups * 4; i += blockDim.x) sm[i] = 0.f;
+    extern __shared__ float sm[];  // [cgroups*V]
+    for (int i = threadIdx.x; i < cgroups * V; i += blockDim.x) sm[i] = 0.f;
     __syncthreads();
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < stride) {
         const int cg = (int)(t % cgroups);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t e = t; e < nvec; e += stride) {
-            float4 g = ld4(gy + e * 4);
-            if (relu) {
-                const float4 yy = ld4(y + e * 4);
-                g.x = yy.x > 0.f ? g.x : 0.f;
-                g.y = yy.y > 0.f ? g.y : 0.f;
-                g.z = yy.z > 0.f ? g.z : 0.f;
-                g.w = yy.w > 0.f ? g.w : 0.f;
-                st4(gy + e * 4, g);
+        float acc[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) acc[q] = 0.f;
+        int64_t e = t;
+        for (; e + stride < nvec; e += 2 * stride) {
+            float g[2][V], yy[2][V];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                ldv<V>(gy + (e + u * stride) * V, g[u]);
+                if (relu) ldv<V>(y + (e + u * stride) * V, yy[u]);
             }
-            acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (relu) {
+#pragma unroll
+                    for (int q = 0; q < V; ++q) g[u][q] = yy[u][q] > 0.f ? g[u][q] : 0.f;
+                    stv<V>(gy + (e + u * stride) * V, g[u]);
+                }
+#pragma unroll
+                for (int q = 0; q < V; ++q) acc[q] += g[u][q];
+            }
         }
-        atomicAdd(&sm[cg * 4 + 0], acc.x);
-        atomicAdd(&sm[cg * 4 + 1], acc.y);
-        atomicAdd(&sm[cg * 4 + 2], acc.z);
-        atomicAdd(&sm[cg * 4 + 3], acc.w);
+        for (; e < nvec; e += stride) {
+            float g[V];
+            ldv<V>(gy + e * V, g);
+            if (relu) {
+                float yy[V];
+                ldv<V>(y + e * V, yy);
+#pragma unroll
+                for (int q = 0; q < V; ++q) g[q] = yy[q] > 0.f ? g[q] : 0.f;
+                stv<V>(gy + e * V, g);
+            }
+#pragma unroll
+            for (int q = 0; q < V; ++q) acc[q] += g[q];
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) atomicAdd(&sm[cg * V + q], acc[q]);
     }
     __syncthreads();
     if (gsum)
-        for (int i = threadIdx.x; i < cgroups * 4; i += blockDim.x) atomicAdd(&gsum[i], sm[i]);
+        for (int i = threadIdx.x; i < cgroups * V; i += blockDim.x) atomicAdd(&gsum[i], sm[i]);
 }
 
 // ------------------------------------------------------------------------------------
@@ -174,20 +210,6 @@ __global__ void __launch_bounds__(256) k_resize_fwd(const T *x, const T *add, T 
 // gather-form transpose: input pixel (ih,iw) sums every output pixel that sampled it.
 // Candidate output rows form a contiguous window around ih/scale; each is re-derived
 // exactly with src_index, so the result is deterministic (no atomics).
-template <int V, typename T>
-__device__ __forceinline__ void ldv(const T *p, float (&v)[V])
-{
-    if constexpr (V == 8) ld8(p, v);
-    else { const float4 t = ld4(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-}
-
-template <int V, typename T>
-__device__ __forceinline__ void stv(T *p, const float (&v)[V])
-{
-    if constexpr (V == 8) st8(p, v);
-    else st4(p, make_float4(v[0], v[1], v[2], v[3]));
-}
-
 // V channels per thread (8 when the channel count allows: 16-byte accesses in the 16-bit types, half the index arithmetic
 // per byte -- the search below, not the memory system, is what this kernel waits for)
 template <typename T, int V>
@@ -851,30 +873,47 @@ __global__ void __launch_bounds__(256) k_rowscale_bias_fwd(T *y, const float *cn
     st4(y + e * 4, v);
 }
 
-template <typename T>
+// V channels per thread and four independent loads in flight per thread: the kernel is a latency-bound stream (a grid that fits
+// the atomics at its end -- 256 workgroups -- has to keep ~8 MB in flight to run at the memory's rate)
+template <typename T, int V>
 __global__ void __launch_bounds__(256) k_rowscale_bias_bwd(const T *gy, const float *cnt, float *gb2, int64_t nvec, int cgroups, int64_t stride)
 {
     extern __shared__ float sm[];
-    for (int i = threadIdx.x; i < cgroups * 4; i += blockDim.x) sm[i] = 0.f;
+    for (int i = threadIdx.x; i < cgroups * V; i += blockDim.x) sm[i] = 0.f;
     __syncthreads();
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < stride) {
         const int cg = (int)(t % cgroups);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float acc[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) acc[q] = 0.f;
         int64_t p = t / cgroups;                          // pixel of element e; stride is a multiple of cgroups
         const int64_t pstep = stride / cgroups;
-        for (int64_t e = t; e < nvec; e += stride, p += pstep) {
-            const float4 g = ld4(gy + e * 4);
-            const float k = cnt[p];
-            acc.x += k * g.x; acc.y += k * g.y; acc.z += k * g.z; acc.w += k * g.w;
+        int64_t e = t;
+        for (; e + 3 * stride < nvec; e += 4 * stride, p += 4 * pstep) {
+            float g[4][V], k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ldv<V>(gy + (e + u * stride) * V, g[u]);
+                k[u] = cnt[p + u * pstep];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < V; ++q) acc[q] += k[u] * g[u][q];
         }
-        atomicAdd(&sm[cg * 4 + 0], acc.x);
-        atomicAdd(&sm[cg * 4 + 1], acc.y);
-        atomicAdd(&sm[cg * 4 + 2], acc.z);
-        atomicAdd(&sm[cg * 4 + 3], acc.w);
+        for (; e < nvec; e += stride, p += pstep) {
+            float g[V];
+            ldv<V>(gy + e * V, g);
+            const float k = cnt[p];
+#pragma unroll
+            for (int q = 0; q < V; ++q) acc[q] += k * g[q];
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) atomicAdd(&sm[cg * V + q], acc[q]);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < cgroups * 4; i += blockDim.x) atomicAdd(&gb2[i], sm[i]);
+    for (int i = threadIdx.x; i < cgroups * V; i += blockDim.x) atomicAdd(&gb2[i], sm[i]);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1049,15 +1088,17 @@ extern "C" int dcf_relu_bwd_chansum(int dtype, void *gy, const void *y, float *g
                                     dcf_stream_t stream)
 {
     DCF_REQUIRE(gy && C % 4 == 0 && (!relu || y), "dcf_relu_bwd_chansum: bad arguments");
-    const int cg = C / 4;
+    const int V = C % 8 == 0 ? 8 : 4;
+    const int cg = C / V;
     const int64_t nvec = npix * cg;
     if (nvec == 0) return DCF_OK;
     int blocks;
     const int64_t stride = chan_stride(nvec, cg, blocks);
     hipStream_t s = S(stream);
     DCF_DISPATCH_DTYPE(dtype, {
-        DCF_LAUNCH_B("relu_bwd_chansum", (double)nvec * 4 * sizeof(T) * (relu ? 3 : 1), s, hipLaunchKernelGGL(k_relu_bwd_chansum<T>, dim3(blocks), dim3(256), sizeof(float) * C, s, (T *)gy, (const T *)y, gsum,
-                                                              nvec, cg, relu, stride));
+        const double bytes = (double)npix * C * sizeof(T) * (relu ? 3 : 1);
+        if (V == 8) DCF_LAUNCH_B("relu_bwd_chansum", bytes, s, hipLaunchKernelGGL((k_relu_bwd_chansum<T, 8>), dim3(blocks), dim3(256), sizeof(float) * C, s, (T *)gy, (const T *)y, gsum, nvec, cg, relu, stride));
+        else DCF_LAUNCH_B("relu_bwd_chansum", bytes, s, hipLaunchKernelGGL((k_relu_bwd_chansum<T, 4>), dim3(blocks), dim3(256), sizeof(float) * C, s, (T *)gy, (const T *)y, gsum, nvec, cg, relu, stride));
     })
     return DCF_OK;
 }
@@ -1251,14 +1292,19 @@ extern "C" int dcf_rowscale_bias_fwd(int dtype, void *y, const float *cnt, const
 extern "C" int dcf_rowscale_bias_bwd(int dtype, const void *gy, const float *cnt, float *gb2, int64_t npix, int C, dcf_stream_t stream)
 {
     DCF_REQUIRE(gy && cnt && gb2 && C % 4 == 0, "dcf_rowscale_bias_bwd: bad arguments");
-    const int cg = C / 4;
+    const int V = C % 8 == 0 ? 8 : 4;
+    const int cg = C / V;
     const int64_t nvec = npix * cg;
     if (nvec == 0) return DCF_OK;
     int blocks;
     // every workgroup ends with C same-address atomics on gb2: 256 workgroups instead of 1024 (0.118 -> 0.068 ms per step)
     const int64_t stride = chan_stride(nvec, cg, blocks, 64);
     hipStream_t s = S(stream);
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("rowscale_bias_bwd", (double)nvec * 4 * sizeof(T) + npix * 4.0, s, hipLaunchKernelGGL(k_rowscale_bias_bwd<T>, dim3(blocks), dim3(256), sizeof(float) * C, s, (const T *)gy, cnt, gb2, nvec, cg, stride)); })
+    DCF_DISPATCH_DTYPE(dtype, {
+        const double bytes = (double)npix * C * sizeof(T) + npix * 4.0;
+        if (V == 8) DCF_LAUNCH_B("rowscale_bias_bwd", bytes, s, hipLaunchKernelGGL((k_rowscale_bias_bwd<T, 8>), dim3(blocks), dim3(256), sizeof(float) * C, s, (const T *)gy, cnt, gb2, nvec, cg, stride));
+        else DCF_LAUNCH_B("rowscale_bias_bwd", bytes, s, hipLaunchKernelGGL((k_rowscale_bias_bwd<T, 4>), dim3(blocks), dim3(256), sizeof(float) * C, s, (const T *)gy, cnt, gb2, nvec, cg, stride));
+    })
     return DCF_OK;
 }
 

@@ -39,6 +39,45 @@ def test_relu_bwd_chansum(dtype):
         assert torch.allclose(gsum.cpu(), gy.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("C,hw", [(64, (300, 400)), (36, (150, 130)), (256, (90, 100))])
+def test_relu_bwd_chansum_grid_stride_trips(C, hw, dtype):
+    """Sizes at which a thread walks several elements (two per trip + a tail) and the 4-channel instantiation (C = 36)."""
+    ops = pkg("ops")
+    y = q(torch.relu(rnd((2, C) + hw, 31)), dtype)
+    gy = q(rnd((2, C) + hw, 32), dtype)
+    gsum = torch.zeros(C, device="cuda")
+    g = to_dev(gy, dtype)
+    ops.relu_bwd_chansum(dtype, g, to_dev(y, dtype), gsum, True)
+    ref = gy * (y > 0)
+    assert torch.equal(from_dev(g), ref)
+    want = ref.double().sum((0, 2, 3))
+    assert float((gsum.cpu().double() - want).abs().max()) <= 1e-4 * float(ref.abs().double().sum((0, 2, 3)).max())
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("C,npix", [(64, 70000), (36, 9001), (256, 17600), (128, 300)])
+def test_rowscale_bias_fwd_bwd(C, npix, dtype):
+    """fc2's bias under the neighbour sum (model.py:216-219: sum_k (W2 h_k + b2) = W2 sum_k h_k + cnt * b2): y += cnt[p] * b2[c]
+    and db2[c] += sum_p cnt[p] * g[p, c], against fp64 sums."""
+    ops = pkg("ops")
+    g = torch.Generator().manual_seed(5)
+    cnt = torch.randint(0, 4, (npix,), generator=g).float()
+    b2 = rnd((C,), 41)
+    y = q(rnd((npix, C), 42), dtype)
+    yd = to_dev(y.view(1, npix, 1, C).permute(0, 3, 1, 2), dtype).view(npix, C)
+    out = ops.rowscale_bias_fwd(dtype, yd, cnt.cuda(), b2.cuda())
+    want = y + cnt[:, None] * b2[None, :]
+    assert rel_err(out.float().cpu(), want) < TOL[dtype]
+    gy = q(rnd((npix, C), 43), dtype)
+    gd = to_dev(gy.view(1, npix, 1, C).permute(0, 3, 1, 2), dtype).view(npix, C)
+    gb = torch.full((C,), 0.5, device="cuda")
+    ops.rowscale_bias_bwd(dtype, gd, cnt.cuda(), gb)
+    ref = (cnt[:, None].double() * gy.double()).sum(0) + 0.5
+    bound = 1e-5 * float((cnt[:, None].double() * gy.double().abs()).sum(0).max()) + 1e-6
+    assert float((gb.cpu().double() - ref).abs().max()) <= bound
+
+
 @pytest.mark.parametrize("dtype", [0, 1, 2])
 @pytest.mark.parametrize("case", [((6, 4), (12, 8), True), ((12, 39), (24, 78), False), ((24, 78), (47, 156), False), ((5, 7), (5, 7), False),
                                   ((44, 50), (88, 100), True), ((5, 6), (23, 31), True), ((4, 5), (19, 26), False),      # x4-5: more matches than the register list holds
