@@ -1470,6 +1470,8 @@ struct dcf_wgs_item {
     float *slabs, *gsum;
     int B, H, W, Cin, Cout, nsplit;
 };
+int dcf_wgrad3v_splits(int B, int H, int W, int Cin, int Cout);
+int dcf_wgrad3v_launch(int dtype, const void *x, const void *gy, float *slabs, float *gsum, int nsplit, int B, int H, int W, double flops, hipStream_t s);
 int dcf_wgrad3s_kind(int dtype, int B, int H, int W, int Cin, int Cout);
 int dcf_wgrad3s_splits(int kind, int B, int H, int W, int Cin, int Cout);
 int dcf_wgrad3s_launch(int dtype, int kind, const dcf_wgs_item *items, int n, double flops, double bytes, hipStream_t s);
@@ -1604,6 +1606,8 @@ extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout,
     int TM, TN, KR;
     int tiles;
     if (kh == 3 && kw == 3 && stride == 1) {      // (the 16-bit kernel's choice also for fp32 launches of the shape: any count works there)
+        const int nv = dcf_wgrad3v_splits(B, Ho, Wo, Cin, Cout);
+        if (nv) return nv;
         const int kind = dcf_wgrad3s_kind(DCF_BF16, B, Ho, Wo, Cin, Cout);
         if (kind) return dcf_wgrad3s_splits(kind, B, Ho, Wo, Cin, Cout);
     }
@@ -1663,6 +1667,7 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
     const double wbytes_ = (double)a.xbytes + (double)a.gbytes + (double)nsplit * Cout * kh * kw * Cin * 4.0;
     int TM, TN, KR;
     if (pad == 1 && H == Ho && W == Wo && kh == 3 && kw == 3 && stride == 1) {
+        if (dtype != DCF_F32 && dcf_wgrad3v_splits(B, H, W, Cin, Cout)) return dcf_wgrad3v_launch(dtype, x, gy, slabs, gsum, nsplit, B, H, W, flops, s);
         const int kind = dcf_wgrad3s_kind(dtype, B, H, W, Cin, Cout);
         if (kind) {
             const dcf_wgs_item it = {x, gy, slabs, gsum, B, H, W, Cin, Cout, nsplit};

@@ -34,6 +34,12 @@ SHAPES = [
     (2, 37, 61, 64, 64, 3, 1),
     (1, 75, 83, 128, 128, 3, 1),
     (3, 41, 43, 192, 128, 3, 1),
+    # strip-walking weight-gradient kernel of the 32 -> 32 layers (conv_wgv.hip): widths that are no multiple of the 32-column
+    # strip, heights that are no multiple of the row range, fewer units than a workgroup has waves, several frames
+    (2, 37, 45, 32, 32, 3, 1),
+    (3, 9, 100, 32, 32, 3, 1),
+    (1, 8, 8, 32, 32, 3, 1),
+    (2, 130, 33, 32, 32, 3, 1),
     # shared-staging weight-gradient kernel: 128-multiple channels (2 x 2 quadrants) and 192 x 192 (3 x 1)
     (2, 9, 44, 128, 128, 3, 1),
     (3, 21, 41, 256, 128, 3, 1),     # two input-channel tiles; pixel ranges crossing frames
@@ -337,7 +343,8 @@ def test_conv_dgrad_halfres_rejects_layers_without_parity_classes():
 
 
 @pytest.mark.parametrize("dtype", [1, 0])
-@pytest.mark.parametrize("shape", [BIG_SHAPES[0], BIG_SHAPES[5], BIG_SHAPES[3], BIG_SHAPES[9], BIG_SHAPES[10], BIG_SHAPES[12]])
+@pytest.mark.parametrize("shape", [BIG_SHAPES[0], BIG_SHAPES[5], BIG_SHAPES[3], BIG_SHAPES[9], BIG_SHAPES[10], BIG_SHAPES[12], BIG_SHAPES[2],
+                                   (2, 301, 397, 32, 32, 3, 1)])
 def test_conv_wgrad_big_launch(shape, dtype):
     """Weight gradient at bench-size pixel counts (many pixel ranges per layer, ranges crossing image rows / frames)."""
     ops = pkg("ops")
