@@ -585,21 +585,39 @@ __global__ void __launch_bounds__(256) k_head_bwd(int Cp, const float *anc, cons
 // Folds the eval-mode BatchNorm (model.py:20,24,29; eval per SURVEY.md F4) into the weights:
 //   scale = gamma*rsqrt(var+eps), shift = beta - mean*scale,  w' = cast(scale*W).
 // ------------------------------------------------------------------------------------
+#define DCF_PREP_MAXCONV 256
 template <typename T>
-__global__ void __launch_bounds__(256) k_weight_prep(const dcf_conv_param *table, const float *params, const float *buffers, char *warena,
+__global__ void __launch_bounds__(256) k_weight_prep(const dcf_conv_param *table, int nconv, const float *params, const float *buffers, char *warena,
                                                      float *ssarena, float eps)
 {
     // 64(co) x 64(ci) tiles per tap, 16 B per lane: whole 256-B rows of the fp32 master weights in, whole 128-B (bf16) rows
     // of both images out; the dgrad image ([ci][tap][co]) goes through an LDS transpose (pitch 65: column reads conflict free).
     __shared__ float tile[64][65];
-    const dcf_conv_param d = table[blockIdx.y];
-    const int K = d.taps * d.cin;
-    const int cot = (d.cout_pad + 63) / 64, cit = (d.cin + 63) / 64;
-    const int ntiles = d.taps * cot * cit;
-    T *wf = reinterpret_cast<T *>(warena + d.wfwd_off);
-    T *wd = d.wdgrad_off >= 0 ? reinterpret_cast<T *>(warena + d.wdgrad_off) : nullptr;
+    // The (conv, tap, 64 x 64 tile) list of all layers is dealt round-robin over the grid: a layer gets workgroups in proportion
+    // to its size (a fixed number of workgroups per layer left the 2.4 M-weight layers to 96 workgroups while 95 of the 96 of a
+    // one-tile layer exited at once).  Every workgroup builds the prefix sums of the tiles per layer itself (<= 256 layers).
+    __shared__ int pre[DCF_PREP_MAXCONV + 1];
+    for (int i = threadIdx.x; i < nconv; i += blockDim.x) {
+        const dcf_conv_param &e = table[i];
+        pre[i + 1] = e.taps * ((e.cout_pad + 63) / 64) * ((e.cin + 63) / 64);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pre[0] = 0;
+        for (int i = 0; i < nconv; ++i) pre[i + 1] += pre[i];
+    }
+    __syncthreads();
+    const int total = pre[nconv];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 lanes x 4 elements per row, 16 rows per pass
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    for (int gt = blockIdx.x; gt < total; gt += gridDim.x) {
+        int lo = 0, hi = nconv;                                // last layer with pre[layer] <= gt
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre[mid] <= gt) lo = mid; else hi = mid; }
+        const dcf_conv_param d = table[lo];
+        const int t = gt - pre[lo];
+        const int K = d.taps * d.cin;
+        const int cit = (d.cin + 63) / 64;
+        T *wf = reinterpret_cast<T *>(warena + d.wfwd_off);
+        T *wd = d.wdgrad_off >= 0 ? reinterpret_cast<T *>(warena + d.wdgrad_off) : nullptr;
         const int tap = t % d.taps;
         const int r = t / d.taps;
         const int c0 = (r % cit) * 64, o0 = (r / cit) * 64;
@@ -631,9 +649,8 @@ __global__ void __launch_bounds__(256) k_weight_prep(const dcf_conv_param *table
             }
         }
         __syncthreads();
-    }
-    // scale | shift (one thread per output channel, first block of the conv)
-    if (blockIdx.x == 0) {
+        // scale | shift (one thread per output channel, by the workgroup that has the layer's first tile)
+        if (t != 0) continue;
         for (int co = threadIdx.x; co < d.cout_pad; co += blockDim.x) {
             float scale = 0.f, shift = 0.f;
             if (co < d.cout) {
@@ -1202,9 +1219,9 @@ extern "C" int dcf_head_bwd(int dtype, const void *head, int Cp, const float *an
 extern "C" int dcf_weight_prep(int dtype, const dcf_conv_param *table, int nconv, const float *params, const float *buffers,
                                void *warena, float *ssarena, float eps, dcf_stream_t stream)
 {
-    DCF_REQUIRE(table && nconv > 0 && params && warena && ssarena, "dcf_weight_prep: bad arguments");
+    DCF_REQUIRE(table && nconv > 0 && nconv <= DCF_PREP_MAXCONV && params && warena && ssarena, "dcf_weight_prep: bad arguments (1..%d layers)", DCF_PREP_MAXCONV);
     hipStream_t s = S(stream);
-    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("weight_prep", s, hipLaunchKernelGGL(k_weight_prep<T>, dim3(96, nconv), dim3(256), 0, s, table, params, buffers, (char *)warena, ssarena, eps)); })
+    DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH("weight_prep", s, hipLaunchKernelGGL(k_weight_prep<T>, dim3(2048), dim3(256), 0, s, table, nconv, params, buffers, (char *)warena, ssarena, eps)); })
     return DCF_OK;
 }
 
