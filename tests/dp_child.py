@@ -49,8 +49,8 @@ def run_rccl1(port, outdir):
       premul   -- the same with allreduce_premul 2 (ncclRedOp PreMulSum inside RCCL, undone by Adam's gradient scale): the
                   collective then CHANGES the buffer, so its stream order against the finalisation launch is observable
                                                                                            -> must equal `plain` BITWISE
-      wrong    -- premul with the hook called BEFORE the finalisation launch (negative control: the all-reduce doubles the
-                  stale arena, the finalisation then overwrites it with the undoubled gradient) -> must DIFFER."""
+      wrong    -- premul with the hook called (and the collective drained) BEFORE the finalisation launch (negative control: the
+                  all-reduce doubles the stale arena, the finalisation then overwrites it with the undoubled gradient) -> must DIFFER."""
     os.environ.update(dict(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", DCF_FORCE_DIST="1",
                            DCF_DIST_BACKEND="nccl"))
     import copy
@@ -83,6 +83,8 @@ def run_rccl1(port, outdir):
                 self._flush_wgrads()
                 self._done = (i0, f0)
                 self.bucket_hook([self._param_ranges(layers, 0, i0), self._param_ranges(layers, f0, len(layers))])   # too early
+                torch.cuda.synchronize()      # (the collective has doubled the STALE arena before the launch below overwrites it:
+                                              # without this the two race and the control passes or fails by chance)
                 self._finalize(0, i0)
                 self._finalize(f0, len(layers))
             backend = tr.model._ensure_backend(tr.model.flat_params.device)

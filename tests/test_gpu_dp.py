@@ -71,8 +71,8 @@ def test_rccl_bucketed_allreduce_world_size_one(request):
     """The product's overlapped, bucketed gradient all-reduce on RCCL itself (backend "nccl", a one-rank process group on the
     one GPU of this box; tests/dp_child.py run_rccl1): the LiDAR + fusion bucket is finalised and handed to
     dist.all_reduce(async_op=True) from the autograd thread while the camera stream's backward still runs, the camera bucket
-    follows, Adam waits for both.  Gradients over three steps equal those of the plain single-rank step (to the 1e-5 the
-    float atomics of the fusion backward allow between any two runs; parameters as far as Adam keeps noise-level gradients
+    follows, Adam waits for both.  Gradients over three steps equal those of the plain single-rank step (to the 1e-4 of the
+    largest gradient that the float atomics of the fusion backward leave between any two runs; parameters as far as Adam keeps noise-level gradients
     together).  With a PreMulSum reduction the collective DOUBLES the buffer: the arena then holds exactly twice the plain
     gradient -- which it can only when RCCL's stream ran behind the finalisation launch -- and the negative control (hook
     called before the finalisation: the launch overwrites the doubled, stale arena) is detected.
@@ -89,7 +89,10 @@ def test_rccl_bucketed_allreduce_world_size_one(request):
     lr = 1e-3
 
     def close(a, b, what):
-        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), "%s: %g apart (max %g)" % (what, float((a - b).abs().max()), float(b.abs().max()))
+        # fp32 model: two runs differ by the summation order of the float atomics (fusion dW1d / db1 / slice-crossing dP rows,
+        # point-sample scatter), up to ~1e-5 of the largest gradient on sums that cancel (measured over repeated runs: 0.4-2e-5);
+        # an all-reduce that raced the finalisation launch is O(1) off (the negative control below)
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()), "%s: %g apart (max %g)" % (what, float((a - b).abs().max()), float(b.abs().max()))
 
     def params_close(a, b, step, what):
         d = (a - b).abs()
