@@ -155,11 +155,12 @@ class _StepGraphs(object):
     LiDAR-stream graph follows once the voxel grid and the KNN maps are there.  One set of graphs per input signature;
     the signature includes the row count of the per-point fusion tensors -- the valid-point count rounded up to ROWS_STEP, a
     coarse step so that real frames (whose in-frustum counts vary by a few per cent) share one or two sets -- and the
-    address of the geometry buffers.  Sets are evicted least-recently-used; a run whose signatures keep missing (more than
-    MAX_MISSES captures) falls back to eager launches for good instead of capturing for ever."""
-    MAX_SETS = 8
+    address of the geometry buffers (the trainer's two buffer sets: two graph sets per signature).  Sets are evicted
+    least-recently-used; a run that keeps meeting NEW shapes / row buckets (more than MAX_MISSES of them) falls back to eager
+    launches for good instead of capturing for ever."""
+    MAX_SETS = 16          # (the trainer's two geometry buffer sets double every shape / row-count bucket)
     ROWS_STEP = 8192
-    MAX_MISSES = 24
+    MAX_MISSES = 24        # distinct (shapes, row bucket) signatures, whatever buffer set they arrived in
 
     def __init__(self, model):
         import collections
@@ -167,6 +168,7 @@ class _StepGraphs(object):
         self.sets = collections.OrderedDict()
         self.cur = None
         self.misses = 0
+        self.seen = set()
         self.disabled = False
 
     @classmethod
@@ -195,7 +197,9 @@ class _StepGraphs(object):
                         cur.wait_event(geom[k])
             while len(self.sets) >= self.MAX_SETS:
                 self.sets.popitem(last=False)
-            self.misses += 1
+            if sig[:-1] not in self.seen:          # the other buffer set of a known signature is not a new kind of input
+                self.seen.add(sig[:-1])
+                self.misses += 1
             st = self.sets[sig] = _GraphSet(self.model, x_lidar, x_image, geom if has_geo or geom is None else None, n_rows)
         else:
             self.sets.move_to_end(sig)
