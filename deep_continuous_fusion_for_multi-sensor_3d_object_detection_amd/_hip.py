@@ -12,7 +12,8 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdcf_hip.so")
+# (DCF_HIP_LIB: another build of the same library, e.g. an A/B variant of one kernel file linked beside the product's)
+LIB_PATH = os.environ.get("DCF_HIP_LIB") or os.path.join(_HERE, "libdcf_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16, F16 = 0, 1, 2
