@@ -43,6 +43,7 @@ SIGNATURES = {
     "dcf_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dcf_knn_bev": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, P, P, P]),
     "dcf_knn_bev_batch": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, P, P, c_size_t, P]),
+    "dcf_knn_bev_sites": (c_int, [P, P, c_int, c_int, c_int, P, c_int, c_float, c_float, c_float, c_float, c_float, P]),
     "dcf_knn_bev_batch_shared": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, P, P, c_size_t, P, c_size_t, P]),
     "dcf_nchw_to_nhwc": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "dcf_nhwc_to_nchw": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P]),
@@ -132,6 +133,12 @@ class WgradItem(ctypes.Structure):
 class KnnMap(ctypes.Structure):
     """struct dcf_knn_map of include/dcf_hip.h."""
     _fields_ = [("idx", c_void_p), ("h", ctypes.c_int32), ("w", ctypes.c_int32)]
+
+
+class KnnSite(ctypes.Structure):
+    """struct dcf_knn_site of include/dcf_hip.h."""
+    _fields_ = [("h", ctypes.c_int32), ("w", ctypes.c_int32), ("stride", ctypes.c_int32), ("fine", ctypes.c_int32), ("idx_out", c_void_p),
+                ("ws", c_void_p), ("ws_stride_bytes", ctypes.c_size_t)]
 
 
 class DcfError(RuntimeError):

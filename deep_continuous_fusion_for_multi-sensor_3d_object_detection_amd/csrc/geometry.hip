@@ -435,6 +435,122 @@ __global__ void __launch_bounds__(256) k_knn_fill(const float *xyz, const int *c
     sorted[pos] = make_float4(xyz[3 * i], xyz[3 * i + 1], __int_as_float(i), 0.f);
 }
 
+// ---- the cell sort of SEVERAL sites of one batch in one launch per phase (dcf_knn_bev_sites): blockIdx.y = site * B + frame.
+// Same arithmetic as the single-site kernels above on each site's own workspace (cellcnt | cellstart | cursor | blocksum | pkey |
+// sorted), so the searches that follow see bit-identical tables.
+#define DCF_MAX_KNN_SITES 4
+struct KnnSortSites {
+    KnnGrid g[DCF_MAX_KNN_SITES];
+    int *ws[DCF_MAX_KNN_SITES];            // frame 0 of the site's workspace (frames g.fs_ws ints apart)
+    int nscan[DCF_MAX_KNN_SITES], nsb[DCF_MAX_KNN_SITES];
+    int pkey_off[DCF_MAX_KNN_SITES], sorted_off[DCF_MAX_KNN_SITES];    // in ints from the workspace start
+    int n, B;
+};
+
+__global__ void __launch_bounds__(256) k_knn_zero_ms(KnnSortSites S)
+{
+    const int site = blockIdx.y / S.B, frame = blockIdx.y - site * S.B;
+    int *p = S.ws[site] + (size_t)frame * S.g[site].fs_ws;
+    const int n = S.nscan[site], n4 = n >> 2;
+    int4 *row = reinterpret_cast<int4 *>(p);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) row[i] = make_int4(0, 0, 0, 0);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_knn_hist_ms(const float *xyz, const int *count, int n_max, KnnSortSites S)
+{
+    const int site = blockIdx.y / S.B, frame = blockIdx.y - site * S.B;
+    const KnnGrid &g = S.g[site];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    xyz += (size_t)frame * g.fs_xyz; count += frame * g.fs_cnt;
+    int *cellcnt = S.ws[site] + (size_t)frame * g.fs_ws, *pkey = cellcnt + S.pkey_off[site];
+    const int n = min(*count, n_max);
+    if (i >= n) return;
+    int ci, cj;
+    point_cell(xyz[3 * i], xyz[3 * i + 1], g, ci, cj);
+    const int key = cell_key(ci, cj, g);
+    pkey[i] = key;
+    atomicAdd(&cellcnt[key], 1);
+}
+
+__global__ void __launch_bounds__(CP_THREADS) k_scan_blocksum_ms(KnnSortSites S)
+{
+    const int site = blockIdx.y / S.B, frame = blockIdx.y - site * S.B;
+    if ((int)blockIdx.x >= S.nsb[site]) return;
+    const int n = S.nscan[site];
+    const int *in = S.ws[site] + (size_t)frame * S.g[site].fs_ws;
+    int *blocksum = const_cast<int *>(in) + 3 * n;
+    const int base = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k)
+        if (base + k < n) c += in[base + k];
+    int tot;
+    block_excl_scan(c, &tot);
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(CP_THREADS) k_compact_scan_ms(KnnSortSites S)
+{
+    const int site = blockIdx.y / S.B, frame = blockIdx.y - site * S.B;
+    const int nb = S.nsb[site];
+    int *blocksum = S.ws[site] + (size_t)frame * S.g[site].fs_ws + 3 * S.nscan[site];
+    int carry = 0;
+    for (int b0 = 0; b0 < nb; b0 += CP_THREADS) {
+        int i = b0 + threadIdx.x;
+        int v = i < nb ? blocksum[i] : 0;
+        int tot;
+        int ex = block_excl_scan(v, &tot);
+        if (i < nb) blocksum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) blocksum[nb] = carry;
+}
+
+__global__ void __launch_bounds__(CP_THREADS) k_scan_apply_ms(KnnSortSites S)
+{
+    const int site = blockIdx.y / S.B, frame = blockIdx.y - site * S.B;
+    if ((int)blockIdx.x >= S.nsb[site]) return;
+    const int n = S.nscan[site];
+    const int *in = S.ws[site] + (size_t)frame * S.g[site].fs_ws;
+    int *out = const_cast<int *>(in) + n, *cursor = out + n;
+    const int *blockoff = cursor + n;
+    const int base = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS;
+    int v[CP_ITEMS];
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        c += v[k];
+    }
+    int tot;
+    int pos = blockoff[blockIdx.x] + block_excl_scan(c, &tot);
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k) {
+        if (base + k < n) {
+            out[base + k] = pos;
+            cursor[base + k] = pos;
+            pos += v[k];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_knn_fill_ms(const float *xyz, const int *count, int n_max, KnnSortSites S)
+{
+    const int site = blockIdx.y / S.B, frame = blockIdx.y - site * S.B;
+    const KnnGrid &g = S.g[site];
+    xyz += (size_t)frame * g.fs_xyz; count += frame * g.fs_cnt;
+    int *ws = S.ws[site] + (size_t)frame * g.fs_ws;
+    const int *pkey = ws + S.pkey_off[site];
+    int *cursor = ws + 2 * S.nscan[site];
+    float4 *sorted = reinterpret_cast<float4 *>(ws + S.sorted_off[site]);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = min(*count, n_max);
+    if (i >= n) return;
+    const int pos = atomicAdd(&cursor[pkey[i]], 1);
+    sorted[pos] = make_float4(xyz[3 * i], xyz[3 * i + 1], __int_as_float(i), 0.f);
+}
+
 template <int K>
 struct TopK {
     float d[K];
@@ -979,6 +1095,15 @@ __device__ __forceinline__ InvRun inv_run(int key, int lane)
     return r;
 }
 
+// zero `n` ints in each of gridDim.y rows `stride` ints apart (hipMemset2DAsync took 14 us for 2 x 560 KB)
+__global__ void __launch_bounds__(256) k_zero_rows(int *p, int n, int64_t stride)
+{
+    int4 *row = reinterpret_cast<int4 *>(p + blockIdx.y * stride);
+    const int n4 = n >> 2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) row[i] = make_int4(0, 0, 0, 0);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[blockIdx.y * stride + (n4 << 2) + threadIdx.x] = 0;
+}
+
 __global__ void __launch_bounds__(256) k_inv_hist(InvMaps m, int n_max, int *cnt)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1160,7 +1285,7 @@ struct KnnFine {                 // a finer site of the same batch whose cells a
 
 static int knn_bev_impl(const char *who, const float *xyz, const int32_t *count_dev, int B, int n_max, int K, int h, int w, int stride,
                         float xs, float xo, float ys, float yo, float rmax2, int32_t *idx_out, void *ws, size_t ws_stride_bytes, hipStream_t s,
-                        const KnnFine *fine = nullptr)
+                        const KnnFine *fine = nullptr, bool presorted = false)
 {
     DCF_REQUIRE(xyz && count_dev && idx_out && ws, "%s: null pointer", who);
     DCF_REQUIRE(K >= 1 && K <= 8, "%s: K must be 1..8 (got %d)", who, K);
@@ -1182,20 +1307,24 @@ static int knn_bev_impl(const char *who, const float *xyz, const int32_t *count_
     size_t ints = 3 * (size_t)nscan + (size_t)nsb + 8 + (size_t)n_max;
     ints = (ints + 3) & ~(size_t)3;
     float4 *sorted = (float4 *)((char *)ws + ints * sizeof(int));
-    if (B == 1) DCF_HIP(hipMemsetAsync(cellcnt, 0, sizeof(int) * (size_t)nscan, s));
-    else DCF_HIP(hipMemset2DAsync(cellcnt, ws_stride_bytes, 0, sizeof(int) * (size_t)nscan, B, s));
     const double fB = (double)B;
-    if (n_max > 0) {
-        const int nb = cdiv(n_max, 256);
-        DCF_LAUNCH_B("knn_hist", fB * n_max * 16.0, s, hipLaunchKernelGGL(k_knn_hist, dim3(nb, B), dim3(256), 0, s, xyz, count_dev, n_max, g, cellcnt, pkey));
-    }
-    int *total = blocksum + nsb;  // scratch int for the scan total
-    DCF_LAUNCH("scan_blocksum", s, hipLaunchKernelGGL(k_scan_blocksum, dim3(nsb, B), dim3(CP_THREADS), 0, s, cellcnt, nscan, blocksum, g.fs_ws));
-    DCF_LAUNCH("compact_scan", s, hipLaunchKernelGGL(k_compact_scan, dim3(1, B), dim3(CP_THREADS), 0, s, blocksum, nsb, total, g.fs_ws));
-    DCF_LAUNCH("scan_apply", s, hipLaunchKernelGGL(k_scan_apply, dim3(nsb, B), dim3(CP_THREADS), 0, s, cellcnt, nscan, blocksum, cellstart, cursor, g.fs_ws));
-    if (n_max > 0) {
-        const int nb = cdiv(n_max, 256);
-        DCF_LAUNCH_B("knn_fill", fB * n_max * (12.0 + 4.0 + 16.0), s, hipLaunchKernelGGL(k_knn_fill, dim3(nb, B), dim3(256), 0, s, xyz, count_dev, n_max, pkey, cursor, sorted, g.fs_xyz, g.fs_cnt, g.fs_ws));
+    if (!presorted) {                    // (dcf_knn_bev_sites has built the tables of every site already)
+        if (B == 1) DCF_HIP(hipMemsetAsync(cellcnt, 0, sizeof(int) * (size_t)nscan, s));
+        else if ((ws_stride_bytes & 15) == 0 && ((uintptr_t)cellcnt & 15) == 0)
+            DCF_LAUNCH_B("knn_zero", (double)B * nscan * 4.0, s, hipLaunchKernelGGL(k_zero_rows, dim3(std::min(cdiv(nscan, 1024), 256), B), dim3(256), 0, s, cellcnt, nscan, (int64_t)(ws_stride_bytes / 4)));
+        else DCF_HIP(hipMemset2DAsync(cellcnt, ws_stride_bytes, 0, sizeof(int) * (size_t)nscan, B, s));
+        if (n_max > 0) {
+            const int nb = cdiv(n_max, 256);
+            DCF_LAUNCH_B("knn_hist", fB * n_max * 16.0, s, hipLaunchKernelGGL(k_knn_hist, dim3(nb, B), dim3(256), 0, s, xyz, count_dev, n_max, g, cellcnt, pkey));
+        }
+        int *total = blocksum + nsb;  // scratch int for the scan total
+        DCF_LAUNCH("scan_blocksum", s, hipLaunchKernelGGL(k_scan_blocksum, dim3(nsb, B), dim3(CP_THREADS), 0, s, cellcnt, nscan, blocksum, g.fs_ws));
+        DCF_LAUNCH("compact_scan", s, hipLaunchKernelGGL(k_compact_scan, dim3(1, B), dim3(CP_THREADS), 0, s, blocksum, nsb, total, g.fs_ws));
+        DCF_LAUNCH("scan_apply", s, hipLaunchKernelGGL(k_scan_apply, dim3(nsb, B), dim3(CP_THREADS), 0, s, cellcnt, nscan, blocksum, cellstart, cursor, g.fs_ws));
+        if (n_max > 0) {
+            const int nb = cdiv(n_max, 256);
+            DCF_LAUNCH_B("knn_fill", fB * n_max * (12.0 + 4.0 + 16.0), s, hipLaunchKernelGGL(k_knn_fill, dim3(nb, B), dim3(256), 0, s, xyz, count_dev, n_max, pkey, cursor, sorted, g.fs_xyz, g.fs_cnt, g.fs_ws));
+        }
     }
     const int nbp = cdiv(g.h8 * g.w8, 4);   // one wave per 8x8 pixel tile
     // coarse sites: one wave per pixel (lanes split the candidates).  DCF_KNN_KERNEL = wave | tile forces one of the two
@@ -1277,6 +1406,65 @@ extern "C" int dcf_knn_bev_batch_shared(const float *xyz, const int32_t *count_d
                            ws_fine_stride_bytes / 4 < (1ull << 31)), "%s: fine workspace stride must be that of the fine site's call", who);
     const KnnFine fine = {fine_h, fine_w, fine_stride, ws_fine, ws_fine_stride_bytes};
     return knn_bev_impl(who, xyz, count_dev, B, n_max, K, h, w, stride, xs, xo, ys, yo, rmax2, idx_out, ws, ws_stride_bytes, S(stream), &fine);
+}
+
+// All fusion sites of a batch in one call: the cell sort of EVERY site in one launch per phase (zero / histogram / three scan
+// phases / fill: 6 launches instead of 6 per site), then each site's search exactly as dcf_knn_bev_batch /
+// dcf_knn_bev_batch_shared would run it (sites[i].fine = index of an earlier, finer site of this call whose cells serve its dense
+// pixels, or -1).  Same maps, bit for bit.  sites is a HOST array.
+extern "C" int dcf_knn_bev_sites(const float *xyz, const int32_t *count_dev, int B, int n_max, int K, const dcf_knn_site *sites, int nsites,
+                                 float xs, float xo, float ys, float yo, float rmax2, dcf_stream_t stream)
+{
+    const char *who = "dcf_knn_bev_sites";
+    DCF_REQUIRE(xyz && count_dev && sites && nsites >= 1 && nsites <= DCF_MAX_KNN_SITES, "%s: 1..%d sites", who, DCF_MAX_KNN_SITES);
+    DCF_REQUIRE(K >= 1 && K <= 8 && n_max >= 0 && B >= 1 && B * nsites <= 65535, "%s: bad dims", who);
+    hipStream_t s = S(stream);
+    KnnSortSites ss;
+    ss.n = nsites; ss.B = B;
+    int max_nsb = 1, max_nscan = 1;
+    for (int i = 0; i < DCF_MAX_KNN_SITES; ++i) {
+        const dcf_knn_site &t = sites[i < nsites ? i : 0];
+        DCF_REQUIRE(t.idx_out && t.ws && t.h > 0 && t.w > 0 && t.stride > 0, "%s: site %d: bad arguments", who, i);
+        DCF_REQUIRE(((uintptr_t)t.ws & 15) == 0 && t.ws_stride_bytes % 16 == 0 && t.ws_stride_bytes >= dcf_knn_workspace_bytes(n_max, t.h, t.w) &&
+                    t.ws_stride_bytes / 4 < (1ull << 31), "%s: site %d: workspace must be 16-byte aligned, its stride a multiple of 16 bytes that holds one frame's workspace", who, i);
+        DCF_REQUIRE(t.fine < i && t.fine >= -1, "%s: site %d: `fine` must name an earlier site of the call (or -1)", who, i);
+        KnnGrid &g = ss.g[i];
+        g.h = t.h; g.w = t.w; g.stride = t.stride; g.xs = xs; g.xo = xo; g.ys = ys; g.yo = yo;
+        g.fs_xyz = B > 1 ? n_max * 3 : 0; g.fs_cnt = B > 1 ? 1 : 0; g.fs_ws = B > 1 ? (int)(t.ws_stride_bytes / 4) : 0; g.fs_out = B > 1 ? K * t.h * t.w : 0;
+        int ncell;
+        knn_dims(t.h, t.w, g.h8, g.w8, ncell);
+        ss.ws[i] = (int *)t.ws;
+        ss.nscan[i] = ncell + 1;
+        ss.nsb[i] = cdiv(ncell + 1, CP_TILE);
+        ss.pkey_off[i] = 3 * ss.nscan[i] + ss.nsb[i] + 8;
+        size_t ints = 3 * (size_t)ss.nscan[i] + (size_t)ss.nsb[i] + 8 + (size_t)n_max;
+        ints = (ints + 3) & ~(size_t)3;
+        ss.sorted_off[i] = (int)ints;
+        if (i < nsites) { max_nsb = std::max(max_nsb, ss.nsb[i]); max_nscan = std::max(max_nscan, ss.nscan[i]); }
+    }
+    const int gy = nsites * B;
+    DCF_LAUNCH_B("knn_zero", (double)B * max_nscan * 4.0, s, hipLaunchKernelGGL(k_knn_zero_ms, dim3(std::min(cdiv(max_nscan, 1024), 256), gy), dim3(256), 0, s, ss));
+    if (n_max > 0)
+        DCF_LAUNCH_B("knn_hist", (double)gy * n_max * 16.0, s, hipLaunchKernelGGL(k_knn_hist_ms, dim3(cdiv(n_max, 256), gy), dim3(256), 0, s, xyz, count_dev, n_max, ss));
+    DCF_LAUNCH("scan_blocksum", s, hipLaunchKernelGGL(k_scan_blocksum_ms, dim3(max_nsb, gy), dim3(CP_THREADS), 0, s, ss));
+    DCF_LAUNCH("compact_scan", s, hipLaunchKernelGGL(k_compact_scan_ms, dim3(1, gy), dim3(CP_THREADS), 0, s, ss));
+    DCF_LAUNCH("scan_apply", s, hipLaunchKernelGGL(k_scan_apply_ms, dim3(max_nsb, gy), dim3(CP_THREADS), 0, s, ss));
+    if (n_max > 0)
+        DCF_LAUNCH_B("knn_fill", (double)gy * n_max * (12.0 + 4.0 + 16.0), s, hipLaunchKernelGGL(k_knn_fill_ms, dim3(cdiv(n_max, 256), gy), dim3(256), 0, s, xyz, count_dev, n_max, ss));
+    for (int i = 0; i < nsites; ++i) {
+        const dcf_knn_site &t = sites[i];
+        KnnFine fine;
+        if (t.fine >= 0) {
+            const dcf_knn_site &f = sites[t.fine];
+            DCF_REQUIRE(t.stride % f.stride == 0 && t.h * t.stride <= f.h * f.stride && t.w * t.stride <= f.w * f.stride,
+                        "%s: site %d must lie on the grid of its fine site", who, i);
+            fine = {f.h, f.w, f.stride, f.ws, f.ws_stride_bytes};
+        }
+        int rc = knn_bev_impl(who, xyz, count_dev, B, n_max, K, t.h, t.w, t.stride, xs, xo, ys, yo, rmax2, t.idx_out, t.ws, t.ws_stride_bytes, s,
+                              t.fine >= 0 ? &fine : nullptr, true);
+        if (rc) return rc;
+    }
+    return DCF_OK;
 }
 
 extern "C" size_t dcf_fusion_invert_workspace_bytes(int n_max, int nmaps)

@@ -12,6 +12,7 @@ calling forward on CPU tensors raises.
   fusion.enabled = False -- the output is the reference's LiDAR-only forward.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -408,6 +409,7 @@ class ObjectDetection_DCF(_FlatParamModule):
 
     KNN_SHARED_MAX_PIXELS = 20000      # sites up to this many pixels (stride 8 and 16 at cfg2) are searched on the finest site's cells
     knn_shared = True
+    knn_merged = os.environ.get("DCF_KNN_MERGED", "1") != "0"      # the four sites' cell sorts in one launch per phase
 
     def fusion_geometry(self, points, uv, n_valid, bufs=None):
         """KNN indices of every fusion site for a batch: points [B,n_max,3], uv [B,n_max,2], n_valid [B] (int).
@@ -420,6 +422,20 @@ class ObjectDetection_DCF(_FlatParamModule):
         L, W = self.config["voxel_length"], self.config["voxel_width"]
         idx = []
         batched = points.is_contiguous() and cnt.is_contiguous()
+        if batched and self.knn_shared and self.knn_merged:
+            # all four sites in one call: their cell sorts share one launch per phase (6 launches instead of 24)
+            sites, first = [], None
+            for si in range(1, 5):
+                s = 2 ** si
+                h, w = L // s, W // s
+                out = bufs["idx"][si - 1] if bufs is not None else torch.empty((B, self.K, h, w), dtype=torch.int32, device=dev)
+                ws = bufs["ws"][si - 1] if bufs is not None else torch.empty((B, ops.knn_ws_stride(points.shape[1], h, w)), dtype=torch.uint8, device=dev)
+                fine = first if (first is not None and h * w <= self.KNN_SHARED_MAX_PIXELS) else -1
+                if first is None:
+                    first = si - 1
+                sites.append((h, w, s, fine, ws, out))
+            idx = ops.knn_bev_sites(points, cnt, self.K, sites, self._grid.aff, self.r_max)
+            return dict(xyz=points.contiguous(), uv=uv.contiguous(), cnt=cnt, idx=idx, aff=self._grid.aff)
         fine = None                     # (h, w, stride, workspace) of the finest site: the coarse sites search ITS cells
         for si in range(1, 5):
             s = 2 ** si

@@ -381,6 +381,26 @@ def knn_bev_batch_shared(xyz, cnt, K, h, w, stride, fine, ws_fine, aff, rmax=Non
     return idx
 
 
+def knn_bev_sites(xyz, cnt, K, sites, aff, rmax=None):
+    """Every fusion site of a batch in one call (dcf_knn_bev_sites): the cell sort of all sites in one launch per phase, then
+    the searches.  sites = list of (h, w, stride, fine, ws, out): fine = index of an earlier, finer site whose cells serve this
+    site's dense pixels (as knn_bev_batch_shared) or -1 (as knn_bev_batch); ws uint8 [B, knn_ws_stride(n_max, h, w)]; out int32
+    [B, K, h, w].  Same maps as the per-site calls."""
+    B, n_max = xyz.shape[0], xyz.shape[1]
+    arr = (H.KnnSite * len(sites))()
+    for i, (h, w, stride, fine, ws, out) in enumerate(sites):
+        st = knn_ws_stride(n_max, h, w)
+        if ws.shape[0] < B or ws.stride(0) != st or ws.dtype != torch.uint8:
+            raise H.DcfError("knn_bev_sites: site %d: workspace must be uint8 [B, %d]" % (i, st))
+        if tuple(out.shape) != (B, K, h, w) or out.dtype != torch.int32 or not out.is_contiguous():
+            raise H.DcfError("knn_bev_sites: site %d: out must be a contiguous int32 [B, K, h, w]" % i)
+        arr[i] = H.KnnSite(h, w, stride, fine, out.data_ptr(), ws.data_ptr(), st)
+    r2 = -1.0 if rmax is None else float(np.float32(rmax) * np.float32(rmax))
+    H.call("dcf_knn_bev_sites", _chk(xyz, "xyz"), _chk(cnt, "cnt"), B, n_max, K, ctypes.addressof(arr), len(sites), float(aff[0]), float(aff[1]),
+           float(aff[2]), float(aff[3]), r2, H.stream_ptr())
+    return [t[5] for t in sites]
+
+
 # ------------------------------------------------------------------ fusion
 def point_sample_fwd(dtype, fmap, uv, cnt, n_max, out=None):
     """out: optional ZEROED [n_max, Cf] tensor to write into (a frame's slice of a batch tensor)."""

@@ -116,6 +116,15 @@ int dcf_knn_bev_batch_shared(const float *xyz, const int32_t *count_dev, int B, 
                              int32_t *idx_out, void *ws, size_t ws_stride_bytes, const void *ws_fine, size_t ws_fine_stride_bytes,
                              dcf_stream_t stream);
 
+/* All fusion sites of a batch in one call: the cell sort of every site in one launch per phase, then each site's search as
+ * dcf_knn_bev_batch (fine = -1) or dcf_knn_bev_batch_shared (fine = index of an earlier, finer site of the call) runs it: the
+ * same maps bit for bit, 6 sort launches instead of 6 per site.  The reference computes these indices once per frame in its
+ * loader (data_import_carla.py: the commented KNN block).  sites is a HOST array of 1..4 entries; every ws is
+ * 16-byte aligned with frames ws_stride_bytes apart (>= dcf_knn_workspace_bytes(n_max, h, w), multiple of 16). */
+typedef struct { int32_t h, w, stride, fine; int32_t *idx_out; void *ws; size_t ws_stride_bytes; } dcf_knn_site;
+int dcf_knn_bev_sites(const float *xyz, const int32_t *count_dev, int B, int n_max, int K, const dcf_knn_site *sites, int nsites,
+                      float xs, float xo, float ys, float yo, float rmax2, dcf_stream_t stream);
+
 /* Inverse of the KNN maps of a step (sites x frames) for the fusion backward: the (pixel, point) pairs of every
  * idx [K][h][w] counting-sorted by (map, point).  start int32 [nmaps*(n_max+1)]: pairs of point q of map g are
  * [start[g*(n_max+1)+q], start[g*(n_max+1)+q+1]); ent_pix / ent_pt int32 [sum K*h*w] (pixel packed (i<<16)|j).

@@ -469,3 +469,45 @@ def test_knn_coarse_site_on_fine_cells_sparse_clouds(where):
         h, w = 704 // 16, 800 // 16
         ii, jj = np.meshgrid(np.arange(0, h, 3), np.arange(0, w, 3), indexing="ij")
         _knn_check_pixels(_coarse_on_fine(ops, d, cnt, 3, 16, g.aff)[1][0].cpu().numpy(), xyz, 3, ii.ravel().astype(np.int32), jj.ravel().astype(np.int32), 16, g.aff)
+
+
+@pytest.mark.parametrize("K,B,rmax", [(3, 2, None), (5, 3, 2.0), (1, 1, None)])
+def test_knn_all_sites_in_one_call_equal_the_per_site_calls(K, B, rmax):
+    """dcf_knn_bev_sites (the four sites' cell sorts in one launch per phase, then the searches) against dcf_knn_bev_batch for the
+    two fine sites and dcf_knn_bev_batch_shared for the two coarse ones: every map bit for bit, on frames of different density
+    (one of them empty when B = 3), with and without a radius cut; a second call on the same workspaces gives the same maps."""
+    ops, H = pkg("ops"), pkg("_hip")
+    g, a = _cfg2_cloud(seed=21)
+    clouds = [a, _cfg2_cloud(seed=22, npts=25000)[1], np.zeros((0, 3), np.float32)][:B]
+    n_max = max(c.shape[0] for c in clouds)
+    d = torch.zeros(B, n_max, 3)
+    for b, c in enumerate(clouds):
+        d[b, :c.shape[0]] = torch.from_numpy(c)
+    d = d.cuda()
+    cnt = torch.tensor([c.shape[0] for c in clouds], dtype=torch.int32, device="cuda")
+    dims = [(704 // s, 800 // s, s) for s in (2, 4, 8, 16)]
+    want = []
+    ws0 = torch.empty((B, ops.knn_ws_stride(n_max, *dims[0][:2])), dtype=torch.uint8, device="cuda")
+    for i, (h, w, s) in enumerate(dims):
+        if i == 0:
+            want.append(ops.knn_bev_batch(d, cnt, K, h, w, s, g.aff, rmax, ws=ws0))
+        elif h * w > 20000:
+            want.append(ops.knn_bev_batch(d, cnt, K, h, w, s, g.aff, rmax))
+        else:
+            want.append(ops.knn_bev_batch_shared(d, cnt, K, h, w, s, dims[0], ws0, g.aff, rmax))
+    sites = []
+    for i, (h, w, s) in enumerate(dims):
+        sites.append((h, w, s, 0 if (i > 0 and h * w <= 20000) else -1,
+                      torch.empty((B, ops.knn_ws_stride(n_max, h, w)), dtype=torch.uint8, device="cuda"),
+                      torch.full((B, K, h, w), -7, dtype=torch.int32, device="cuda")))
+    got = ops.knn_bev_sites(d, cnt, K, sites, g.aff, rmax)
+    for i in range(4):
+        assert torch.equal(got[i], want[i]), "site %d" % i
+    again = [t.clone() for t in got]
+    ops.knn_bev_sites(d, cnt, K, sites, g.aff, rmax)
+    for i in range(4):
+        assert torch.equal(sites[i][5], again[i])
+    with pytest.raises(H.DcfError):             # `fine` must name an earlier site
+        bad = list(sites)
+        bad[1] = bad[1][:3] + (2,) + bad[1][4:]
+        ops.knn_bev_sites(d, cnt, K, bad, g.aff, rmax)
