@@ -49,6 +49,7 @@ SIGNATURES = {
     "dcf_nhwc_to_nchw": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "dcf_image_to_nhwc4": (c_int, [c_int, P, P, c_int, c_int, c_int, P]),
     "dcf_conv2d_fwd": (c_int, [c_int, P, P, P, P, P] + [c_int] * 12 + [P]),
+    "dcf_conv2d_fwd_rowscale": (c_int, [c_int, P, P, P, P, P, P] + [c_int] * 12 + [P]),
     "dcf_conv2d_dgrad": (c_int, [c_int, P, P, P, P, P] + [c_int] * 11 + [P]),
     "dcf_conv2d_dgrad_halfres": (c_int, [c_int, P, P, P, P, P, P] + [c_int] * 11 + [P]),
     "dcf_fp8_act_scale": (c_int, [c_float, P]),

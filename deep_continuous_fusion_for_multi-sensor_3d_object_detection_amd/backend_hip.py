@@ -489,6 +489,15 @@ class HipBackend(object):
         pool[2] = off + need
         return pool[0][off:off + need].view(B, rows, cb)
 
+    def conv_fwd_rowscale(self, L, x, res, cnt, b2_off):
+        """conv_fwd of a 1x1 layer without BatchNorm + cnt[m] * b2[c] in the same epilogue (the fusion site's fc2 under the neighbour
+        sum); the fp8 kernel has no such epilogue: there the bias stays a pass of its own."""
+        if self._use_fp8(L, x.shape[:3]) or L.bn is not None or L.kh != 1 or L.kw != 1 or L.stride != 1:
+            return self.rowscale_bias_fwd(self.conv_fwd(L, x, res, False), cnt, b2_off)
+        y = ops.conv2d_fwd_rowscale(self.dtype, x, self._w(L), self.params[b2_off:], cnt, res, False, L.cout_pad)
+        L.out_shape = (y.shape[0], y.shape[1], y.shape[2])
+        return y
+
     def rowscale_bias_fwd(self, y, cnt, b2_off):
         return ops.rowscale_bias_fwd(self.dtype, y, cnt, self.params[b2_off:])
 

@@ -45,6 +45,7 @@ struct ConvArgs {
     int pixbytes;        // byte pitch between adjacent input pixels (= Ck*esize except for the stem)
     unsigned xbytes, wbytes;  // sizes of the gathered tensor and of the weight image (buffer descriptors)
     const char *mask;         // [M][Cn] or null: output *= (mask > 0)
+    const float *rowscale = nullptr;   // [M] or null: the shift enters as rowscale[m] * shift[c] (dcf_conv2d_fwd_rowscale)
     const char *resq = nullptr;   // stride-2 dgrad with parity classes only: residual living on the (2i, 2j) sub-grid of the
                               // output, [B][ceil(Ho/2)][ceil(Wo/2)][Cn] (the input gradient of a 1x1 / stride-2 shortcut)
     // stride-2 dgrad only: output pixels are enumerated parity class by parity class ((oh+pad)&1, (ow+pad)&1),
@@ -299,7 +300,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a)
         for (int j = 0; j < TM; ++j) { const int m = m0 + (wm * TM + j) * 32 + r; mq[j] = m < clsM ? m : -1; }
         conv_epilogue_add<T, TN, TM>(acc, mq, n0 + wn * TN * 32 + 8 * h, a.Cn, reinterpret_cast<const T *>(a.resq));
     }
-    conv_epilogue_phases<T, TN, TM>(acc, mpix, n0 + wn * TN * 32 + 8 * h, a.Cn, a.shift, res, mask, a.relu, y);
+    conv_epilogue_phases<T, TN, TM>(acc, mpix, n0 + wn * TN * 32 + 8 * h, a.Cn, a.shift, res, mask, a.relu, y, a.rowscale);
     DCF_STAMP(4);
     DCF_WEND();
 }
@@ -509,7 +510,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm_dma(ConvArgs a)
         for (int j = 0; j < TM; ++j) { const int m = m0 + (wm * TM + j) * 32 + r; mq[j] = m < clsM ? m : -1; }
         conv_epilogue_add<T, TN, TM>(acc, mq, n0 + wn * TN * 32 + 8 * h, a.Cn, reinterpret_cast<const T *>(a.resq));
     }
-    conv_epilogue_phases<T, TN, TM>(acc, mpix, n0 + wn * TN * 32 + 8 * h, a.Cn, a.shift, res, mask, a.relu, y);
+    conv_epilogue_phases<T, TN, TM>(acc, mpix, n0 + wn * TN * 32 + 8 * h, a.Cn, a.shift, res, mask, a.relu, y, a.rowscale);
     DCF_STAMP(4);
     DCF_WEND();
 }
@@ -1488,9 +1489,31 @@ static int check_conv(const char *who, int dtype, int Cin, int Cout, int kh, int
     return DCF_OK;
 }
 
+static int conv2d_fwd_impl(int dtype, const void *x, const void *w, const float *shift, const float *rowscale, const void *res, void *y,
+                           int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                           int relu, dcf_stream_t stream);
+
 extern "C" int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const float *shift, const void *res, void *y,
                               int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
                               int relu, dcf_stream_t stream)
+{
+    return conv2d_fwd_impl(dtype, x, w, shift, nullptr, res, y, B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, relu, stream);
+}
+
+// The same with the shift scaled per output pixel: y = act(conv(x, w) + rowscale[m] * shift[c] + res), rowscale fp32 [B*Ho*Wo].
+// The fusion site's second Linear layer under the neighbour sum (model.py:216-219): sum_k (W2 h_k + b2) = W2 sum_k h_k + cnt * b2
+// -- the cnt * b2 term in the GEMM's epilogue instead of a pass of its own over the result.  1x1 layers only.
+extern "C" int dcf_conv2d_fwd_rowscale(int dtype, const void *x, const void *w, const float *shift, const float *rowscale, const void *res,
+                                       void *y, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                                       int relu, dcf_stream_t stream)
+{
+    DCF_REQUIRE(shift && rowscale && kh == 1 && kw == 1, "dcf_conv2d_fwd_rowscale: needs shift, rowscale and a 1x1 layer");
+    return conv2d_fwd_impl(dtype, x, w, shift, rowscale, res, y, B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, relu, stream);
+}
+
+static int conv2d_fwd_impl(int dtype, const void *x, const void *w, const float *shift, const float *rowscale, const void *res, void *y,
+                           int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                           int relu, dcf_stream_t stream)
 {
     int rc = check_conv("dcf_conv2d_fwd", dtype, Cin, Cout, kh, kw, stride);
     if (rc) return rc;
@@ -1499,7 +1522,7 @@ extern "C" int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const flo
     DCF_REQUIRE((int64_t)B * H * W * Cin < (1ll << 31) * 1, "dcf_conv2d_fwd: tensor too large for 32-bit pixel index");
     ConvArgs a;
     a.x = (const char *)x; a.w = (const char *)w; a.shift = shift; a.res = (const char *)res; a.y = (char *)y;
-    a.mask = nullptr; a.parity = 0;
+    a.mask = nullptr; a.parity = 0; a.rowscale = rowscale;
     a.B = B; a.Hi = H; a.Wi = W; a.Ck = Cin; a.Ho = Ho; a.Wo = Wo; a.Cn = Cout;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.relu = relu; a.M = B * Ho * Wo;
     a.pixbytes = Cin * (dtype == DCF_F32 ? 4 : 2);

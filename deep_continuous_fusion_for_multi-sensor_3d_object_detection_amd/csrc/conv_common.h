@@ -84,10 +84,15 @@ __device__ __forceinline__ void conv_epilogue_add(f32x16 (&acc)[TN][TM], const i
 
 template <typename T, int TN, int TM>
 __device__ __forceinline__ void conv_epilogue_phases(f32x16 (&acc)[TN][TM], const int (&m)[TM], int c0, int Cn, const float *shift,
-                                                     const T *res, const T *mask, int relu, T *y)
+                                                     const T *res, const T *mask, int relu, T *y, const float *rowscale = nullptr)
 {
     if (res) conv_epilogue_add<T, TN, TM>(acc, m, c0, Cn, res);
     if (shift) {
+        // rowscale (fp32 per output pixel, optional): the shift enters as rowscale[m] * shift[c] -- the bias of a Linear layer
+        // under a sum over a pixel's rowscale[m] neighbours (fusion fc2)
+        float rsv[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) rsv[j] = rowscale ? (m[j] >= 0 ? rowscale[m[j]] : 0.f) : 1.f;
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -97,7 +102,7 @@ __device__ __forceinline__ void conv_epilogue_phases(f32x16 (&acc)[TN][TM], cons
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[i][j][8 * p + k] += sh[k];
+                    for (int k = 0; k < 8; ++k) acc[i][j][8 * p + k] += rowscale ? rsv[j] * sh[k] : sh[k];
             }
     }
     if (relu) {

@@ -576,8 +576,7 @@ class Plan(object):
                 self.ctx["fuse_fp"] = fp
         P = K.conv_fwd(f["fc1_feat"], fp.view(B, n_max, 1, fp.shape[-1]), None, False).view(B, n_max, cb)
         hsum, cnt = K.fusion_gather_fwd(P, geom["xyz"], geom["idx"][site], f["stride"], geom["aff"], f["w1d_off"], f["b1_off"])
-        out = K.conv_fwd(f["fc2"], hsum, x, False)                               # x + hsum.W2^T
-        out = K.rowscale_bias_fwd(out, cnt, f["b2_off"])                         # + cnt*b2
+        out = K.conv_fwd_rowscale(f["fc2"], hsum, x, cnt, f["b2_off"])           # x + hsum.W2^T + cnt*b2 (one epilogue)
         if save:
             self.ctx["fuse%d" % site] = dict(fp=fp, P=P, hsum=hsum, cnt=cnt, geom=geom, fmap_shape=tuple(fmap.shape))
         return out

@@ -59,6 +59,17 @@ def conv2d_fwd(dtype, x, w, shift, res, kh, kw, stride, pad, relu, cout):
     return y
 
 
+def conv2d_fwd_rowscale(dtype, x, w, shift, rowscale, res, relu, cout):
+    """1x1 conv2d_fwd whose shift is scaled per output pixel: y = act(conv + rowscale[m] * shift[c] + res); rowscale fp32 [B*H*W]."""
+    B, Hh, W, Cin = x.shape
+    if rowscale.numel() != B * Hh * W or rowscale.dtype != torch.float32:
+        raise H.DcfError("conv2d_fwd_rowscale: rowscale must be fp32 with one entry per output pixel")
+    y = torch.empty((B, Hh, W, cout), dtype=x.dtype, device=x.device)
+    H.call("dcf_conv2d_fwd_rowscale", dtype, x, w, shift, _chk(rowscale, "rowscale"), res, y, B, Hh, W, Cin, Hh, W, cout, 1, 1, 1, 0, int(relu),
+           H.stream_ptr())
+    return y
+
+
 def fp8_act_scale(amax):
     """The activation scale rule of the fp8 path (largest power of two s with amax*s <= 224)."""
     import ctypes

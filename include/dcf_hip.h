@@ -152,6 +152,12 @@ int dcf_image_to_nhwc4(int dtype, const uint8_t *img, void *y, int B, int H, int
 int dcf_conv2d_fwd(int dtype, const void *x, const void *w, const float *shift, const void *res, void *y,
                    int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
                    int relu, dcf_stream_t stream);
+/* 1x1 layers: the shift scaled per output pixel, y = act(conv(x,w) + rowscale[m]*shift[c] + res); rowscale fp32 [B*Ho*Wo].
+ * The bias of the fusion site's second Linear layer under the neighbour sum (reference model.py:216-219:
+ * sum_k (W2 h_k + b2) = W2 sum_k h_k + cnt*b2), in the GEMM's epilogue. */
+int dcf_conv2d_fwd_rowscale(int dtype, const void *x, const void *w, const float *shift, const float *rowscale, const void *res,
+                            void *y, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                            int relu, dcf_stream_t stream);
 /* Input gradient: gx [B,H,W,Cin] = conv_transpose(gy [B,Ho,Wo,Cout], wt) (+ res).
  * wt [Cin][kh][kw][Cout] (dtype) as produced by dcf_weight_prep.
  * Optional fused ReLU backward of the layer that produced x: mask (dtype, like gx) zeroes gx where

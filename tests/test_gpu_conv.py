@@ -291,6 +291,24 @@ def test_conv_dgrad_big_launch(shape, dtype):
     assert float((got3 * (mask <= 0)).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dtype", [1, 0, 2])
+@pytest.mark.parametrize("shape", [(2, 24, 40, 64, 64), (1, 33, 35, 128, 128), (2, 352, 400, 64, 64), (3, 11, 13, 256, 192)])
+def test_conv_fwd_rowscale(shape, dtype):
+    """dcf_conv2d_fwd_rowscale: y = conv1x1(x, w) + cnt[m] * b[c] + res in one epilogue (the fusion site's fc2 under the neighbour sum,
+    reference model.py:216-219), against the fp32 statement, incl. the launch of the stride-2 site's size."""
+    ops, H = pkg("ops"), pkg("_hip")
+    B, Hh, W, Cin, Cout = shape
+    x, w = _mk((B, Hh, W, Cin, Cout, 1, 1), dtype, 81)
+    b = rnd((Cout,), 82)
+    cnt = torch.randint(0, 4, (B, Hh * W), generator=torch.Generator().manual_seed(83)).float()
+    res = q(rnd((B, Cout, Hh, W), 84), dtype)
+    ref = F.conv2d(x, w) + res + cnt.view(B, 1, Hh, W) * b.view(1, -1, 1, 1)
+    y = ops.conv2d_fwd_rowscale(dtype, to_dev(x, dtype), to_dev(w, dtype), b.cuda(), cnt.cuda(), to_dev(res, dtype), False, Cout)
+    _assert_quantised_close(from_dev(y), ref, dtype, "conv + cnt*b + res")
+    with pytest.raises(H.DcfError):
+        ops.conv2d_fwd_rowscale(dtype, to_dev(x, dtype), to_dev(w, dtype), b.cuda(), cnt.cuda()[:, :-1].contiguous(), None, False, Cout)
+
+
 HALFRES_SHAPES = [
     (2, 17, 13, 32, 64, 3, 2),       # odd sizes: the even sub-grid is the larger class
     (2, 10, 10, 128, 192, 3, 2),
