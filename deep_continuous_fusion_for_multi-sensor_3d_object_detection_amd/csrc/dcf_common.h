@@ -40,10 +40,16 @@ extern int g_dcf_prof_on;
 // ... and / or bytes: the tensors the kernel has to read and write once, whatever its tiling re-reads (HBM-bound kernels)
 #define DCF_LAUNCH_B(name, bytes, stream, ...) DCF_LAUNCH_WB(name, 0.0, bytes, stream, __VA_ARGS__)
 
+// (-DDCF_NO_LAUNCH: a library whose launches do nothing -- tools/host_split.py then times the HOST side of a step alone)
+#ifdef DCF_NO_LAUNCH
+#define DCF_DO_LAUNCH(...) do { if (g_dcf_prof_on < 0) { __VA_ARGS__; } } while (0)
+#else
+#define DCF_DO_LAUNCH(...) do { __VA_ARGS__; } while (0)
+#endif
 #define DCF_LAUNCH_WB(name, work, bytes, stream, ...)                               \
     do {                                                                            \
         if (g_dcf_prof_on) dcf_prof_begin(name, stream, work, bytes);               \
-        __VA_ARGS__;                                                                \
+        DCF_DO_LAUNCH(__VA_ARGS__);                                                 \
         if (g_dcf_prof_on) dcf_prof_end(stream);                                    \
         hipError_t e__ = hipGetLastError();                                         \
         if (e__ != hipSuccess) {                                                    \

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Host enqueue time of the cfg2 step by phase (the GPU runs behind, unsynchronised): geometry, forward, loss, backward + Adam,
-and the number of C-ABI calls per phase.  Usage (GPU box): python tools/host_split.py"""
+and the number of C-ABI calls per phase.  Usage (GPU box): python tools/host_split.py
+With the launch-free build (make -C <pkg>/csrc nolaunch; DCF_HIP_LIB=<pkg>/libdcf_hip_nolaunch.so) the GPU never holds the host
+back (no queue back-pressure, the valid-count event is instantly done): the figures are then the host's own work per step, without
+the ~3 us of every hipLaunchKernel."""
 import os, sys, time, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
