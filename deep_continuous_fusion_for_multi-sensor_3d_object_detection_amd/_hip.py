@@ -218,6 +218,16 @@ def call(name, *args):
     return rc
 
 
+def fn(name):
+    """The bound foreign function itself, for call sites hot enough to marshal their own arguments (ints / None only); a
+    non-zero status goes to fail()."""
+    return getattr(lib(), name)
+
+
+def fail(name, rc):
+    raise DcfError("%s failed (%d): %s" % (name, rc, lib().dcf_last_error().decode()))
+
+
 def set_option(name, value):
     """Tuning option of the library (dcf_set_option): which kernel / tile shape a launch takes, never its result.
     value None = unset (back to the built-in choice)."""

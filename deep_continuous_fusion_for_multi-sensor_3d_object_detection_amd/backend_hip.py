@@ -31,6 +31,8 @@ class HipBackend(object):
         self.es = 4 if self.dtype == H.F32 else 2
         self.dev = params.device
         self._fus_dws = {}                 # fusion backward: boundary-row workspaces per (pairs, channels, frames)
+        self._wtab = {}                    # grouped weight gradients: ctypes tables per layer sequence
+        self._fn_fwd, self._fn_dgrad = H.fn("dcf_conv2d_fwd"), H.fn("dcf_conv2d_dgrad")
         self._pbase, self._gbase = params.data_ptr(), grads.data_ptr()     # (arena slices go to the C ABI as raw addresses: a view costs ~2.5 us)
         self.bn_train = False          # batch statistics instead of running statistics (train-mode BatchNorm)
         # fp8 forward path (0 = off): convolutions with cin >= fp8_min_cin (and cin % 64 == 0) read e4m3 images
@@ -256,7 +258,7 @@ class HipBackend(object):
 
     def conv_fwd(self, L, x, res, relu, nxt=None):
         """nxt: the convolution that will read the result (fp8 path: its e4m3 image is written by this epilogue)."""
-        if self._use_fp8(L, x.shape[:3]):
+        if self.has_fp8 and self._use_fp8(L, x.shape[:3]):
             y = self._conv_fwd_fp8(L, x, res, relu, nxt)
             L.out_shape = (y.shape[0], y.shape[1], y.shape[2])
             return y
@@ -264,8 +266,20 @@ class HipBackend(object):
             raw = ops.conv2d_fwd(self.dtype, x, self._w(L), None, None, L.kh, L.kw, L.stride, L.pad, False, L.cout_pad)
             L.out_shape = (raw.shape[0], raw.shape[1], raw.shape[2])
             return self._bn_fwd(L, raw, res, relu)
-        y = ops.conv2d_fwd(self.dtype, x, self._w(L), self._shift(L), res, L.kh, L.kw, L.stride, L.pad, relu, L.cout_pad)
-        L.out_shape = (y.shape[0], y.shape[1], y.shape[2])
+        # the step's ~75 plain forward convolutions: per-layer constants cached, arguments marshalled here (ops.conv2d_fwd ->
+        # H.call converts 19 generic arguments per launch; this path is ~half its host time)
+        shp = x.shape
+        c = L.__dict__.get("_fwc")
+        if c is None or c[0] != shp:
+            B, Hh, W, Cin = shp
+            Ho, Wo = ops.conv_out_size(Hh, L.kh, L.stride, L.pad), ops.conv_out_size(W, L.kw, L.stride, L.pad)
+            c = L._fwc = (shp, (B, Ho, Wo, L.cout_pad), (B, Hh, W, Cin, Ho, Wo, L.cout_pad, L.kh, L.kw, L.stride, L.pad), (B, Ho, Wo))
+        y = torch.empty(c[1], dtype=x.dtype, device=x.device)
+        rc = self._fn_fwd(self.dtype, x.data_ptr(), self._wbase + L.wfwd_off, self._shift(L), None if res is None else res.data_ptr(),
+                          y.data_ptr(), *c[2], 1 if relu else 0, H.stream_ptr())
+        if rc:
+            H.fail("dcf_conv2d_fwd", rc)
+        L.out_shape = c[3]
         return y
 
     # train-mode BatchNorm as separate kernels (batch statistics; running stats updated in place)
@@ -295,7 +309,14 @@ class HipBackend(object):
         """mask: fused ReLU backward of the layer that produced the tensor gx belongs to."""
         if L.wdgrad_off < 0:
             raise H.DcfError("layer %s was planned without an input gradient" % L.name)
-        return ops.conv2d_dgrad(self.dtype, gy, self._w(L, True), res, in_shape, L.kh, L.kw, L.stride, L.pad, mask)
+        gshp = gy.shape
+        gx = torch.empty(in_shape, dtype=gy.dtype, device=gy.device)
+        rc = self._fn_dgrad(self.dtype, gy.data_ptr(), self._wbase + L.wdgrad_off, None if res is None else res.data_ptr(),
+                            None if mask is None else mask.data_ptr(), gx.data_ptr(), in_shape[0], in_shape[1], in_shape[2], in_shape[3],
+                            gshp[1], gshp[2], gshp[3], L.kh, L.kw, L.stride, L.pad, H.stream_ptr())
+        if rc:
+            H.fail("dcf_conv2d_dgrad", rc)
+        return gx
 
     def shortcut_dgrad(self, Ld, dd, L1, g1, in_shape, mask=None):
         """Input gradient of a strided block whose shortcut is a 1x1 / stride-2 conv Ld and whose main path starts with the
@@ -316,10 +337,25 @@ class HipBackend(object):
         q = self._wq
         if not q:
             return
-        items = (H.WgradItem * len(q))()
+        # the table of a step is the previous step's with new x / gy addresses: the ctypes array is kept per layer sequence
+        # (80 sixteen-field constructors per step were 0.3 ms of host time)
+        key = tuple([t[0].idx for t in q])
+        ent = self._wtab.get(key)
+        shapes = [t[1].shape for t in q]
+        sig = (self.bn_train, self._slbase, self._gsbase, tuple([t[0].nsplit for t in q]))
+        if ent is None or ent[1] != shapes or ent[2] != sig:
+            items = (H.WgradItem * len(q))()
+            for i, (L, x, gy) in enumerate(q):
+                B, Hh, W, Cin = x.shape
+                items[i] = H.WgradItem(self.dtype, L.nsplit, 0, 0, self._slbase + 4 * L.slab_off, self._gs(L), B, Hh, W, Cin, L.cout_pad, L.kh, L.kw, L.stride, L.pad, 0)
+            if len(self._wtab) > 16:
+                self._wtab.clear()
+            ent = self._wtab[key] = (items, shapes, sig)
+        items = ent[0]
         for i, (L, x, gy) in enumerate(q):
-            B, Hh, W, Cin = x.shape
-            items[i] = H.WgradItem(self.dtype, L.nsplit, x.data_ptr(), gy.data_ptr(), self._slbase + 4 * L.slab_off, self._gs(L), B, Hh, W, Cin, L.cout_pad, L.kh, L.kw, L.stride, L.pad, 0)
+            it = items[i]
+            it.x = x.data_ptr()
+            it.gy = gy.data_ptr()
         H.call("dcf_conv2d_wgrad_group", ctypes.addressof(items), len(q), H.stream_ptr())
         self._wq = []                      # the launches are enqueued: x / gy may be released (same stream)
 
@@ -337,7 +373,10 @@ class HipBackend(object):
         """defer=False: gy (or x) is modified in place later in the backward (e.g. masked by a ReLU) -- launch now."""
         if self._group and defer and L.kind != "stem":
             # independent of everything else in the backward: collected (x, gy kept alive) and issued together at the end
-            self._wq = self._wq + [(L, x, gy)]
+            q = self.__dict__.get("_wq")
+            if q is None:
+                q = self._wq = []
+            q.append((L, x, gy))
             return
         ops.conv2d_wgrad(self.dtype, x, gy, self._slbase + 4 * L.slab_off, L.nsplit, L.kh, L.kw, L.stride, L.pad, self._gs(L))
 
