@@ -534,7 +534,7 @@ class HipBackend(object):
         sum); the fp8 kernel has no such epilogue: there the bias stays a pass of its own."""
         if self._use_fp8(L, x.shape[:3]) or L.bn is not None or L.kh != 1 or L.kw != 1 or L.stride != 1:
             return self.rowscale_bias_fwd(self.conv_fwd(L, x, res, False), cnt, b2_off)
-        y = ops.conv2d_fwd_rowscale(self.dtype, x, self._w(L), self.params[b2_off:], cnt, res, False, L.cout_pad)
+        y = ops.conv2d_fwd_rowscale(self.dtype, x, self._w(L), self._pbase + 4 * b2_off, cnt, res, False, L.cout_pad)
         L.out_shape = (y.shape[0], y.shape[1], y.shape[2])
         return y
 
@@ -542,4 +542,4 @@ class HipBackend(object):
         return ops.rowscale_bias_fwd(self.dtype, y, cnt, self.params[b2_off:])
 
     def rowscale_bias_bwd(self, gy, cnt, b2_off):
-        ops.rowscale_bias_bwd(self.dtype, gy, cnt, self.grads[b2_off:])
+        ops.rowscale_bias_bwd(self.dtype, gy, cnt, self._gbase + 4 * b2_off)

@@ -461,6 +461,9 @@ def fusion_gather_bwd_inv_batch(dtype, P, xyz, inv, n_max, g0, khw, stride, aff,
            _chk(ghsum, "ghsum"), _chk(gP, "gP"), gw1d, gb1, ws, B, H.stream_ptr())
 
 
+_DWS_BYTES = {}
+
+
 def fusion_bwd_direct_workspace(device, max_entries, Cb, B):
     """Zeroed workspace of fusion_gather_bwd_direct_batch for maps of up to max_entries (= K*h*w) pairs (left zero by the kernel)."""
     return torch.zeros((max(H.lib().dcf_fusion_gather_bwd_direct_workspace_bytes(max_entries, Cb, B) // 4, 1),), dtype=torch.float32, device=device)
@@ -472,14 +475,18 @@ def fusion_gather_bwd_direct_batch(dtype, P, xyz, inv, n_max, g0, khw, stride, a
     start, ent = inv
     B, rows, Cb = P.shape
     me = khw[0] * khw[1] * khw[2]
-    if gP.dtype != P.dtype or tuple(gP.shape) != tuple(P.shape):
+    if gP.dtype != P.dtype or gP.shape != P.shape:
         raise H.DcfError("fusion_gather_bwd_direct_batch: gP must look like P")
-    if dws.numel() * 4 < H.lib().dcf_fusion_gather_bwd_direct_workspace_bytes(me, Cb, B):
+    need = _DWS_BYTES.get((me, Cb, B))
+    if need is None:
+        need = _DWS_BYTES[(me, Cb, B)] = H.lib().dcf_fusion_gather_bwd_direct_workspace_bytes(me, Cb, B)
+    if dws.numel() * 4 < need:
         raise H.DcfError("fusion_gather_bwd_direct_batch: workspace too small")
-    seg = start[g0 * (n_max + 1):]
-    H.call("dcf_fusion_gather_bwd_direct_batch", dtype, _chk(P, "P"), rows, _chk(xyz, "xyz"), xyz.stride(0), seg, seg[n_max:], n_max + 1, ent[0], ent[1],
-           me, khw[1], khw[2], stride, float(aff[0]), float(aff[1]), float(aff[2]), float(aff[3]), w1d, b1, Cb,
-           _chk(ghsum, "ghsum"), _chk(gP, "gP"), gw1d, gb1, ws, dws, B, H.stream_ptr())
+    # (raw addresses of the map's start segment and of the two pair arrays: four tensor views per call otherwise)
+    seg = start.data_ptr() + 4 * g0 * (n_max + 1)
+    H.call("dcf_fusion_gather_bwd_direct_batch", dtype, _chk(P, "P"), rows, _chk(xyz, "xyz"), xyz.stride(0), seg, seg + 4 * n_max, n_max + 1,
+           ent.data_ptr(), ent.data_ptr() + 4 * ent.stride(0), me, khw[1], khw[2], stride, float(aff[0]), float(aff[1]), float(aff[2]), float(aff[3]),
+           w1d, b1, Cb, _chk(ghsum, "ghsum"), _chk(gP, "gP"), gw1d, gb1, ws, dws, B, H.stream_ptr())
 
 
 def fusion_gather_fwd(dtype, P, xyz, idx, stride, aff, w1d, b1, out=None):
