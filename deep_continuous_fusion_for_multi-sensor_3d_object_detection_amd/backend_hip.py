@@ -342,7 +342,7 @@ class HipBackend(object):
         key = tuple([t[0].idx for t in q])
         ent = self._wtab.get(key)
         shapes = [t[1].shape for t in q]
-        sig = (self.bn_train, self._slbase, self._gsbase, tuple([t[0].nsplit for t in q]))
+        sig = (self.bn_train, self._slbase, self._gsbase, tuple([(t[0].nsplit, t[0].slab_off, t[0].gsum_off) for t in q]))
         if ent is None or ent[1] != shapes or ent[2] != sig:
             items = (H.WgradItem * len(q))()
             for i, (L, x, gy) in enumerate(q):
@@ -532,7 +532,8 @@ class HipBackend(object):
     def conv_fwd_rowscale(self, L, x, res, cnt, b2_off):
         """conv_fwd of a 1x1 layer without BatchNorm + cnt[m] * b2[c] in the same epilogue (the fusion site's fc2 under the neighbour
         sum); the fp8 kernel has no such epilogue: there the bias stays a pass of its own."""
-        if self._use_fp8(L, x.shape[:3]) or L.bn is not None or L.kh != 1 or L.kw != 1 or L.stride != 1:
+        if self._use_fp8(L, x.shape[:3]) or L.bn is not None or L.kh != 1 or L.kw != 1 or L.stride != 1 or L.cout_pad != L.cout:
+            # (a padded layer: the epilogue would read cout_pad entries of the cout-long master bias)
             return self.rowscale_bias_fwd(self.conv_fwd(L, x, res, False), cnt, b2_off)
         y = ops.conv2d_fwd_rowscale(self.dtype, x, self._w(L), self._pbase + 4 * b2_off, cnt, res, False, L.cout_pad)
         L.out_shape = (y.shape[0], y.shape[1], y.shape[2])

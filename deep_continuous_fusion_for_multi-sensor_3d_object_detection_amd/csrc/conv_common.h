@@ -11,6 +11,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // ---- LDS-DMA helpers (used by k_conv_igemm_dma and k_conv_wgrad3g)
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// the same without the compiler-level memory fence: for waits that only guard REGISTERS filled by an inline-asm load (the
+// uses are tied to it through "+v" operands of an asm placed behind it)
+template <int N> __device__ __forceinline__ void wait_vmcnt_nomem() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N)); }
 
 // One LDS-DMA instruction: 64 lanes x 16 B, lane l from buffer offset voff[l], to LDS bytes [lds_dst, lds_dst + 1024).
 // A lane whose offset is outside the descriptor's range has ZEROS written for it (probed on MI355X:

@@ -63,16 +63,25 @@ extern int g_dcf_prof_on;
 // first use) and changed afterwards only through dcf_set_option() (tests and tools compare kernels that way).  None of them
 // changes results.  Switches that DO -- the timing ablations that turn phases of a kernel off -- exist only in builds with
 // -DDCF_ABLATE (make ABLATE=1; tools/rs_ablate.py and friends): the shipped library has no way to reach them.
-const char *dcf_opt(const char *name);          // current value or nullptr (runtime.cpp)
-extern int g_dcf_opt_epoch;                      // bumped by dcf_set_option
+// Launches come from several host threads (the main thread, the autograd thread, the gradient-bucket hook): a call site's
+// cached view is a pair of atomics -- a reader sees either the old value with the old epoch (and refreshes on its next call)
+// or the new pair; interned values are never freed, so a stale pointer stays readable.
+#include <atomic>
+const char *dcf_opt(const char *name);          // current value or nullptr (runtime.cpp; takes the registry mutex)
+extern std::atomic<int> g_dcf_opt_epoch;         // bumped by dcf_set_option
 struct DcfOpt {                                  // a call site's cached view of one option: static DcfOpt o("RS_KIND");
-    const char *name, *val;
-    int epoch;
+    const char *name;
+    std::atomic<const char *> val;
+    std::atomic<int> epoch;
     explicit DcfOpt(const char *n) : name(n), val(nullptr), epoch(-1) {}
     const char *str()
     {
-        if (epoch != g_dcf_opt_epoch) { val = dcf_opt(name); epoch = g_dcf_opt_epoch; }
-        return val;
+        const int now = g_dcf_opt_epoch.load(std::memory_order_acquire);
+        if (epoch.load(std::memory_order_acquire) != now) {
+            val.store(dcf_opt(name), std::memory_order_release);
+            epoch.store(now, std::memory_order_release);
+        }
+        return val.load(std::memory_order_acquire);
     }
 };
 #ifdef DCF_ABLATE

@@ -20,10 +20,12 @@ void dcf_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *dcf_last_error(void) { return g_err; }
-extern "C" int dcf_version(void) { return 100; }
+// 101: dcf_fusion_gather_bwd_inv gained its workspace argument (round 3), the dcf_conv3x3_*_wf entry points and the
+// DCF_CONV_FRAG table flag were added (round 4) -- INTEGRATION.md, "Versions"
+extern "C" int dcf_version(void) { return 101; }
 
 // ------------------------------------------------------------------ tuning options (dcf_common.h)
-int g_dcf_opt_epoch = 0;
+std::atomic<int> g_dcf_opt_epoch{0};
 namespace {
 std::mutex g_opt_mu;
 std::map<std::string, const char *> g_opts;      // name -> interned value (nullptr = unset); never freed: call sites cache the pointers
@@ -48,7 +50,7 @@ extern "C" int dcf_set_option(const char *name, const char *value)
     }
     std::lock_guard<std::mutex> lk(g_opt_mu);
     g_opts[name] = value ? strdup(value) : nullptr;
-    ++g_dcf_opt_epoch;
+    g_dcf_opt_epoch.fetch_add(1, std::memory_order_acq_rel);
     return DCF_OK;
 }
 

@@ -100,6 +100,7 @@ class LossTotal(nn.Module):
             raise ValueError("loss_sampling must be compat or device (got %r)" % (self.sampling,))
         self.seed = int(config.get("loss_seed", 0))
         self.calls = 0                     # device sampling: the call count enters the hash, so every step draws fresh lists
+                                           # (saved with the checkpoint: Train.save_checkpoint / load_checkpoint)
         self.last_samples = None           # device sampling with keep_samples: (pos [B,cap], neg [B,n], counts [B,2]) of the last call
         self.keep_samples = False
         anc = AnchorBoundingBoxFeature(config)()
@@ -320,7 +321,9 @@ class LossTotal(nn.Module):
             outs = (torch.empty((B, geo[7]), dtype=torch.int32, device=dev), torch.empty((B, geo[8]), dtype=torch.int32, device=dev),
                     torch.empty((B, 2), dtype=torch.int32, device=dev))
             self.last_samples = outs
-        seed = (self.seed * 0x9E3779B1 + self.calls) & 0xFFFFFFFFFFFFFFFF
+        # rank 0 / a single process: (seed, calls) as before; other data-parallel ranks draw from streams of their own
+        rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+        seed = (self.seed * 0x9E3779B1 + self.calls + rank * 0x85EBCA77C2B2AE63) & 0xFFFFFFFFFFFFFFFF
         self.calls += 1
         red = {"last": 0, "sum": 1, "mean": 2}[self.reduction]
         return _FusedLossSample.apply(base, cls, reg, anc, boxes, nb, geo, seed, c["regress_loss_gain"], red, outs)

@@ -296,7 +296,7 @@ class Train(nn.Module):
         optimiser moments / step count and the epoch, so that training can really resume."""
         sd = {k: v.detach().clone().contiguous().cpu() for k, v in self.model.state_dict().items()}
         opt = {"step": self.optimizer.step_count, "m": self.optimizer.m.cpu(), "v": self.optimizer.v.cpu()}
-        torch.save({"model": sd, "optimizer": opt, "epoch": int(epoch)}, path)
+        torch.save({"model": sd, "optimizer": opt, "epoch": int(epoch), "loss_calls": int(getattr(self.loss_total, "calls", 0))}, path)
 
     def load_checkpoint(self, path):
         ck = torch.load(path, map_location="cpu")
@@ -306,6 +306,8 @@ class Train(nn.Module):
         self.model.load_state_dict(ck["model"])
         self.optimizer.load_state_dict({k: (v.to(self.model.flat_params.device) if torch.is_tensor(v) else v)
                                         for k, v in ck["optimizer"].items()})
+        if hasattr(self.loss_total, "calls"):       # device sampling: a resumed run continues the draw sequence instead of replaying it
+            self.loss_total.calls = int(ck.get("loss_calls", self.optimizer.step_count))
         return int(ck.get("epoch", 0))
 
     def get_loss_value(self, lidar_voxel, camera_image, object_data, num_ref_box, **extra):
