@@ -658,20 +658,36 @@ class OffsettoBbox(nn.Module):
 
 class LidarBackboneNetwork(nn.Module):
     """model.py:140-173 surface: (x_cls [B,4,h,w], x_reg [B,14,h,w]) = net(x [B,C,L,W]).
-    Implemented as a view of the full engine (the decode channels are simply dropped)."""
+    Implemented as a view of the full engine (the decode channels are simply dropped).
+
+    Like the reference's, the constructor needs no config (`LidarBackboneNetwork()`, model.py:139): the parameters do not
+    depend on the BEV grid, only the engine's plan does, so the net is built on the packaged config's grid and re-planned
+    -- same parameters -- for the grid of the first input that differs (L and W multiples of 16, model.py:151)."""
 
     def __init__(self, out_feature=(32, 64, 128, 192, 256), num_res_block=(1, 2, 4, 6, 6), Num_anchor=2, config=None):
         super(LidarBackboneNetwork, self).__init__()
         if Num_anchor != 2:
             raise NotImplementedError("the head kernel is specialised for the reference's 2 anchors")
-        cfg = dict(config) if config is not None else None
-        if cfg is None:
-            raise ValueError("LidarBackboneNetwork needs the config dict for the BEV grid size (voxel_length/width)")
+        if config is None:
+            import yaml
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "config", "config_carla.yaml")) as f:
+                cfg = yaml.safe_load(f)
+            cfg["voxel_channel"] = out_feature[0]
+        else:
+            cfg = dict(config)
         cfg["lidar_module"] = dict(("out_feature%d" % (i + 1), out_feature[i]) for i in range(5))
         cfg["lidar_module"].update(dict(("num_res_block%d" % (i + 1), num_res_block[i]) for i in range(5)))
         cfg["fusion"] = {"enabled": False}
+        self._cfg = cfg
         self.net = ObjectDetection_DCF(cfg)
 
     def forward(self, x):
+        L, W = int(x.shape[2]), int(x.shape[3])
+        if (L, W) != (self._cfg["voxel_length"], self._cfg["voxel_width"]):
+            cfg = dict(self._cfg, voxel_length=L, voxel_width=W)
+            net = ObjectDetection_DCF(cfg).to(x.device)
+            net.load_state_dict(self.net.state_dict())
+            net.train(self.net.training)
+            self._cfg, self.net = cfg, net
         pred = self.net(x, None)
         return pred[:, 0:4], pred[:, 4:18]

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--tag", default="")
     ap.add_argument("--dgrad", action="store_true")
+    ap.add_argument("--std", action="store_true", help="time dcf_conv2d_fwd (standard weight layout: conv_lc / conv_rs) instead of the _wf entry")
     ap.add_argument("names", nargs="*")
     args = ap.parse_args()
     B = args.batch
@@ -30,6 +31,8 @@ def main():
             res = (torch.rand((B, Hh, W, Co), device="cuda") - 0.5).bfloat16()
             mask = (torch.rand((B, Hh, W, Co), device="cuda") - 0.3).bfloat16()
             t = timeit(lambda: ops.conv3x3_dgrad_wf(1, x, wf, res, (B, Hh, W, Co), mask=mask), iters=30)
+        elif args.std:
+            t = timeit(lambda: ops.conv2d_fwd(1, x, w, None, None, 3, 3, 1, 1, False, Co), iters=30)
         else:
             t = timeit(lambda: ops.conv3x3_fwd_wf(1, x, wf, None, None, False, Co), iters=30)
         out.append("%s %.1f" % (name, t * 1e6))
