@@ -1458,11 +1458,12 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
                           int B, int H, int W, int Ck, int Cn, int relu, int flip, const char *name_base, double flops, hipStream_t s);
 // the same layers with loader and consumer waves (conv_lc.hip); option CONV_LC=0 falls back to conv_rs.hip
 int dcf_conv3x3_lc_launch(int dtype, const void *x, const void *w, const float *shift, const void *res, const void *mask, void *y,
-                          int B, int H, int W, int Ck, int Cn, int relu, int flip, const char *name_base, double flops, hipStream_t s);
-static bool use_lc()
+                          int B, int H, int W, int Ck, int Cn, int relu, int flip, const char *name_base, double flops, int force, hipStream_t s);
+// CONV_LC: 0 = never, 2 = whenever the shape is supported, unset / 1 = where it measured faster (see dcf_conv3x3_lc_launch)
+static int use_lc()
 {
     static DcfOpt e_o("CONV_LC"); const char *e = e_o.str();
-    return !(e && atoi(e) == 0);
+    return e ? atoi(e) : 1;
 }
 // spatial-tile streaming kernel for the HBM-bound 32 / 64-channel 3x3 / stride-1 layers (conv_sp.hip)
 int dcf_conv3x3_sp_launch(int dtype, const void *x, const void *w, const float *shift, const void *res, const void *mask, void *y,
@@ -1542,7 +1543,7 @@ static int conv2d_fwd_impl(int dtype, const void *x, const void *w, const float 
         rc = dcf_conv3x3_sp_launch(dtype, x, w, shift, res, nullptr, y, B, H, W, Cin, Cout, relu, 0, dtype == DCF_F16 ? "conv_fwd_f16" : "conv_fwd_bf16", flops, S(stream));
         if (rc != DCF_EUNSUPPORTED) return rc;
         if (use_lc()) {
-            rc = dcf_conv3x3_lc_launch(dtype, x, w, shift, res, nullptr, y, B, H, W, Cin, Cout, relu, 0, dtype == DCF_F16 ? "conv_fwd_f16" : "conv_fwd_bf16", flops, S(stream));
+            rc = dcf_conv3x3_lc_launch(dtype, x, w, shift, res, nullptr, y, B, H, W, Cin, Cout, relu, 0, dtype == DCF_F16 ? "conv_fwd_f16" : "conv_fwd_bf16", flops, use_lc() == 2, S(stream));
             if (rc != DCF_EUNSUPPORTED) return rc;
         }
         rc = dcf_conv3x3_rs_launch(dtype, x, w, shift, res, nullptr, y, B, H, W, Cin, Cout, relu, 0, dtype == DCF_F16 ? "conv_fwd_f16" : "conv_fwd_bf16", flops, S(stream));
@@ -1584,7 +1585,7 @@ static int conv2d_dgrad_impl(int dtype, const void *gy, const void *wt, const vo
         rc = dcf_conv3x3_sp_launch(dtype, gy, wt, nullptr, res, mask, gx, B, H, W, Cout, Cin, 0, 1, dtype == DCF_F16 ? "conv_dgrad_f16" : "conv_dgrad_bf16", flops, S(stream));
         if (rc != DCF_EUNSUPPORTED) return rc;
         if (use_lc()) {
-            rc = dcf_conv3x3_lc_launch(dtype, gy, wt, nullptr, res, mask, gx, B, H, W, Cout, Cin, 0, 1, dtype == DCF_F16 ? "conv_dgrad_f16" : "conv_dgrad_bf16", flops, S(stream));
+            rc = dcf_conv3x3_lc_launch(dtype, gy, wt, nullptr, res, mask, gx, B, H, W, Cout, Cin, 0, 1, dtype == DCF_F16 ? "conv_dgrad_f16" : "conv_dgrad_bf16", flops, use_lc() == 2, S(stream));
             if (rc != DCF_EUNSUPPORTED) return rc;
         }
         rc = dcf_conv3x3_rs_launch(dtype, gy, wt, nullptr, res, mask, gx, B, H, W, Cout, Cin, 0, 1, dtype == DCF_F16 ? "conv_dgrad_f16" : "conv_dgrad_bf16", flops, S(stream));

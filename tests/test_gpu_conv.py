@@ -442,3 +442,86 @@ def test_conv_sp_kernel_forced_on_small_shapes(shape, dtype):
     got3 = from_dev(gx3)
     _assert_quantised_close(got3, (xg.grad + gres) * (gmask > 0), dtype, "sp dgrad+res+mask")
     assert float((got3 * (gmask <= 0)).abs().max()) == 0.0
+
+
+# ---- loader / consumer kernel over 2-D tiles (csrc/conv_lc.hip), forced on shapes that the automatic choice would leave to
+# conv_rs.hip: odd widths / heights (tiles cut by the image border on every side), a width smaller than the smallest tile, one /
+# two / three / four 64-channel chunks, 64-, 128-, 192- and 256-channel outputs (both tile kinds), several frames, enough tiles
+# for the persistent loop to walk more than one per workgroup.  Forward with the fused epilogue, input gradient with residual +
+# mask, against torch's fp32 convolution; and against conv_rs.hip on the same inputs (same products, another summation order).
+LC_SHAPES = [
+    (1, 16, 16, 64, 64),
+    (2, 37, 61, 64, 64),
+    (1, 75, 83, 128, 128),
+    (3, 41, 43, 192, 128),
+    (2, 9, 13, 256, 64),
+    (1, 50, 101, 64, 192),
+    (2, 23, 200, 128, 256),
+    (1, 176, 200, 128, 128),          # 120 tiles of 6 x 50
+    (4, 90, 102, 192, 192),           # > 256 tiles: the persistent loop
+]
+
+
+@pytest.mark.parametrize("dtype", [1, 2])
+@pytest.mark.parametrize("shape", LC_SHAPES)
+def test_conv_lc_fwd_dgrad(shape, dtype):
+    ops, H = pkg("ops"), pkg("_hip")
+    B, Hh, W, Cin, Cout = shape
+    x, w = _mk((B, Hh, W, Cin, Cout, 3, 1), dtype, 41)
+    shift = rnd((Cout,), 42)
+    ref_lin = F.conv2d(x, w, None, 1, 1)
+    res = q(rnd(tuple(ref_lin.shape), 43), dtype)
+    xd, wd = to_dev(x, dtype), to_dev(w, dtype)
+    try:
+        H.set_option("CONV_LC", 2)
+        y = ops.conv2d_fwd(dtype, xd, wd, None, None, 3, 3, 1, 1, False, Cout)
+        y2 = ops.conv2d_fwd(dtype, xd, wd, shift.cuda(), to_dev(res, dtype), 3, 3, 1, 1, True, Cout)
+        H.set_option("CONV_LC", 0)
+        y_rs = ops.conv2d_fwd(dtype, xd, wd, None, None, 3, 3, 1, 1, False, Cout)
+    finally:
+        H.set_option("CONV_LC", None)
+    assert rel_err(from_dev(y), ref_lin) < TOL[dtype]
+    ref2 = torch.relu(ref_lin + shift.view(1, -1, 1, 1) + res)
+    assert rel_err(from_dev(y2), ref2) < TOL[dtype]
+    assert float(from_dev(y2).min()) >= 0.0
+    # one unit in the last place of the 16-bit output at most, relative to the largest output
+    assert rel_err(from_dev(y), from_dev(y_rs)) < (8e-3 if dtype == 1 else 1e-3)
+    # input gradient: roles swap (reduction over Cout)
+    xg = x.clone().requires_grad_(True)
+    yy = F.conv2d(xg, w, None, 1, 1)
+    gy = q(rnd(tuple(yy.shape), 44), dtype)
+    yy.backward(gy)
+    wt = w.permute(1, 2, 3, 0).contiguous().cuda().to(TORCH_DT[dtype])
+    resg = q(rnd((B, Cin, Hh, W), 45), dtype)
+    mask = q(rnd((B, Cin, Hh, W), 46), dtype)
+    try:
+        H.set_option("CONV_LC", 2)
+        gx = ops.conv2d_dgrad(dtype, to_dev(gy, dtype), wt, None, (B, Hh, W, Cin), 3, 3, 1, 1)
+        gx3 = ops.conv2d_dgrad(dtype, to_dev(gy, dtype), wt, to_dev(resg, dtype), (B, Hh, W, Cin), 3, 3, 1, 1, to_dev(mask, dtype))
+    finally:
+        H.set_option("CONV_LC", None)
+    assert rel_err(from_dev(gx), xg.grad) < TOL[dtype]
+    got3 = from_dev(gx3)
+    assert rel_err(got3, (xg.grad + resg) * (mask > 0)) < TOL[dtype]
+    assert float((got3 * (mask <= 0)).abs().max()) == 0.0
+
+
+def test_conv_lc_is_the_automatic_choice_for_multi_round_launches():
+    """The launch name recorded by the library's profiling layer tells which kernel ran: conv_lc for a launch of more than one
+    round of workgroups, conv_rs for a single round (csrc/conv_lc.hip: dcf_conv3x3_lc_launch)."""
+    ops, H = pkg("ops"), pkg("_hip")
+    names = {}
+    for B, tag in ((1, "single"), (8, "multi")):
+        x = torch.zeros((B, 88, 100, 192), device="cuda", dtype=torch.bfloat16)
+        w = torch.zeros((192, 3, 3, 192), device="cuda", dtype=torch.bfloat16)
+        H.call("dcf_prof_reset")
+        H.call("dcf_prof_enable", 1)
+        try:
+            ops.conv2d_fwd(1, x, w, None, None, 3, 3, 1, 1, False, 192)
+            torch.cuda.synchronize()
+        finally:
+            H.call("dcf_prof_enable", 0)
+        names[tag] = [n for n in H.prof_read() if n.startswith("conv_fwd")]
+        H.call("dcf_prof_reset")
+    assert any("<rs" in n for n in names["single"]), names
+    assert any("<lc" in n for n in names["multi"]), names

@@ -603,3 +603,23 @@ def test_stack_backward_without_gradient_for_the_deep_outputs():
     with pytest.raises(RuntimeError) as e:
         a[2].sum().backward()
     assert "stale forward" in str(e.value)
+
+
+def test_lidar_backbone_network_bare_constructor_replans_for_the_input_grid():
+    """`LidarBackboneNetwork()` (no config, /root/reference/model.py:139) on a grid other than the packaged config's: the same
+    parameters give the same (cls, reg) as a net built with the grid in its config."""
+    m = pkg("model")
+    import yaml, os
+    with open(os.path.join(os.path.dirname(m.__file__), "config", "config_carla.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    widths, blocks = (32, 64, 96, 128, 160), (1, 1, 2, 1, 1)
+    cfg.update(voxel_length=64, voxel_width=32, voxel_channel=32)
+    ref = m.LidarBackboneNetwork(widths, blocks, config=cfg).cuda()
+    bare = m.LidarBackboneNetwork(widths, blocks).cuda()
+    bare.net.load_state_dict(ref.net.state_dict())
+    x = torch.from_numpy(pkg("detfill").uniform((2, 32, 64, 32), 77, 0.0, 1.0)).cuda()
+    with torch.no_grad():
+        c0, r0 = ref(x)
+        c1, r1 = bare(x)
+    assert c1.shape == (2, 4, 16, 8) and r1.shape == (2, 14, 16, 8)
+    assert float((c0 - c1).abs().max()) < 1e-5 and float((r0 - r1).abs().max()) < 1e-5

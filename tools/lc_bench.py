@@ -44,7 +44,9 @@ def main():
         y1 = ops.conv2d_fwd(dt, x, w, shift, res, 3, 3, 1, 1, True, Co)
         g1 = ops.conv2d_dgrad(dt, gy, wt, resg, (B, Hh, W, Ci), 3, 3, 1, 1, mask=mask)
         torch.cuda.synchronize()
-        eqf, eqd = bool(torch.equal(y0, y1)), bool(torch.equal(g0, g1))
+        # (the 2-D kernel sums chunk-major, conv_rs kernel-row-major: the same products in another fp32 order -- an output may land
+        # on the neighbouring 16-bit value)
+        eqf, eqd = bool(torch.allclose(y0.float(), y1.float(), atol=1.6e-2, rtol=0)), bool(torch.allclose(g0.float(), g1.float(), atol=1.6e-2, rtol=0))
         if not eqf:
             d = (y0.float() - y1.float()).abs()
             print("   fwd mismatch: max %.4g, %d of %d elements, first at %s" % (d.max().item(), int((d > 0).sum()), d.numel(), tuple((d > 0).nonzero()[0].tolist())))
@@ -60,7 +62,7 @@ def main():
         t3 = timeit(lambda: ops.conv2d_dgrad(dt, gy, wt, resg, (B, Hh, W, Ci), 3, 3, 1, 1, mask=mask))
         tot["rs_fwd"] += t0 * cnt; tot["lc_fwd"] += t1 * cnt; tot["rs_dgrad"] += t2 * cnt; tot["lc_dgrad"] += t3 * cnt
         print("%-6s %4d %4d %4d %4d | %8.1f %6.1f %8.0f %s | %10.1f %6.1f %8.0f %s  (x%d)" % (
-            name, Hh, W, Ci, Co, t0 * 1e6, t1 * 1e6, fl / t1 / 1e12, "==" if eqf else "NE", t2 * 1e6, t3 * 1e6, fl / t3 / 1e12, "==" if eqd else "NE", cnt), flush=True)
+            name, Hh, W, Ci, Co, t0 * 1e6, t1 * 1e6, fl / t1 / 1e12, ("%.0e" % (y0.float() - y1.float()).abs().max().item()) if eqf else "NE", t2 * 1e6, t3 * 1e6, fl / t3 / 1e12, ("%.0e" % (g0.float() - g1.float()).abs().max().item()) if eqd else "NE", cnt), flush=True)
     print("weighted totals (ms):", {k: round(v * 1e3, 3) for k, v in tot.items()})
 
 

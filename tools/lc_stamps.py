@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--wg", type=int, default=0)
+    ap.add_argument("--summary", action="store_true", help="one line: median busy cycles per tap of each wave")
     ap.add_argument("name")
     args = ap.parse_args()
     L = ctypes.CDLL(H.LIB_PATH)
@@ -39,7 +40,21 @@ def main():
         L.dcf_lc_stamps_read(buf.ctypes.data_as(ctypes.c_void_p), dims)
         st = buf.reshape(dims[0], dims[1], dims[2], dims[3])[args.wg]
         t0 = st[st > 0].min()
+        marks = st[:, dims[2] - 8:, 0]
+        if (marks > 0).any():
+            for wv in range(8):
+                if (marks[wv] > 0).any():
+                    print("wave %d prologue marks (cycles since first stamp): %s" % (wv, " ".join("%d" % (m - t0) for m in marks[wv] if m > 0)))
+        st = st.copy(); st[:, dims[2] - 8:, :] = 0
         ng = int((st[0, :, 0] > 0).sum())
+        if args.summary:
+            busy = np.zeros((8, ng - 1))
+            for g in range(1, ng):
+                busy[:, g - 1] = st[:, g, 0] - st[:, g - 1, 1].min()
+            print("TH/TW %s/%s: barrier 0 opened at %d; median busy cycles per tap, waves 0..7: %s; median period %d" % (
+                os.environ.get("DCF_LC_TH"), os.environ.get("DCF_LC_TW"), int(st[:, 0, 1].min() - t0), " ".join("%5d" % v for v in np.median(busy, axis=1)),
+                int(np.median(np.diff(st[:, :ng, 1].min(axis=0))))))
+            return
         print("barrier | arrival of waves 0..7 (cycles)                                  | opened | last to arrive | since previous")
         prev = 0
         for g in range(ng):
