@@ -235,6 +235,8 @@ def rocprof_kernel(name):
     if t and t[0].startswith("sp"):                          # spatial-tile streaming kernel: 'conv_fwd_bf16<sp32>'
         c = t[0][2:]                                         # instantiations: <T, 32, 8, 2> (default) and <T, 64, 4, 3>
         return "k_conv3x3_sp", [dt, c, "8" if c == "32" else "4", "2" if c == "32" else "3"]
+    if t and t[0].startswith("lc"):                          # loader / consumer kernel over 2-D tiles: 'conv_fwd_bf16<lc0,6x50>'
+        return "k_conv3x3_lc", [dt] + {0: ["2", "5", "2", "2", "3", "440"], 1: ["1", "5", "2", "2", "4", "504"]}[int(t[0][2:])]
     if t and t[0].startswith("rs"):                          # row-sharing kernel: 'conv_fwd_bf16<rs0,9>' = tile kind 0, 9 position tiles
         return "k_conv3x3_rs", [dt] + {0: ["1", "5", "4", "2", "2", "1", "false"], 1: ["1", "3", "2", "4", "2", "1", "false"],
                                        2: ["1", "1", "2", "4", "6", "2", "true"]}[int(t[0][2:])]
@@ -392,8 +394,9 @@ def main():
     ap.add_argument("--image-stream", default="resnet18", help="camera trunk: resnet18 (cfg2), resnet34, resnet50 (cfg4)")
     ap.add_argument("--image", default="1242x375", help="camera frame WxH (cfg2/cfg4: 1242x375, cfg5: 1920x1080)")
     ap.add_argument("--bn-mode", default="eval", help="eval = what the reference's train.py really does (F4); train = batch statistics")
-    ap.add_argument("--graphs", action="store_true", help="replay captured forward/backward HIP graphs instead of eager launches "
-                    "(measured equal on this workload: the step is kernel-bound, not launch-bound)")
+    ap.add_argument("--graphs", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
+                    help="captured forward/backward HIP graphs instead of eager launches: auto (default) = at batch 1 on one GPU, where "
+                    "the step runs at the host's pace (251 against 200 frames/s); at batch >= 2 the step is kernel-bound")
     ap.add_argument("--from-host", action="store_true", help="feed the timed steps from host memory through FrameLoader "
                     "(pinned staging + H2D on a copy stream): the PCIe-inclusive rate")
     ap.add_argument("--no-from-host", action="store_true", help="skip the short PCIe-inclusive leg reported as `from_host`")
@@ -414,8 +417,9 @@ def main():
     cfg["loss_sampling"] = args.loss_sampling
     global PMC_TAG
     key = (args.points, args.knn, args.image_stream, args.batch, args.dtype, args.image.lower())
-    PMC_TAG = {(100000, 3, "resnet18", 2, "bf16", "1242x375"): "", (300000, 3, "resnet18", 1, "bf16", "1920x1080"): "cfg5shape_bf16_"}.get(key)
-    cfg["hip_graphs"] = bool(args.graphs)
+    PMC_TAG = {(100000, 3, "resnet18", 2, "bf16", "1242x375"): "", (120000, 5, "resnet50", 4, "f16", "1242x375"): "cfg4_",
+               (300000, 3, "resnet18", 1, "bf16", "1920x1080"): "cfg5shape_bf16_", (300000, 3, "resnet18", 1, "fp8", "1920x1080"): "cfg5_fp8_"}.get(key)
+    cfg["hip_graphs"] = {"auto": "auto", "on": True, "off": False}[args.graphs]
     torch.manual_seed(0)
     np.random.seed(1234 + rank)
     trainer = train.Train(cfg)
@@ -505,6 +509,10 @@ def main():
                                           args.knn, args.bn_mode, " (reference F4)" if args.bn_mode == "eval" else "", args.batch),
                           "global_batch": args.batch * ws, "parallelism": "dp%d" % ws, "final_loss": round(loss, 4),
                           "input": "host memory through FrameLoader (PCIe-inclusive)" if args.from_host else "resident in HBM",
+                          # SURVEY.md 8(d)'s metric starts at the H2D copy of the raw frame: the PCIe-inclusive rate of the same step
+                          # (frames in host memory -> pinned staging -> H2D one batch ahead), beside the HBM-resident `value`
+                          "from_host_frames_per_s": from_host["value"] if from_host else (round(frames / dt, 3) if args.from_host else None),
+                          "from_host_ms_per_step": from_host["ms_per_step"] if from_host else (round(dt / args.steps * 1e3, 3) if args.from_host else None),
                           "loss_sampling": args.loss_sampling},
                "roofline": roof, "cpu_baseline": cpu, "from_host": from_host, "kernel_classes": classes, "kernel_breakdown": breakdown}
         print(json.dumps(out))

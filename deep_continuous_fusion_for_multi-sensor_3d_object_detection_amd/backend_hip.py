@@ -176,10 +176,11 @@ class HipBackend(object):
         self.__dict__.pop("_done", None)   # ... and so is its half-finished bucket state (a backward that raised after bucket_ready)
 
     # Gradient buckets (data parallel): the layer table is ordered LiDAR stream | camera stream | fusion layers, and so is
-    # the parameter arena.  With a hook installed (train.Train, world size > 1) the backward finalises the LiDAR + fusion
-    # layers as soon as their weight gradients are complete and hands the arena ranges to the hook, which starts their
-    # all-reduce while the camera stream's backward still runs; the camera bucket follows at the end.  Without a hook:
-    # one flush, one finalisation launch (the single-GPU path is unchanged).
+    # the parameter arena.  With a hook installed (train.Train, world size > 1) the backward finalises FOUR buckets in the
+    # order it completes them -- LiDAR stages 4-5 + FPN + heads, the rest of the LiDAR stream + the fusion layers, camera
+    # layer4 + FPN, the rest of the camera stream -- and hands each one's arena ranges to the hook, which starts its
+    # all-reduce while the backward goes on.  Without a hook: one flush, one finalisation launch (the single-GPU path is
+    # unchanged).
     bucket_hook = None
 
     def _layer_split(self, layers):
@@ -188,6 +189,26 @@ class HipBackend(object):
         if not img or not fus or max(img) + 1 != min(fus) or max(fus) + 1 != len(layers):
             return None
         return min(img), min(fus)
+
+    def _bucket_layers(self, layers, which):
+        """Layer index ranges of a gradient bucket, in the order the backward completes them:
+          lidar_hi      LiDAR stages 4-5, FPN, heads  (33 MB of the 50 MB LiDAR stream at cfg2)
+          lidar+fusion  the rest of the LiDAR stream + the fusion layers
+          image_hi      camera layer4 + camera FPN    (34 MB of the 45 MB camera stream)
+        and whatever is left at the end of the backward (camera stem .. layer3)."""
+        sp = self._layer_split(layers)
+        if sp is None:
+            return None
+        i0, f0 = sp
+        if which == "lidar_hi":
+            l4 = [L.idx for L in layers[:i0] if ".layer4." in L.name]
+            return [(min(l4), i0)] if l4 else None
+        if which == "lidar+fusion":
+            return [(0, i0), (f0, len(layers))]
+        if which == "image_hi":
+            l4 = [L.idx for L in layers[i0:f0] if ".layer4." in L.name]
+            return [(min(l4), f0)] if l4 else None
+        raise ValueError("unknown gradient bucket %r" % (which,))
 
     def _finalize(self, lo, hi):
         tab = self.table.data_ptr() + lo * ctypes.sizeof(H.ConvParam)
@@ -200,30 +221,49 @@ class HipBackend(object):
         b = layers[hi].w_off if hi < len(layers) else self.params.numel()
         return a, b
 
+    def _finalize_pending(self, layers, ranges):
+        """Finalise the not-yet-finalised layers inside the index ranges; returns their arena ranges."""
+        done = self.__dict__.setdefault("_done", [False] * len(layers))
+        out = []
+        for lo, hi in ranges:
+            i = lo
+            while i < hi:
+                if done[i]:
+                    i += 1
+                    continue
+                j = i
+                while j < hi and not done[j]:
+                    done[j] = True
+                    j += 1
+                self._finalize(i, j)
+                out.append(self._param_ranges(layers, i, j))
+                i = j
+        return out
+
     def bucket_ready(self, layers, which):
+        """The backward tells that every weight gradient of bucket `which` has been queued: with a hook installed, flush the queue,
+        finalise those layers and hand their arena ranges over (their all-reduce starts under the rest of the backward)."""
         if self.bucket_hook is None:
             return
-        sp = self._layer_split(layers)
-        if sp is None:
+        rng = self._bucket_layers(layers, which)
+        if rng is None:
             return
-        i0, f0 = sp
         self._flush_wgrads()
-        self._finalize(0, i0)                       # LiDAR stream
-        self._finalize(f0, len(layers))             # fusion layers
-        self._done = (i0, f0)
-        self.bucket_hook([self._param_ranges(layers, 0, i0), self._param_ranges(layers, f0, len(layers))])
+        out = self._finalize_pending(layers, rng)
+        if out:
+            self.bucket_hook(out)
 
     def end_backward(self, layers):
         self._flush_wgrads()
-        done = self.__dict__.pop("_done", None)
-        if done is None:
+        if self.__dict__.get("_done") is None:
             self._finalize(0, self.nconv)
             if self.bucket_hook is not None:
                 self.bucket_hook([(0, self.params.numel())])
             return
-        i0, f0 = done
-        self._finalize(i0, f0)                      # camera stream
-        self.bucket_hook([self._param_ranges(layers, i0, f0)])
+        out = self._finalize_pending(layers, [(0, len(layers))])
+        self.__dict__.pop("_done", None)
+        if out:
+            self.bucket_hook(out)
 
     # ------------------------------------------------------------------ convolutions
     def _amax(self, L):

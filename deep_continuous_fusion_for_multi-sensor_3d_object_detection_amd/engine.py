@@ -500,6 +500,10 @@ class Plan(object):
                     prev = None
                 g = blocks[bi].backward(K, g, extra, need_gx=not first, g_masked=masked, prev=prev)
                 masked = prev is not None
+            if si == 3:
+                # stages 4-5, the FPN and the heads are complete: two thirds of the LiDAR stream's parameters (data-parallel
+                # runs start that bucket's all-reduce here)
+                K.bucket_ready(self.layers, "lidar_hi")
         if c["fused"]:
             # every gradient of the LiDAR stream and of the fusion layers is complete here; only the camera stream is left:
             # the backend may finalise and hand over that bucket now (data-parallel runs all-reduce it under the camera
@@ -556,6 +560,8 @@ class Plan(object):
                 prev = blocks[bi - 1] if bi > 0 else (self.img_stages[li - 1][-1] if li > 0 else None)
                 g = blocks[bi].backward(K, g, extra, need_gx=True, g_masked=masked, prev=prev)
                 masked = prev is not None
+            if li == 3:
+                K.bucket_ready(self.layers, "image_hi")        # camera layer4 + FPN: three quarters of the camera stream's parameters
         # g = gradient at the max-pool output
         gc1 = K.maxpool_bwd(im["c1"], g, None, im.get("pool_idx"))
         gc1 = K.bn_bwd(self.stem, K.relu_mask(gc1, im["c1"]))

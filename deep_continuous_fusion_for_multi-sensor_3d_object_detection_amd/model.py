@@ -376,7 +376,11 @@ class ObjectDetection_DCF(_FlatParamModule):
         from .engine import IMAGE_ARCHS
         if self.fusion_enabled and stream not in IMAGE_ARCHS:
             raise NotImplementedError("image_stream=%r (one of %s)" % (stream, sorted(IMAGE_ARCHS)))
-        self.use_graphs = bool(config.get("hip_graphs", False))
+        # hip_graphs: True / False (default), or "auto" (bench.py's default) = replay captured graphs for batches of ONE frame in a single-rank run -- the
+        # one configuration where the step runs at the host's pace (measured: batch 1 251 frames/s replayed against 200 eager on
+        # the same box, profiles/r04e_*; at batch 2 the step is kernel-bound and eager launches keep the gradient buckets' overlap)
+        hg = config.get("hip_graphs", False)
+        self.use_graphs = "auto" if str(hg).lower() == "auto" else bool(hg)
         self._graphs = None
         self._plan = Plan(config, with_image=self.fusion_enabled, cf=self.cf, image_arch=str(fu.get("image_stream", "resnet18")))
         self._backend = None
@@ -508,7 +512,7 @@ class ObjectDetection_DCF(_FlatParamModule):
             for b in self._nbt:
                 b += 1
         need = torch.is_grad_enabled() and self._param_list[0].requires_grad
-        if self.use_graphs and need and not bn_train and not self._profiling():
+        if self.graphs_wanted(x_lidar.shape[0]) and need and not bn_train and not self._profiling():
             if self._graphs is None:
                 self._graphs = _StepGraphs(self)
             if self._graphs.misses > self._graphs.MAX_MISSES and not self._graphs.disabled:
@@ -520,6 +524,13 @@ class ObjectDetection_DCF(_FlatParamModule):
                 return _RunGraphs.apply(self._param_list[0], self, x_lidar, x_image, geom)
         K.prepare()
         return _RunPlan.apply(self._param_list[0], self, x_lidar, x_image, geom, need)
+
+    def graphs_wanted(self, batch):
+        if self.use_graphs == "auto":
+            import torch.distributed as dist
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            return batch == 1 and not multi
+        return bool(self.use_graphs)
 
     graphs_off = False     # set True to force the eager path (per-kernel event timing cannot see inside a graph)
 

@@ -95,7 +95,14 @@ class Train(nn.Module):
         # factor applied to every rank's gradient INSIDE the RCCL reduction (ncclRedOp PreMulSum) and undone in the Adam step's
         # gradient scale -- e.g. a power of two that lifts small fp16 gradients over the exchange; None = plain sum
         self.allreduce_premul = config.get("allreduce_premul", None)
-        self._pending, self._reduced = [], 0
+        # grad_bucket_dtype: "bf16" exchanges the gradient buckets as bf16 (half the bytes over xGMI: 48 MB instead of 96 MB per
+        # step at cfg2; every rank rounds its own gradient once, the sum of the rounded values is widened back to fp32 for Adam);
+        # "f32" (default) exchanges the fp32 arena itself
+        self.grad_bucket_dtype = str(config.get("grad_bucket_dtype", os.environ.get("DCF_GRAD_BUCKET_DTYPE", "f32"))).lower()
+        if self.grad_bucket_dtype not in ("f32", "fp32", "bf16"):
+            raise ValueError("grad_bucket_dtype must be f32 or bf16 (got %r)" % (self.grad_bucket_dtype,))
+        self._g16 = None
+        self._pending, self._reduced, self._widen = [], 0, []
 
     def sync_replicas(self):
         """Identical replicas: rank 0's parameters, buffers, optimiser moments and step count win (called at construction;
@@ -241,7 +248,23 @@ class Train(nn.Module):
             if b <= a:
                 continue
             seg = g[a:b]
-            if _through_host(seg):
+            if self.grad_bucket_dtype == "bf16":
+                # the bucket goes out in bf16: rounded here (behind the finalisation launch, same stream), summed by the collective,
+                # widened back into the fp32 arena once the collective is done (one_step, before the optimiser step)
+                from . import ops
+                from . import _hip as H
+                if self._g16 is None or self._g16.numel() != g.numel():
+                    self._g16 = torch.empty(g.numel(), dtype=torch.bfloat16, device=g.device)
+                seg16 = self._g16[a:b]
+                H.call("dcf_cast", H.F32, seg, H.BF16, seg16, b - a, H.stream_ptr())
+                self._widen.append((a, b))
+                if _through_host(seg16):
+                    h = seg16.cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                    seg16.copy_(h)
+                else:
+                    self._pending.append(dist.all_reduce(seg16, op=dist.ReduceOp.SUM, async_op=True))
+            elif _through_host(seg):
                 h = seg.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM)
                 seg.copy_(h)
@@ -256,10 +279,10 @@ class Train(nn.Module):
         self.optimizer.zero_grad()
         n = world()
         grouped = dist.is_available() and dist.is_initialized()
-        overlap = ((n > 1 or (self.overlap_force and grouped)) and self.overlap_allreduce and not self.model.use_graphs
+        overlap = ((n > 1 or (self.overlap_force and grouped)) and self.overlap_allreduce and not self.model.graphs_wanted(lidar_voxel.shape[0])
                    and self.model._backend is not None)
         premul = 1.0
-        self._pending, self._reduced = [], 0
+        self._pending, self._reduced, self._widen = [], 0, []
         if overlap:
             self.model._backend.bucket_hook = self._bucket_ready
         try:
@@ -270,7 +293,11 @@ class Train(nn.Module):
         if overlap and self._reduced == self.model.flat_grads.numel():
             for w in self._pending:
                 w.wait()
-            if self.allreduce_premul is not None and not _through_host(self.model.flat_grads):
+            if self._widen:                         # bf16 buckets: the summed values back into the fp32 arena
+                from . import _hip as H
+                for a, b in self._widen:
+                    H.call("dcf_cast", H.BF16, self._g16[a:b], H.F32, self.model.flat_grads[a:b], b - a, H.stream_ptr())
+            elif self.allreduce_premul is not None and not _through_host(self.model.flat_grads):
                 premul = float(self.allreduce_premul)
         else:                                      # single rank, captured graphs, or a backward that skipped the buckets
             for w in self._pending:
@@ -315,6 +342,14 @@ class Train(nn.Module):
             pred_cls, pred_reg, _ = self._predict(lidar_voxel, camera_image, extra)
             self.loss_value = self.loss_total(object_data, num_ref_box, pred_cls, pred_reg)
         return self.loss_value.item(), pred_cls, pred_reg
+
+
+def _eval_barrier():
+    """All ranks meet before and after rank 0's evaluation (train.main): no rank enters a gradient all-reduce while rank 0 is
+    still evaluating.  The device is drained first, so that the barrier is not queued behind this rank's own work."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
 
 
 def init_distributed():
@@ -399,12 +434,20 @@ def main():
             training.one_step_raw(dataset.geometry, batch)
             if batch_ndx % 100 == 0:
                 print("training at ", batch_ndx, "is processed, loss %.4f" % training.loss_value.item())
-            if rank0 and batch_ndx % 500 == 0 and batch_ndx != 0:          # train.py:87-100
-                mean, cum, npos, nt, tp = evaluate(training, tester, test_dataset, test_loader, max_batches=int(config.get("eval_batches", 7)))           # `batch_ndx_ > 5`
-                print("batch %d: validation loss %.4f, positives %d, labelled %d, TP@0.5 %d" % (batch_ndx, mean, npos, nt, tp[0.5]))
+            if batch_ndx % 500 == 0 and batch_ndx != 0:                    # train.py:87-100
+                # Rank 0 evaluates, the others WAIT HERE: without the barriers they would walk into the next step's gradient
+                # all-reduce and sit in it for as long as the evaluation takes (minutes: an RCCL watchdog hazard).  A barrier on
+                # the host (monitored_barrier where the backend has it) has no such timeout coupling to a pending collective.
+                _eval_barrier()
+                if rank0:
+                    mean, cum, npos, nt, tp = evaluate(training, tester, test_dataset, test_loader, max_batches=int(config.get("eval_batches", 7)))           # `batch_ndx_ > 5`
+                    print("batch %d: validation loss %.4f, positives %d, labelled %d, TP@0.5 %d" % (batch_ndx, mean, npos, nt, tp[0.5]))
+                _eval_barrier()
+        _eval_barrier()
         if rank0:                                                          # train.py:105-122
             mean, cum, npos, nt, tp = evaluate(training, tester, test_dataset, test_loader, max_batches=int(config.get("eval_batches_epoch", 12)))   # `batch_ndx > 10`
             print("epoch %d: validation loss %.4f (cumulative %.2f), positives %d, labelled %d, TP %s" % (epoch, mean, cum, npos, nt, dict(tp)))
+        _eval_barrier()
 
 
 if __name__ == "__main__":

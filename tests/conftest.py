@@ -41,6 +41,14 @@ def _start_dp_children(config):
                                              cwd=ROOT)))
     log = open(os.path.join(outdir, "rccl1.log"), "w")
     procs.append(("rccl1", subprocess.Popen([sys.executable, child, "rccl1", "0", _free_port(), outdir], stdout=log, stderr=subprocess.STDOUT, cwd=ROOT)))
+    import torch
+    if torch.cuda.device_count() >= 2:
+        # two REAL devices: the same two ranks as above on GPU 0 and GPU 1, exchanging their gradient buckets through RCCL
+        port3 = _free_port()
+        for rank in range(2):
+            log = open(os.path.join(outdir, "n2_r%d.log" % rank), "w")
+            procs.append(("n2_r%d" % rank, subprocess.Popen([sys.executable, child, "rccl2", str(rank), port3, outdir], stdout=log,
+                                                            stderr=subprocess.STDOUT, cwd=ROOT)))
     # ... and bench.py itself with two ranks on this one GPU (gloo instead of RCCL): the N > 1 code path of the benchmark
     port2 = _free_port()
     for rank in range(2):

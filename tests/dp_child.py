@@ -6,6 +6,9 @@ world 1: one process takes both frames (B = 2).  world 2: rank r takes frame r (
 exchange gradients through gloo (DCF_DIST_BACKEND=gloo) -- functionally what RCCL does on an 8-GPU node, on one GPU.
 Writes the parameter arena after each step to <outdir>/w<world>_r<rank>.pt.
 
+world "rccl2": the same two ranks on devices 0 and 1 with RCCL ("nccl") -- started by conftest.py only where two GPUs are visible;
+writes <outdir>/n2_r<rank>.pt.
+
 world "rccl1": ONE rank in a world-size-1 RCCL ("nccl") process group -- the product's bucketed, overlapped all-reduce
 (Train._bucket_ready: dist.all_reduce(arena slice, async_op=True) from the autograd thread, behind dcf_wgrad_finalize_rows)
 on the real backend with the one GPU a test box has.  Writes <outdir>/rccl1.pt (see run_rccl1).
@@ -49,6 +52,8 @@ def run_rccl1(port, outdir):
       premul   -- the same with allreduce_premul 2 (ncclRedOp PreMulSum inside RCCL, undone by Adam's gradient scale): the
                   collective then CHANGES the buffer, so its stream order against the finalisation launch is observable
                                                                                            -> must equal `plain` BITWISE
+      bf16     -- overlap with grad_bucket_dtype "bf16": the buckets are rounded to bf16, all-reduced as bf16 and widened back
+                                                                                           -> `plain` to bf16 rounding
       wrong    -- premul with the hook called (and the collective drained) BEFORE the finalisation launch (negative control: the
                   all-reduce doubles the stale arena, the finalisation then overwrites it with the undoubled gradient) -> must DIFFER."""
     os.environ.update(dict(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", DCF_FORCE_DIST="1",
@@ -70,6 +75,8 @@ def run_rccl1(port, outdir):
         c["overlap_allreduce"] = False if mode == "plain" else "force"
         if mode in ("premul", "wrong"):
             c["allreduce_premul"] = 2.0
+        if mode == "bf16":
+            c["grad_bucket_dtype"] = "bf16"
         tr = T.Train(c)
         det.fill_state_dict(tr.model)
         calls = []
@@ -77,16 +84,19 @@ def run_rccl1(port, outdir):
         tr._bucket_ready = lambda ranges: (calls.append(list(ranges)), orig(ranges))[1]
         if mode == "wrong":
             def bad_bucket_ready(self, layers, which):
-                if self.bucket_hook is None:
+                if self.bucket_hook is None or which != "lidar+fusion":
                     return
                 i0, f0 = self._layer_split(layers)
                 self._flush_wgrads()
-                self._done = (i0, f0)
-                self.bucket_hook([self._param_ranges(layers, 0, i0), self._param_ranges(layers, f0, len(layers))])   # too early
+                done = self.__dict__.setdefault("_done", [False] * len(layers))
+                todo = [(a, b) for a, b in ((0, i0), (f0, len(layers)))]
+                self.bucket_hook([self._param_ranges(layers, a, b) for a, b in todo])                              # too early
                 torch.cuda.synchronize()      # (the collective has doubled the STALE arena before the launch below overwrites it:
                                               # without this the two race and the control passes or fails by chance)
-                self._finalize(0, i0)
-                self._finalize(f0, len(layers))
+                for a, b in todo:
+                    self._finalize(a, b)
+                    for i in range(a, b):
+                        done[i] = True
             backend = tr.model._ensure_backend(tr.model.flat_params.device)
             backend.bucket_ready = bad_bucket_ready.__get__(backend, HB)
         params, grads = [], []
@@ -100,7 +110,7 @@ def run_rccl1(port, outdir):
             grads.append(tr.model.flat_grads.detach().cpu().clone())
         return {"params": params, "grads": grads, "hook_calls": calls, "numel": tr.model.flat_grads.numel()}
 
-    for mode in ("plain", "overlap", "premul", "wrong"):
+    for mode in ("plain", "overlap", "premul", "wrong", "bf16"):
         try:
             out[mode] = run(mode)
         except Exception as e:                       # e.g. PreMulSum not available in this RCCL build: reported, not hidden
@@ -113,9 +123,10 @@ def run_rccl1(port, outdir):
 def main():
     if sys.argv[1] == "rccl1":
         return run_rccl1(sys.argv[3], sys.argv[4])
-    world, rank, port, outdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
-    os.environ.update(dict(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world),
-                           DCF_DIST_BACKEND="gloo"))
+    two_gpus = sys.argv[1] == "rccl2"          # two ranks on devices 0 and 1, gradients exchanged by RCCL (boxes with >= 2 GPUs)
+    world, rank, port, outdir = (2 if two_gpus else int(sys.argv[1])), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    os.environ.update(dict(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), LOCAL_RANK=str(rank) if two_gpus else "0",
+                           WORLD_SIZE=str(world), DCF_DIST_BACKEND="nccl" if two_gpus else "gloo"))
     import numpy as np
     import torch
     from _util import golden_cfg, load_golden, pkg
@@ -163,7 +174,7 @@ def main():
         outs.append(trainer.model.flat_params.detach().cpu().clone())
         grads.append((trainer.model.flat_grads.detach() / world).cpu().clone())     # what Adam consumed (gscale = 1 / world)
     torch.save({"params": outs, "grads": grads, "loss": float(trainer.loss_value.item()), "lr": cfg["learning_rate"]},
-               os.path.join(outdir, "w%d_r%d.pt" % (world, rank)))
+               os.path.join(outdir, ("n%d_r%d.pt" if two_gpus else "w%d_r%d.pt") % (world, rank)))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -83,8 +83,10 @@ def test_rccl_bucketed_allreduce_world_size_one(request):
     plain, ov = r["plain"], r["overlap"]
     assert "error" not in plain and "error" not in ov, (plain.get("error"), ov.get("error"))
     # the hook really ran per bucket: (LiDAR, fusion) then (camera), together covering the arena
-    assert [len(c) for c in ov["hook_calls"]] == [2, 1] * 3
-    assert sum(b - a for c in ov["hook_calls"][:2] for a, b in c) == ov["numel"]
+    # four buckets per step, in the order the backward completes them: LiDAR stages 4-5 + FPN + heads; the rest of the LiDAR
+    # stream and the fusion layers (two arena ranges); camera layer4 + FPN; the rest of the camera stream
+    assert [len(c) for c in ov["hook_calls"]] == [1, 2, 1, 1] * 3
+    assert sum(b - a for c in ov["hook_calls"][:4] for a, b in c) == ov["numel"]
     assert not plain["hook_calls"]
     lr = 1e-3
 
@@ -107,9 +109,37 @@ def test_rccl_bucketed_allreduce_world_size_one(request):
     close(pm["grads"][0], 2.0 * plain["grads"][0], "PreMulSum reduction, step 0")
     for step in range(3):
         params_close(pm["params"][step], plain["params"][step], step, "PreMulSum path, parameters after step %d" % step)
+    # bf16 buckets: every gradient rounded to bf16 once (one rank: the sum is the rounded value itself)
+    b16 = r["bf16"]
+    assert "error" not in b16, b16.get("error")
+    g, g16 = plain["grads"][0], b16["grads"][0]
+    assert float((g16 - g).abs().max()) <= 2.0 ** -8 * float(g.abs().max()) and float(((g16 - g).abs() > 2.0 ** -8 * g.abs() + 1e-4 * float(g.abs().max())).float().mean()) == 0.0
+    assert torch.equal(g16, g16.bfloat16().float()), "the arena does not hold bf16 values"
+    for step in range(3):
+        assert float((b16["params"][step] - plain["params"][step]).abs().max()) <= 2.5 * lr * (step + 1)
     assert "error" not in wrong, wrong.get("error")
     (a0, b0), _ = wrong["hook_calls"][0]            # LiDAR-stream range of the arena
     got, want = wrong["grads"][0][a0:b0], 2.0 * plain["grads"][0][a0:b0]
     assert float((got - want).abs().max()) > 0.25 * float(want.abs().max()), \
         "negative control: an all-reduce started before the finalisation launch went unnoticed"
     # (what it holds instead is a race between the collective and the launch: the undoubled gradient, or twice the stale arena)
+
+
+def test_two_devices_rccl_equal_one_rank_with_twice_the_batch(request):
+    """Where the box has TWO GPUs: rank r on device r, gradient buckets exchanged by RCCL over xGMI while the backward runs
+    (the product's launch mode, /root/reference/train.py:24,51-56 replaced by one process per GPU); 2 x (B = 1) must equal
+    1 x (B = 2).  Skipped on a one-GPU box (conftest.py starts the children only when two devices are visible)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the two-device RCCL exchange needs two")
+    outdir = _wait(request, "n2_r")
+    _wait(request, "w1_r0")
+    one = torch.load(os.path.join(outdir, "w1_r0.pt"))
+    r0 = torch.load(os.path.join(outdir, "n2_r0.pt"))
+    r1 = torch.load(os.path.join(outdir, "n2_r1.pt"))
+    a, b, c = one["grads"][0], r0["grads"][0], r1["grads"][0]
+    assert torch.equal(b, c), "the ranks hold different reduced gradients"
+    assert float((a - b).abs().max()) < 1e-4 * float(a.abs().max())
+    lr = one["lr"]
+    for step in range(2):
+        assert torch.equal(r0["params"][step], r1["params"][step]), "replicas diverged at step %d" % step
+        assert float((one["params"][step] - r0["params"][step]).abs().max()) <= 2.5 * lr * (step + 1)
