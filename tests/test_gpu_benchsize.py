@@ -300,3 +300,103 @@ def test_cfg4_full_size_f16_step_matches_fp32_path():
     assert any("image_backbone.layer4" in e[2] for e in errs) and any("fusion.site4" in e[2] for e in errs)
     assert errs[0][0] < 0.08, "gradient of %s: relative L2 error %g" % (errs[0][2], errs[0][0])
     assert max(e[1] for e in errs) < 0.15, "gradient of %s: rel err %g" % (max(errs, key=lambda e: e[1])[2], max(e[1] for e in errs))
+
+
+def _cfg5_config(dtype):
+    cfg = _cfg2_config(dtype, batch=1, n_points=300000, K=3, stream="resnet18")
+    cfg.update(dict(image_height=1080, image_width=1920))
+    return cfg
+
+
+def test_cfg5_full_size_bf16_and_fp8_step_matches_fp32_path():
+    """BASELINE configs[4] at FULL size: 300 k points, 1920x1080 image, four fusion sites, batch 1 -- one forward + backward of
+    the bf16 path and of the fp8 path (e4m3 forward convolutions on the Cin >= 128 launches of >= 512 tiles, the selection the
+    benchmark makes) against the fp32 HIP path on the same frame and weights.  The camera stream's largest maps (540x960x64
+    stem, 270x480 stride 4, the 135x240x128 layer) are hit at their real sizes, with the launch shapes of the benchmark.
+    bf16 bounds as the cfg2-size 16-bit test; fp8: two steps (the activation scales are those of the step before), the
+    prediction within e4m3 noise of the bf16 one, the straight-through gradients aligned with the bf16 path's."""
+    det, calib, D, T = pkg("detfill"), pkg("calib"), pkg("data_import_carla"), pkg("train")
+    lim6 = (0.0, 70.4, -40.0, 40.0, -2.4, 0.8)
+    crt = calib.hd_crt()
+    pts = [torch.from_numpy(det.synthetic_points(300000, lim6, 91)).cuda()]
+    img = torch.from_numpy(det.synthetic_image(1080, 1920, 91)).unsqueeze(0).cuda()
+    res, R = {}, None
+    for dt in ("f32", "bf16", "fp8"):
+        cfg = _cfg5_config(dt)
+        tr = T.Train(cfg)
+        det.fill_state_dict(tr.model)
+        geo = D.FrameGeometry(cfg, crt)
+        preds = []
+        for step in range(2 if dt == "fp8" else 1):
+            tr.model.flat_grads.zero_()
+            x_lidar, geom = tr.geometry_async(geo, pts)
+            pred = tr.model(x_lidar, img, geom=geom)
+            if R is None:
+                R = torch.from_numpy(det.uniform(tuple(pred.shape), 99, -1.0, 1.0)).cuda()
+                R[:, 18:] = 0
+            (pred * R).sum().backward()
+            torch.cuda.synchronize()
+            preds.append(pred.detach().float().cpu())
+        if dt == "fp8":
+            K = tr.model._backend
+            used = [L for L in K.plan.layers if L.w8_off >= 0 and float(K._amax(L)[1].item()) > 0]
+            assert K.has_fp8 and len(used) >= 8, "fp8 launches at cfg5: %d" % len(used)
+        res[dt] = (preds, tr.model.flat_grads.cpu().clone(), tr.model._plan.table.entries)
+        del tr
+        torch.cuda.empty_cache()
+    (p32,), g32, entries = res["f32"]
+    (p16,), g16, _ = res["bf16"]
+    p8s, g8, _ = res["fp8"]
+    assert p16.shape == (1, 32, 176, 200)
+    for name, sl in (("cls", slice(0, 4)), ("reg", slice(4, 18))):
+        a, b = p16[:, sl], p32[:, sl]
+        assert float((a - b).abs().max() / b.abs().max()) < 3e-2, name
+        assert float((a - b).norm() / b.norm()) < 2e-2, name
+    assert torch.isfinite(g16).all() and float((g16 - g32).norm() / g32.norm()) < 0.1
+    errs = []
+    for (key, shape, off, n, layout) in entries:
+        if n < 4096 or float(g32[off:off + n].abs().max()) < 1e-12:
+            continue
+        a, b = g16[off:off + n], g32[off:off + n]
+        errs.append((float((a - b).norm() / (b.norm() + 1e-20)), key))
+    errs.sort(reverse=True)
+    print("cfg5 full size, bf16 vs fp32, worst per-tensor relative L2:", errs[:5])
+    assert any("image_backbone.layer1" in e[1] for e in errs) and any("fusion.site1" in e[1] for e in errs)
+    assert errs[0][0] < 0.25, "gradient of %s: relative L2 error %g" % (errs[0][1], errs[0][0])
+    # fp8 forward: both steps finite and within e4m3 noise of the bf16 prediction; gradients (bf16 straight-through) aligned
+    for p8 in p8s:
+        assert torch.isfinite(p8).all()
+        assert float((p8[:, :18] - p16[:, :18]).norm() / p16[:, :18].norm()) < 0.08
+    assert not torch.equal(p8s[1], p16)
+    assert torch.isfinite(g8).all()
+    cos = float((g8 * g16).sum() / (g8.norm() * g16.norm()))
+    assert cos > 0.9, cos
+
+
+def test_cfg4_full_size_frame_matches_cpu_statement():
+    """The cfg4 full-size test above compares the f16 path with the fp32 HIP path; a bug shared by both would pass it.  Here ONE
+    frame of that configuration (120 k points, ResNet-50 camera stream, K = 5) goes through the fp32 HIP forward and through the
+    CPU statement (oracle/model_ref.py with its own brute-force KNN): class scores and box offsets to 1e-3 of their maximum."""
+    det, calib, D = pkg("detfill"), pkg("calib"), pkg("data_import_carla")
+    cfg = _cfg2_config("f32", batch=1, n_points=120000, K=5, stream="resnet50")
+    crt = calib.kitti_like_crt()
+    pts = det.synthetic_points(120000, (0.0, 70.4, -40.0, 40.0, -2.4, 0.8), 72)
+    img = torch.from_numpy(det.synthetic_image(375, 1242, 72)).unsqueeze(0)
+    net = pkg("model").ObjectDetection_DCF(cfg)
+    det.fill_state_dict(net)
+    net = net.cuda()
+    geo = D.FrameGeometry(cfg, crt)
+    vox, pc, uv, cnt, _ = geo(torch.from_numpy(pts))
+    with torch.no_grad():
+        got = net(vox.unsqueeze(0), img.cuda(), points=pc.unsqueeze(0), uv=uv.unsqueeze(0), n_valid=cnt).float().cpu()
+    grid, pc_ref, uv_ref, n_ref, _ = geometry_ref.voxelization_projection(pts, cfg, crt, proj_mode="correct")
+    shapes = {}
+    shapes.update(model_ref.lidar_state_shapes(cfg)); shapes.update(model_ref.image_state_shapes(64, arch="resnet50")); shapes.update(model_ref.fusion_state_shapes(cfg, 64))
+    sd = model_ref.make_state_dict(shapes)
+    gc = geometry_ref.grid_constants(cfg)
+    with torch.no_grad():
+        ref = model_ref.forward(sd, cfg, torch.from_numpy(grid).unsqueeze(0), img, torch.from_numpy(pc_ref).unsqueeze(0),
+                                torch.from_numpy(uv_ref).unsqueeze(0), [n_ref], "eval", fusion={"K": 5, "aff": gc["aff"], "rmax": None})
+    for name, sl in (("cls", slice(0, 4)), ("reg", slice(4, 18))):
+        a, b = got[:, sl], ref[:, sl]
+        assert float((a - b).abs().max() / b.abs().max()) < 1e-3, "%s: %g" % (name, float((a - b).abs().max() / b.abs().max()))
