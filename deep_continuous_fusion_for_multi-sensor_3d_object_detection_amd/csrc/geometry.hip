@@ -551,55 +551,100 @@ __global__ void __launch_bounds__(256) k_knn_fill_ms(const float *xyz, const int
     sorted[pos] = make_float4(xyz[3 * i], xyz[3 * i + 1], __int_as_float(i), 0.f);
 }
 
+// K best (d2, index) pairs in ascending lexicographic order.  Round 4: insertion is a branch-free compare-exchange chain on
+// 64-bit keys (bits of d2 above the index: for the non-negative d2 of a distance the unsigned order of the bits IS the float
+// order, so the key order is the (d2, index) order of rounds 1-3; a NaN or infinite d2 sorts behind the empty slot's 3.0e38 and is
+// never kept, as before).  The branchy version cost ~540 cycles per candidate in k_knn_search (tools/knn_stamps.py): exec-mask
+// juggling through scalar registers on a wave that is alone on its SIMD.
 template <int K>
 struct TopK {
     float d[K];
     int id[K];
-    int cnt;
     __device__ __forceinline__ void clear()
     {
-        cnt = 0;
 #pragma unroll
         for (int q = 0; q < K; ++q) { d[q] = 3.0e38f; id[q] = 0x7fffffff; }
     }
     __device__ __forceinline__ float kth() const { return d[K - 1]; }
-    __device__ __forceinline__ bool full() const { return cnt >= K; }
-    // insert keeping ascending (d2, index); fully unrolled bubble from the tail
+    __device__ __forceinline__ bool full() const { return id[K - 1] != 0x7fffffff; }
+    __device__ __forceinline__ int count() const
+    {
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < K; ++q) c += id[q] != 0x7fffffff;
+        return c;
+    }
+    static __device__ __forceinline__ unsigned long long key(float dd, int ii)
+    {
+        return ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)ii;
+    }
     __device__ __forceinline__ void insert(float dd, int ii)
     {
-        if (!(dd < d[K - 1] || (dd == d[K - 1] && ii < id[K - 1]))) return;
-        d[K - 1] = dd;
-        id[K - 1] = ii;
+        unsigned long long x = key(dd, ii);
 #pragma unroll
-        for (int q = K - 1; q > 0; --q) {
-            const bool sw = (d[q] < d[q - 1]) || (d[q] == d[q - 1] && id[q] < id[q - 1]);
-            if (sw) {
-                float td = d[q]; d[q] = d[q - 1]; d[q - 1] = td;
-                int ti = id[q]; id[q] = id[q - 1]; id[q - 1] = ti;
-            }
+        for (int q = 0; q < K; ++q) {
+            const unsigned long long kq = key(d[q], id[q]);
+            const bool lt = x < kq;
+            const unsigned long long lo = lt ? x : kq;
+            x = lt ? kq : x;
+            d[q] = __uint_as_float((unsigned)(lo >> 32));
+            id[q] = (int)(unsigned)lo;
         }
-        if (cnt < K) ++cnt;
+    }
+    // a key of another list that may already be in this one (merging lists that share earlier merges): a second copy is dropped
+    __device__ __forceinline__ void insert_unique(unsigned long long x)
+    {
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const unsigned long long kq = key(d[q], id[q]);
+            if (x == kq) x = ~0ull;
+            const bool lt = x < kq;
+            const unsigned long long lo = lt ? x : kq;
+            x = lt ? kq : x;
+            d[q] = __uint_as_float((unsigned)(lo >> 32));
+            id[q] = (int)(unsigned)lo;
+        }
     }
 };
 
-// One wave per 8x8 tile of BEV pixels (= one coarse block of the cell grid): all 64 lanes walk the
-// SAME cells / coarse rings, so control flow is wave-uniform and every candidate point is one scalar
-// (broadcast) load; only the K-best insertion is per lane.
+// Per-tile counters of k_knn_search (tools/knn_stamps.py; -DKNN_STAMP builds only): cycles and candidate points of the window
+// phase and of the ring phase, rings walked, blocks scanned -- which tiles the launch waits for, and why.
+#ifdef KNN_STAMP
+#define KNN_STAMP_TILES 4096
+__device__ long long g_knn_stamps[KNN_STAMP_TILES][16];
+#define KNN_ST(k, v) do { if (blockIdx.y == 0 && tile < KNN_STAMP_TILES && lane == 0 && wv == 0) g_knn_stamps[tile][k] = (v); } while (0)
+#define KNN_CNT(var, n) (var) += (n)
+#define KNN_T(k) KNN_ST(k, __builtin_amdgcn_s_memtime() - st_t0)
+#else
+#define KNN_ST(k, v) do { } while (0)
+#define KNN_CNT(var, n) do { } while (0)
+#define KNN_T(k) do { } while (0)
+#endif
+
+// One workgroup per 8x8 tile of BEV pixels (= one coarse block of the cell grid), lane = pixel: all lanes walk the SAME cells /
+// coarse rings, so control flow is uniform and every candidate point is a register broadcast; only the K-best insertion is per lane.
 //   phase A: the 12x12 cell window around the tile (every lane's fine rings 0..2 are inside it)
 //   phase B: coarse block rings around the tile for lanes whose neighbourhood is sparse
 // A lane stops as soon as every unvisited point is provably farther than its K-th candidate.
-template <int K>
-__global__ void __launch_bounds__(256) k_knn_search(const int *count, int n_max, KnnGrid g, const int *cellstart,
-                                                    const float4 *sorted, float rmax2, int *out)
+// Round 4: FOUR waves per tile (one wave per tile before).  A tile's time is one serial chain -- candidate after candidate through
+// the lanes' K-best lists, ~30 dependent instructions each -- and the launch waits for its longest chain with one or two waves on
+// every SIMD (tools/knn_stamps.py).  The four waves walk the same cells and rings and each takes every fourth candidate; their
+// lists are merged through LDS where a decision needs the pixel's true K-th (end of the window phase, end of a ring, after a
+// block of more than KNN_MERGE_POINTS points), after which all four hold the same list and decide alike.
+constexpr int KNN_MERGE_POINTS = 256;
+template <int K, int NW>
+__global__ void __launch_bounds__(64 * NW) k_knn_search(const int *count, int n_max, KnnGrid g, const int *cellstart,
+                                                       const float4 *sorted, float rmax2, int *out)
 {
     count += blockIdx.y * g.fs_cnt; cellstart += (size_t)blockIdx.y * g.fs_ws; out += (size_t)blockIdx.y * g.fs_out;
     sorted = reinterpret_cast<const float4 *>(reinterpret_cast<const int *>(sorted) + (size_t)blockIdx.y * g.fs_ws);
     const int lane = threadIdx.x & 63;
-    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (tile >= g.h8 * g.w8) return;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x;
     const int TI = tile / g.w8, TJ = tile - TI * g.w8;
     const int i = TI * 8 + (lane >> 3), j = TJ * 8 + (lane & 7);
     const bool inside = (i < g.h) && (j < g.w);
+    __shared__ unsigned long long s_keys[NW][K][64];
     const float s = (float)g.stride;
     const float X = __fdiv_rn(__fsub_rn(__fmul_rn((float)i + 0.5f, s), g.xo), g.xs);
     const float Y = __fdiv_rn(__fsub_rn(__fmul_rn((float)j + 0.5f, s), g.yo), g.ys);
@@ -610,27 +655,56 @@ __global__ void __launch_bounds__(256) k_knn_search(const int *count, int n_max,
     TopK<K> top;
     top.clear();
     bool done = !inside;
+#ifdef KNN_STAMP
+    long long st_pts = 0, st_rings = 0, st_blocks = 0;
+    const long long st_t0 = __builtin_amdgcn_s_memtime();
+#endif
 
     // candidates reach the lanes as register broadcasts: the wave loads up to 64 points with ONE vector load and then
     // hands them round with v_readlane (a dependent scalar load per point leaves the wave waiting on memory per point)
+    // (four candidates per trip: their distance arithmetic is independent, only the compare-exchange chains are serial; lanes
+    // beyond n hold NaN coordinates, which no test accepts)
+    const float d2lim = rmax2 >= 0.0f ? rmax2 : __int_as_float(0x7f800000);
+    const float4 nopoint = make_float4(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000), 0.f, 0.f);
     auto offer = [&](const float4 &mine, int n, bool take) {
-        for (int u = 0; u < n; ++u) {
-            const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), u));
-            const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), u));
-            const int qi = __builtin_amdgcn_readlane(__float_as_int(mine.z), u);
-            const float dx = __fsub_rn(qx, X), dy = __fsub_rn(qy, Y);
-            const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
-            if (take && !(rmax2 >= 0.0f && d2 > rmax2)) top.insert(d2, qi);
+        const float lim = take ? d2lim : -1.0f;                 // a lane that does not take accepts no distance
+        for (int u0 = wv; u0 < n; u0 += 4 * NW) {               // this wave's candidates: wv, wv + NW, wv + 2 NW, ... (< 64)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int u = u0 + NW * v;
+                const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), u));
+                const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), u));
+                const int qi = __builtin_amdgcn_readlane(__float_as_int(mine.z), u);
+                const float dx = __fsub_rn(qx, X), dy = __fsub_rn(qy, Y);
+                const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+                top.insert(d2 <= lim ? d2 : __int_as_float(0x7f800000), qi);
+            }
+        }
+    };
+    // the four waves' lists of every pixel merged into each of them (uniform: every wave of the tile comes here together)
+    auto merge = [&]() {
+        if constexpr (NW > 1) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) s_keys[wv][q][lane] = TopK<K>::key(top.d[q], top.id[q]);
+            __syncthreads();
+#pragma unroll
+            for (int o = 1; o < NW; ++o) {
+#pragma unroll
+                for (int q = 0; q < K; ++q) top.insert_unique(s_keys[(wv + o) % NW][q][lane]);
+            }
+            __syncthreads();
         }
     };
     auto scan_range = [&](int b, int e, bool take) {
+        KNN_CNT(st_pts, e - b);
         for (int p0 = b; p0 < e; p0 += 64) {
             const int n = min(64, e - p0);
-            const float4 mine = lane < n ? sorted[p0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 mine = lane < n ? sorted[p0 + lane] : nopoint;
             offer(mine, n, take);
         }
     };
 
+    KNN_T(8);                                                  // the frame's point count has arrived
     if (n > 0) {
         // ---- phase A: rows 8TI-2 .. 8TI+9, three column segments (one per coarse block column)
         const int H8 = g.h8 * 8, W8 = g.w8 * 8;
@@ -650,6 +724,10 @@ __global__ void __launch_bounds__(256) k_knn_search(const int *count, int n_max,
             // start_r <= t < start_r + len_r -- so the whole window arrives with one vector load per 64 points
             const int len = pe - ps;
             int inc = len;
+#ifdef KNN_STAMP
+            if (__any(len > 1 << 30)) return;
+            KNN_T(9);                                           // the window's cell ranges have arrived
+#endif
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const int v = __shfl_up(inc, o, 64);
@@ -657,6 +735,7 @@ __global__ void __launch_bounds__(256) k_knn_search(const int *count, int n_max,
             }
             const int total = __builtin_amdgcn_readlane(inc, 63);
             const int exc = inc - len;
+            KNN_ST(2, (long long)total);
             for (int base = 0; base < total; base += 64) {
                 const int t = base + lane;
                 int src = 0;
@@ -667,15 +746,27 @@ __global__ void __launch_bounds__(256) k_knn_search(const int *count, int n_max,
                     if (t >= s_r && t < s_r + l_r) src = p_r + (t - s_r);
                 }
                 const int n = min(64, total - base);
-                const float4 mine = lane < n ? sorted[src] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 mine = lane < n ? sorted[src] : nopoint;
+#ifdef KNN_STAMP
+                if (base == 0) {
+                    KNN_T(10);                                  // gather addresses computed
+                    if (__any(mine.z == 123456.f)) return;
+                    KNN_T(11);                                  // first 64 points have arrived
+                }
+#endif
                 offer(mine, n, !done);
             }
         }
+        merge();
         {
             const float bound = 2.5f * cwmin - 1e-3f;         // every unvisited point is >= 2.5 cells away
             if (!done && top.full() && top.kth() < bound * bound) done = true;
             if (rmax2 >= 0.0f && bound > 0.f && bound * bound > rmax2) done = true;
         }
+        KNN_ST(0, __builtin_amdgcn_s_memtime() - st_t0);
+#ifdef KNN_STAMP
+        { const long long left = __popcll(__ballot(!done)); KNN_ST(6, left); }
+#endif
         // ---- phase B: coarse rings (lanes still searching restart; order of visits does not matter)
         if (!__all(done)) {
             if (!done) top.clear();
@@ -715,9 +806,12 @@ __global__ void __launch_bounds__(256) k_knn_search(const int *count, int n_max,
                             const float ddy = fmaxf(0.f, fmaxf(loy - Y, Y - hiy) - 1e-3f);
                             visit = (ddx * ddx + ddy * ddy) <= top.kth();
                         }
-                        if (__any(visit)) scan_range(cps, cpe, visit);
+                        if (__any(visit)) { KNN_CNT(st_blocks, 1); scan_range(cps, cpe, visit); }
+                        if (cpe - cps > KNN_MERGE_POINTS) merge();      // (the next blocks are pruned with the true K-th)
                     }
                 }
+                merge();
+                KNN_CNT(st_rings, 1);
                 const float bound = (8.0f * (float)R + 0.5f) * cwmin - 1e-3f;
                 if (!done && top.full() && top.kth() < bound * bound) done = true;
                 if (rmax2 >= 0.0f && bound > 0.f && bound * bound > rmax2) done = true;
@@ -725,10 +819,14 @@ __global__ void __launch_bounds__(256) k_knn_search(const int *count, int n_max,
             }
         }
     }
+#ifdef KNN_STAMP
+    KNN_ST(1, __builtin_amdgcn_s_memtime() - st_t0);
+    KNN_ST(3, st_pts); KNN_ST(4, st_rings); KNN_ST(5, st_blocks);
+#endif
     if (inside) {
         const int hw = g.h * g.w, pix = i * g.w + j;
 #pragma unroll
-        for (int q = 0; q < K; ++q) out[q * hw + pix] = (q < top.cnt) ? top.id[q] : -1;
+        for (int q = 0; q < K; ++q) out[q * hw + pix] = top.id[q] != 0x7fffffff ? top.id[q] : -1;
     }
 }
 
@@ -1326,12 +1424,15 @@ static int knn_bev_impl(const char *who, const float *xyz, const int32_t *count_
             DCF_LAUNCH_B("knn_fill", fB * n_max * (12.0 + 4.0 + 16.0), s, hipLaunchKernelGGL(k_knn_fill, dim3(nb, B), dim3(256), 0, s, xyz, count_dev, n_max, pkey, cursor, sorted, g.fs_xyz, g.fs_cnt, g.fs_ws));
         }
     }
-    const int nbp = cdiv(g.h8 * g.w8, 4);   // one wave per 8x8 pixel tile
+    const int nbp = g.h8 * g.w8;            // one workgroup (four waves) per 8x8 pixel tile
     // coarse sites: one wave per pixel (lanes split the candidates).  DCF_KNN_KERNEL = wave | tile forces one of the two
     // kernels (dcf_set_option: the parity tests compare them on the same site; both produce the exact (d2, index) order)
     static DcfOpt force_o("KNN_KERNEL"); const char *force = force_o.str();
     const bool per_wave = force && force[0] == 'w' ? true : (force && force[0] == 't' ? false : (h * w <= 20000));
     const int nbw = cdiv(h * w, 4);
+    // waves per tile of k_knn_search (option KNN_TILE_WAVES = 1 | 2 | 4 forces)
+    static DcfOpt tw_o("KNN_TILE_WAVES"); const char *tw = tw_o.str();
+    const int tile_waves = tw && (tw[0] == '1' || tw[0] == '2' || tw[0] == '4') ? tw[0] - '0' : (nbp * B <= 1500 ? 4 : 1);
     if (fine) {
         // dense pixels on the fine site's cells, the rest on this site's own blocks (k_knn_search_fine)
         KnnGrid gf = g;
@@ -1363,8 +1464,14 @@ static int knn_bev_impl(const char *who, const float *xyz, const int32_t *count_
         if (per_wave)                                                                                                    \
             DCF_LAUNCH_B("knn_search_wave", fB * ((double)h * w * K * 4.0 + (double)n_max * 16.0), s, hipLaunchKernelGGL(k_knn_search_wave<KK>, dim3(nbw, B), dim3(256), 0, s, count_dev, n_max, g, \
                                                                 cellstart, sorted, rmax2, idx_out));                     \
+        else if (tile_waves == 4)                                                                                        \
+            DCF_LAUNCH_B("knn_search", fB * ((double)h * w * K * 4.0 + (double)n_max * 16.0), s, hipLaunchKernelGGL((k_knn_search<KK, 4>), dim3(nbp, B), dim3(256), 0, s, count_dev, n_max, g, \
+                                                           cellstart, sorted, rmax2, idx_out));                          \
+        else if (tile_waves == 2)                                                                                        \
+            DCF_LAUNCH_B("knn_search", fB * ((double)h * w * K * 4.0 + (double)n_max * 16.0), s, hipLaunchKernelGGL((k_knn_search<KK, 2>), dim3(nbp, B), dim3(128), 0, s, count_dev, n_max, g, \
+                                                           cellstart, sorted, rmax2, idx_out));                          \
         else                                                                                                             \
-            DCF_LAUNCH_B("knn_search", fB * ((double)h * w * K * 4.0 + (double)n_max * 16.0), s, hipLaunchKernelGGL(k_knn_search<KK>, dim3(nbp, B), dim3(256), 0, s, count_dev, n_max, g, \
+            DCF_LAUNCH_B("knn_search", fB * ((double)h * w * K * 4.0 + (double)n_max * 16.0), s, hipLaunchKernelGGL((k_knn_search<KK, 1>), dim3(nbp, B), dim3(64), 0, s, count_dev, n_max, g, \
                                                            cellstart, sorted, rmax2, idx_out));                          \
         break;
     switch (K) {
@@ -1504,3 +1611,12 @@ extern "C" int dcf_fusion_invert(const dcf_knn_map *maps, int nmaps, int K, int 
     DCF_LAUNCH_B("inv_fill", (double)total * 12.0, s, hipLaunchKernelGGL(k_inv_fill, dim3(cdiv(total, 256)), dim3(256), 0, s, m, n_max, cursor, ent_pix, ent_pt));
     return DCF_OK;
 }
+
+#ifdef KNN_STAMP
+extern "C" int dcf_knn_stamps_read(long long *dst, int *dims)
+{
+    dims[0] = KNN_STAMP_TILES; dims[1] = 16;
+    DCF_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_knn_stamps), sizeof(long long) * KNN_STAMP_TILES * 16));
+    return DCF_OK;
+}
+#endif

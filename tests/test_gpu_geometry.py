@@ -368,6 +368,39 @@ def test_knn_tile_kernel_far_cluster_full_site(where):
     assert np.array_equal(got, geometry_ref.knn_bev(xyz, K, h, w, stride, g.aff, rmax=30.0))
 
 
+@pytest.mark.parametrize("cloud", ["cfg2", "far_corner", "two_clusters", "one_point"])
+def test_knn_tile_kernel_waves_per_tile_change_nothing(cloud):
+    """Round 4: k_knn_search runs a tile with one, two or four waves that share the candidates (every wave takes every NW-th
+    point of the same cells and rings) and merge their K-best lists through LDS where the pixel's true K-th decides something;
+    the lists hold 64-bit (d2 bits, index) keys and insertion is a branch-free compare-exchange chain.  Whole-site, bit-for-bit
+    equality of the three with each other and with the per-pixel wave kernel, K = 1 .. 8, with and without radius cuts."""
+    ops, H = pkg("ops"), pkg("_hip")
+    g, xyz = _cfg2_cloud(seed=21)
+    if cloud != "cfg2":
+        base = {"far_corner": [(69.7, 39.2)], "two_clusters": [(69.9, -39.9), (35.0, 3.0)], "one_point": [(12.3, -20.1)]}[cloud]
+        rows = [[cx + 0.013 * t, cy - 0.007 * t, -1.0 + 0.1 * t] for cx, cy in base for t in range(1 if cloud == "one_point" else 7)]
+        xyz = np.asarray(rows, dtype=np.float32)
+    n = xyz.shape[0]
+    d = torch.from_numpy(xyz).cuda()
+    cnt = torch.tensor([n], dtype=torch.int32, device="cuda")
+    try:
+        for rmax in (None, 30.0, 1.5):
+            for stride, K in ((2, 3), (4, 5), (4, 1), (4, 8), (8, 2)):
+                h, w = 704 // stride, 800 // stride
+                H.set_option("KNN_KERNEL", "wave")
+                ref = ops.knn_bev(d, cnt, K, h, w, stride, g.aff, rmax)
+                H.set_option("KNN_KERNEL", "tile")
+                for tw in ("1", "2", "4", None):
+                    H.set_option("KNN_TILE_WAVES", tw)
+                    got = ops.knn_bev(d, cnt, K, h, w, stride, g.aff, rmax)
+                    assert torch.equal(got, ref), (rmax, stride, K, tw)
+            if rmax == 1.5:
+                assert int((ref < 0).sum()) > 0
+    finally:
+        H.set_option("KNN_TILE_WAVES", None)
+        H.set_option("KNN_KERNEL", None)
+
+
 @pytest.mark.parametrize("stride,K", [(2, 3), (8, 5), (16, 3)])
 def test_knn_batch_equals_per_frame(stride, K):
     """dcf_knn_bev_batch (every phase once for the batch, grid.y = frame) == dcf_knn_bev frame by frame, bit for bit: frames with

@@ -43,3 +43,30 @@ for si in range(1, 5):
     torch.cuda.synchronize(); H.call("dcf_prof_enable", 0)
     pr = H.prof_read()
     print("site stride %2d (%dx%d):" % (s, h, w), {k: round(v[0] / v[1] * 1e3, 1) for k, v in pr.items()})
+
+# the engine's call: both frames of a cfg2 batch, the four sites in one dcf_knn_bev_sites call; waves per tile of k_knn_search 1 / 2 / 4 / automatic
+B = 2
+fr = [geo(pool.pts[b]) for b in range(B)]
+n_max = max(f[1].shape[0] for f in fr)
+pts = torch.zeros((B, n_max, 3), device="cuda")
+for b, f in enumerate(fr):
+    pts[b, :f[1].shape[0]] = f[1]
+cnts = torch.cat([f[3].reshape(1) for f in fr]).to(torch.int32)
+sites = []
+for si in range(1, 5):
+    s = 2 ** si
+    h, w = 704 // s, 800 // s
+    sites.append((h, w, s, 0 if h * w <= 20000 else -1, torch.empty((B, ops.knn_ws_stride(n_max, h, w)), dtype=torch.uint8, device="cuda"),
+                  torch.empty((B, 3, h, w), dtype=torch.int32, device="cuda")))
+for tw in ("1", "2", "4", None):
+    H.set_option("KNN_TILE_WAVES", tw)
+    ops.knn_bev_sites(pts, cnts, 3, sites, g.aff, None)
+    H.call("dcf_prof_reset"); H.call("dcf_prof_enable", 1)
+    for _ in range(5):
+        ops.knn_bev_sites(pts, cnts, 3, sites, g.aff, None)
+    torch.cuda.synchronize(); H.call("dcf_prof_enable", 0)
+    pr = H.prof_read()
+    print("sites call, B=2, waves per tile %s: total %.1f us;" % (tw or "auto", sum(v[0] for v in pr.values()) / 5 * 1e3),
+          {k: (round(v[0] / v[1] * 1e3, 1), v[1] // 5) for k, v in pr.items()})
+    print("   whole call on the GPU timeline: %.1f us" % timeit(lambda: ops.knn_bev_sites(pts, cnts, 3, sites, g.aff, None)))
+H.set_option("KNN_TILE_WAVES", None)
