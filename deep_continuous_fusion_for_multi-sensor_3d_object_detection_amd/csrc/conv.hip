@@ -863,170 +863,6 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgArgs a)
 }
 
 // ------------------------------------------------------------------------------------
-// Nine-tap weight gradient with the gy tile shared by the taps (round 4): the 3x3 layers that wgrad_body serves (stride 2).
-// wgrad_body gives every (channel tile, TAP) its own workgroup, so a pixel range's gy rows are fetched nine times and the loop
-// stages 1 KB per MFMA: the grouped launch ran at its L2 -> LDS traffic (1.04 GB against 0.55 algorithmic, section 6).  Here a
-// workgroup is NINE waves, wave = tap: a stage's 32 gy rows go to LDS once (double-buffered, one barrier per stage) and every
-// wave stages only its own tap's x rows (wave-private, as before) -- 0.55 KB per MFMA, gy from L2 once.  A wave keeps its tap's
-// 64 x 64 (or 64 x 32) tile for the whole pixel range of the slab, so the cross-wave reduction of wgrad_body disappears.  Same
-// slab layout, same nsplit, same per-split gsum rows (the slab's sum in its first row, zeros in the other three).
-// ------------------------------------------------------------------------------------
-template <typename T, int TM, int TN>
-__device__ __forceinline__ void wgrad_t9_body(const WgArgs &a, const int bid)
-{
-    constexpr int ES = DT<T>::size;
-    static_assert(ES == 2, "16-bit operands only");
-    constexpr int PK = 32;
-    constexpr int RA = TM * 32 * ES, RB = TN * 32 * ES;
-    constexpr int PA = RA == 64 ? 64 : 192, PB = RB == 64 ? 64 : 192;       // (bank spread of the transposed reads, as wgrad_body)
-    constexpr int NT = 9;
-    __shared__ __attribute__((aligned(16))) char lds_all[2 * PK * PA + NT * PK * PB];
-    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char *ldsB = lds_all + 2 * PK * PA + wid * PK * PB;
-
-    const int ninner = a.co_tiles * a.ci_tiles;
-    const int L = bid;
-    const bool xcd = ((a.nsplit & 7) == 0) && (a.nsplit >= 48);
-    const int slab_id = xcd ? (L / (8 * ninner)) * 8 + (L & 7) : L / ninner;
-    if (slab_id >= a.nsplit) return;
-    const int t = xcd ? (L >> 3) % ninner : L % ninner;
-    const int cit = t % a.ci_tiles, cot = t / a.ci_tiles;
-    const int co0 = cot * TM * 32, ci0 = cit * TN * 32;
-    const int tap = wid, ki = tap / 3, kj = tap - ki * 3;
-    const int p_begin = slab_id * 4 * a.per_split;
-    const int p_end = min(p_begin + 4 * a.per_split, a.M);
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-    const bool do_sum = (a.gsum != nullptr) && (tap == 0) && (cit == 0);
-    float fsum[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) fsum[i] = 0.f;
-
-    constexpr int CA = RA / 16, CB = RB / 16, NLB = CB / 2;
-    const int rowA = a.Cout * ES;
-    const int coutA = min(TM * 32, a.Cout - co0) * ES;
-    const int cinB = min(TN * 32, a.Cin - ci0) * ES;
-    const __amdgpu_buffer_rsrc_t srcG = __builtin_amdgcn_make_buffer_rsrc((void *)a.gy, 0, a.gbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t srcX = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
-    constexpr unsigned OOB = 0xFFFFFF00u;
-    // gy: thread t of the first PK * CA threads stages chunk (t % CA) of row (t / CA)
-    const int tid = threadIdx.x;
-    const bool stagesA = tid < PK * CA;
-    const int arow = tid / CA, achunk = tid - arow * CA;
-    int pA = p_begin + arow;
-    unsigned voA = (unsigned)pA * (unsigned)rowA + (unsigned)(co0 * ES + achunk * 16);
-    const bool okA = achunk * 16 < coutA;
-    // x: lane l stages half of pixel row (l >> 1) of this wave's tap
-    const int lrow = lane >> 1, lhalf = lane & 1;
-    int pcur = p_begin + lrow;
-    int bB, ohB, owB;
-    {
-        const int b = pcur / (a.Ho * a.Wo);
-        const int rem = pcur - b * (a.Ho * a.Wo);
-        bB = b; ohB = rem / a.Wo; owB = rem - ohB * a.Wo;
-    }
-    const unsigned colB = (unsigned)(ci0 * ES + lhalf * NLB * 16);
-    const int tapH = ki - a.pad, tapW = kj - a.pad;
-
-    uint4 ra, rb[NLB];
-    auto load_stage = [&]() {
-        ra = make_uint4(0, 0, 0, 0);
-        if (stagesA) ra = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srcG, (okA && pA < p_end) ? voA : OOB, 0, 0));
-        const int ih = ohB * a.stride + tapH, iw = owB * a.stride + tapW;
-        const bool inimg = (pcur < p_end) && (ih >= 0) && (ih < a.H) && (iw >= 0) && (iw < a.W);
-        const unsigned voB = (unsigned)((bB * a.H + ih) * a.W + iw) * (unsigned)a.pixbytes + colB;
-#pragma unroll
-        for (int i = 0; i < NLB; ++i) {
-            const bool ok = inimg && ((lhalf * NLB + i) * 16 < cinB);
-            rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srcX, ok ? voB + i * 16 : OOB, 0, 0));
-        }
-        pA += PK; voA += (unsigned)(PK * rowA);
-        pcur += PK;
-        owB += PK;
-        while (owB >= a.Wo) { owB -= a.Wo; ++ohB; }
-        while (ohB >= a.Ho) { ohB -= a.Ho; ++bB; }
-    };
-    if (p_begin < p_end) load_stage();
-    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, hh = g >> 1;
-    int sbuf = 0;
-    for (int p0 = p_begin; p0 < p_end; p0 += PK, sbuf ^= 1) {
-        char *ldsA = lds_all + sbuf * PK * PA;
-        if (stagesA) *reinterpret_cast<uint4 *>(ldsA + arow * PA + achunk * 16) = ra;
-#pragma unroll
-        for (int i = 0; i < NLB; ++i) *reinterpret_cast<uint4 *>(ldsB + lrow * PB + (lhalf * NLB + i) * 16) = rb[i];
-        // one barrier per stage: the gy rows are everybody's; the buffer written next is the one all waves left a stage ago
-        __syncthreads();
-        if (p0 + PK < p_end) load_stage();
-#pragma unroll
-        for (int ks = 0; ks < PK / 16; ++ks) {
-            uint4 fa[TM], fb[TN];
-            const int row0 = ks * 16 + 8 * hh + q;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const char *base = ldsA + row0 * PA + (i * 32 + 16 * (g & 1) + 4 * pp) * 2;
-                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base));
-                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base + 4 * PA));
-                uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-                fa[i] = make_uint4(l2.x, l2.y, h2.x, h2.y);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const char *base = ldsB + row0 * PB + (j * 32 + 16 * (g & 1) + 4 * pp) * 2;
-                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base));
-                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(base + 4 * PB));
-                uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-                fb[j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    Mma<T>::run(fa[i], fb[j], acc[i][j]);
-            if (do_sum) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const unsigned w[4] = {fa[i].x, fa[i].y, fa[i].z, fa[i].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { float lo, hi; unpack2<T>(w[e], lo, hi); fsum[i] += lo + hi; }
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (do_sum) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const float tot = fsum[i] + __shfl_xor(fsum[i], 32, 64);
-            const int co = co0 + i * 32 + (lane & 31);
-            if (lane < 32 && co < a.Cout) {
-                a.gsum[(size_t)(slab_id * 4) * a.Cout + co] = tot;
-#pragma unroll
-                for (int r = 1; r < 4; ++r) a.gsum[(size_t)(slab_id * 4 + r) * a.Cout + co] = 0.f;
-            }
-        }
-    }
-    float *slab = a.slabs + (size_t)slab_id * a.Cout * 9 * a.Cin;
-    const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int ci = ci0 + j * 32 + r;
-#pragma unroll
-            for (int qq = 0; qq < 16; ++qq) {
-                const int co = co0 + i * 32 + (qq & 3) + 8 * (qq >> 2) + 4 * h;
-                if (co < a.Cout && ci < a.Cin) slab[((size_t)co * 9 + tap) * a.Cin + ci] = acc[i][j][qq];
-            }
-        }
-}
-
-// ------------------------------------------------------------------------------------
 // wgrad kernel for 3x3 / stride 1 / pad 1 layers (all but a handful of the network's convs).
 // The generic kernel above stages gy and x once PER TAP (9x each) and moves two LDS fragments per
 // MFMA; here one wave owns the three horizontal taps of KR kernel rows and walks the PADDED image
@@ -1615,22 +1451,6 @@ __global__ void __launch_bounds__(256) k_conv_wgrad_grp(WgGroup g)
     wgrad_body<T, TM, TN>(g.a[i], (int)blockIdx.x - g.off[i]);
 }
 
-template <typename T, int TM, int TN>
-__global__ void __launch_bounds__(576) k_conv_wgrad_t9(WgArgs a)
-{
-    wgrad_t9_body<T, TM, TN>(a, blockIdx.x);
-}
-
-// ... and for the nine-tap kernel (576 threads per workgroup)
-template <typename T, int TM, int TN>
-__global__ void __launch_bounds__(576) k_conv_wgrad_t9_grp(WgGroup g)
-{
-    int i = 0;
-#pragma unroll
-    for (int k = 1; k < DCF_WG_GROUP; ++k) i += (k < g.n && (int)blockIdx.x >= g.off[k]);
-    wgrad_t9_body<T, TM, TN>(g.a[i], (int)blockIdx.x - g.off[i]);
-}
-
 }  // namespace
 
 // row-sharing kernel for the 3x3 / stride-1 / pad-1 layers (conv_rs.hip)
@@ -1797,14 +1617,6 @@ extern "C" int dcf_conv2d_dgrad_halfres(int dtype, const void *gy, const void *w
 
 static void wgrad_tiles(int Cin, int Cout, int &TM, int &TN) { TM = Cout >= 64 ? 2 : 1; TN = Cin >= 64 ? 2 : 1; }
 
-// 3x3 layers of the generic weight-gradient kernel (stride 2) with 64-channel output tiles and 16-bit operands go to the nine-tap
-// kernel (wgrad_t9_body) -- in the grouped launch and on their own alike, so both write the same bits.  Option WGRAD_T9=0: off.
-static bool wgrad_t9(int dtype, int kh, int kw, int TM)
-{
-    static DcfOpt t9_o("WGRAD_T9"); const char *t9 = t9_o.str();
-    return dtype != DCF_F32 && kh == 3 && kw == 3 && TM == 2 && !(t9 && atoi(t9) == 0);
-}
-
 // 3x3 / stride-1 layers: tile of the row-sharing kernel; KR = kernel rows per wave
 static int wgrad3_nw()
 {
@@ -1952,18 +1764,6 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
     wgrad_tiles(Cin, Cout, TM, TN);
     a.co_tiles = cdiv(Cout, TM * 32);
     a.ci_tiles = cdiv(Cin, TN * 32);
-    if (wgrad_t9(dtype, kh, kw, TM)) {
-        dim3 grid9(a.co_tiles * a.ci_tiles * nsplit);
-#define DCF_WG9(T_, NAME_)                                                                                                                      \
-    do {                                                                                                                                        \
-        if (TN == 2) DCF_LAUNCH_WB(NAME_ "<2,2>", flops, wbytes_, s, hipLaunchKernelGGL((k_conv_wgrad_t9<T_, 2, 2>), grid9, dim3(576), 0, s, a));  \
-        else DCF_LAUNCH_WB(NAME_ "<2,1>", flops, wbytes_, s, hipLaunchKernelGGL((k_conv_wgrad_t9<T_, 2, 1>), grid9, dim3(576), 0, s, a));          \
-    } while (0)
-        if (dtype == DCF_F16) DCF_WG9(f16_t, "conv_wgrad_t9_f16");
-        else DCF_WG9(bf16_t, "conv_wgrad_t9_bf16");
-#undef DCF_WG9
-        return DCF_OK;
-    }
     dim3 grid(a.co_tiles * a.ci_tiles * kh * kw * nsplit);
 #define DCF_WG(T_, NAME_)                                                                                                                       \
     do {                                                                                                                                        \
@@ -2011,7 +1811,6 @@ extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_st
         else {
             wgrad_tiles(it.Cin, it.Cout, TM, TN);
             bucket[i] = 1 + (TM == 2 ? 0 : 2) + (TN == 2 ? 0 : 1);
-            if (wgrad_t9(it.dtype, it.kh, it.kw, TM)) bucket[i] = TN == 2 ? 6 : 7;      // the nine-tap kernel
         }
         if (bucket[i] < 0) {
             int rc = dcf_conv2d_wgrad(it.dtype, it.x, it.gy, it.slabs, it.gsum, it.nsplit, it.B, it.H, it.W, it.Cin, Ho, Wo, it.Cout, it.kh, it.kw,
@@ -2037,8 +1836,7 @@ extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_st
         }
     static DcfOpt gen_env_o("WGRAD_GROUP_GENERIC"); const char *gen_env = gen_env_o.str();
     const bool group_generic = !(gen_env && atoi(gen_env) == 0);
-    for (int bk = 0; bk <= 7; ++bk) {
-        if (bk == 5) continue;
+    for (int bk = 0; bk <= 4; ++bk) {
         for (int dt = DCF_BF16; dt <= DCF_F16; ++dt) {
             WgGroup g;
             int cnt = 0, blocks = 0;
@@ -2059,14 +1857,7 @@ extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_st
                 } else if (bk == 1) DCF_GRP_GEN(2, 2);
                 else if (bk == 2) DCF_GRP_GEN(2, 1);
                 else if (bk == 3) DCF_GRP_GEN(1, 2);
-                else if (bk == 4) DCF_GRP_GEN(1, 1);
-                else if (bk == 6) {
-                    if (dt == DCF_F16) DCF_LAUNCH_WB("conv_wgrad_t9_grp_f16<2,2>", flops, bytes, s, hipLaunchKernelGGL((k_conv_wgrad_t9_grp<f16_t, 2, 2>), dim3(blocks), dim3(576), 0, s, g));
-                    else DCF_LAUNCH_WB("conv_wgrad_t9_grp_bf16<2,2>", flops, bytes, s, hipLaunchKernelGGL((k_conv_wgrad_t9_grp<bf16_t, 2, 2>), dim3(blocks), dim3(576), 0, s, g));
-                } else {
-                    if (dt == DCF_F16) DCF_LAUNCH_WB("conv_wgrad_t9_grp_f16<2,1>", flops, bytes, s, hipLaunchKernelGGL((k_conv_wgrad_t9_grp<f16_t, 2, 1>), dim3(blocks), dim3(576), 0, s, g));
-                    else DCF_LAUNCH_WB("conv_wgrad_t9_grp_bf16<2,1>", flops, bytes, s, hipLaunchKernelGGL((k_conv_wgrad_t9_grp<bf16_t, 2, 1>), dim3(blocks), dim3(576), 0, s, g));
-                }
+                else DCF_GRP_GEN(1, 1);
 #undef DCF_GRP_GEN
                 cnt = 0; blocks = 0; flops = 0.0; bytes = 0.0;
                 return DCF_OK;
@@ -2107,7 +1898,7 @@ extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_st
                     a.co_tiles = cdiv(it.Cout, TM * 32);
                     a.ci_tiles = cdiv(it.Cin, TN * 32);
                     // the kernel's XCD mapping wants a layer to start on a multiple of 8 workgroups; the extra ones exit at once
-                    blocks += (a.co_tiles * a.ci_tiles * (bk >= 6 ? 1 : it.kh * it.kw) * it.nsplit + 7) / 8 * 8;
+                    blocks += (a.co_tiles * a.ci_tiles * it.kh * it.kw * it.nsplit + 7) / 8 * 8;
                 }
                 flops += 2.0 * it.B * Ho * Wo * (double)it.Cout * it.Cin * it.kh * it.kw;
                 bytes += (double)a.xbytes + (double)a.gbytes + (double)it.nsplit * it.Cout * it.kh * it.kw * it.Cin * 4.0;

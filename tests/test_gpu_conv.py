@@ -45,8 +45,8 @@ SHAPES = [
     (3, 21, 41, 256, 128, 3, 1),     # two input-channel tiles; pixel ranges crossing frames
     (1, 13, 50, 192, 192, 3, 1),
     (2, 30, 38, 192, 192, 3, 1),
-    # nine-tap weight-gradient kernel of the stride-2 3x3 layers (round 4: nine waves per workgroup, wave = tap, shared gy tile):
-    # pixel ranges crossing rows and frames, partial channel tiles on both operands, odd sizes
+    # stride-2 3x3 layers (generic weight-gradient kernel, parity-class input gradient): pixel ranges crossing rows and frames,
+    # partial channel tiles on both operands, odd sizes
     (3, 23, 37, 64, 128, 3, 2),
     (1, 31, 29, 96, 160, 3, 2),
 ]
