@@ -633,14 +633,12 @@ __device__ long long g_knn_stamps[KNN_STAMP_TILES][16];
 // block of more than KNN_MERGE_POINTS points), after which all four hold the same list and decide alike.
 constexpr int KNN_MERGE_POINTS = 256;
 template <int K, int NW>
-__global__ void __launch_bounds__(64 * NW) k_knn_search(const int *count, int n_max, KnnGrid g, const int *cellstart,
-                                                       const float4 *sorted, float rmax2, int *out)
+__device__ __forceinline__ void knn_search_tile(const int *count, int n_max, const KnnGrid &g, const int *cellstart,
+                                                const float4 *sorted, float rmax2, int *out, const int tile, const int wv)
 {
     count += blockIdx.y * g.fs_cnt; cellstart += (size_t)blockIdx.y * g.fs_ws; out += (size_t)blockIdx.y * g.fs_out;
     sorted = reinterpret_cast<const float4 *>(reinterpret_cast<const int *>(sorted) + (size_t)blockIdx.y * g.fs_ws);
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = blockIdx.x;
     const int TI = tile / g.w8, TJ = tile - TI * g.w8;
     const int i = TI * 8 + (lane >> 3), j = TJ * 8 + (lane & 7);
     const bool inside = (i < g.h) && (j < g.w);
@@ -830,6 +828,13 @@ __global__ void __launch_bounds__(64 * NW) k_knn_search(const int *count, int n_
     }
 }
 
+template <int K, int NW>
+__global__ void __launch_bounds__(64 * NW) k_knn_search(const int *count, int n_max, KnnGrid g, const int *cellstart,
+                                                       const float4 *sorted, float rmax2, int *out)
+{
+    knn_search_tile<K, NW>(count, n_max, g, cellstart, sorted, rmax2, out, blockIdx.x, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+}
+
 // Coarse sites (few pixels, many points per cell): one WAVE per pixel, lanes split the candidate
 // points of every visited cell range, each keeping a private K-best; the wave-wide K-best is then
 // extracted with K rounds of a 64-lane lexicographic (d2, index) min.  Same traversal and the same
@@ -860,13 +865,13 @@ __device__ __forceinline__ void wave_merge(const TopK<K> &mine, float (&gd)[K], 
 }
 
 template <int K>
-__global__ void __launch_bounds__(256) k_knn_search_wave(const int *count, int n_max, KnnGrid g, const int *cellstart,
-                                                         const float4 *sorted, float rmax2, int *out)
+__device__ __forceinline__ void knn_search_wave(const int *count, int n_max, const KnnGrid &g, const int *cellstart,
+                                                const float4 *sorted, float rmax2, int *out, const int bx)
 {
     count += blockIdx.y * g.fs_cnt; cellstart += (size_t)blockIdx.y * g.fs_ws; out += (size_t)blockIdx.y * g.fs_out;
     sorted = reinterpret_cast<const float4 *>(reinterpret_cast<const int *>(sorted) + (size_t)blockIdx.y * g.fs_ws);
     const int lane = threadIdx.x & 63;
-    const int pix = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int pix = __builtin_amdgcn_readfirstlane(bx * 4 + (threadIdx.x >> 6));
     const int hw = g.h * g.w;
     if (pix >= hw) return;
     const int i = pix / g.w, j = pix - i * g.w;
@@ -977,6 +982,13 @@ __global__ void __launch_bounds__(256) k_knn_search_wave(const int *count, int n
     }
 }
 
+template <int K>
+__global__ void __launch_bounds__(256) k_knn_search_wave(const int *count, int n_max, KnnGrid g, const int *cellstart,
+                                                         const float4 *sorted, float rmax2, int *out)
+{
+    knn_search_wave<K>(count, n_max, g, cellstart, sorted, rmax2, out, blockIdx.x);
+}
+
 // Coarse sites, dense regions on a FINER site's cells (round 3).  k_knn_search_wave looks at the site's own cells: at stride 8 / 16 a
 // cell is 0.8 m / 1.6 m wide and the 5 x 5 window a wave scans first holds hundreds to thousands of points near the sensor.
 // k_knn_search_fine runs the same search, one wave per pixel, in two phases on two cell structures:
@@ -1005,9 +1017,9 @@ __device__ __forceinline__ float open_edge_distance(const KnnGrid &gf, float X, 
 }
 
 template <int K>
-__global__ void __launch_bounds__(256) k_knn_search_fine(const int *count, int n_max, KnnGrid g, KnnGrid gf, const int *cellstart_c,
-                                                         const float4 *sorted_c, const int *cellstart, const float4 *sorted, float rmax2,
-                                                         int *out, int dense_min)
+__device__ __forceinline__ void knn_search_fine(const int *count, int n_max, const KnnGrid &g, const KnnGrid &gf, const int *cellstart_c,
+                                                const float4 *sorted_c, const int *cellstart, const float4 *sorted, float rmax2,
+                                                int *out, int dense_min, const int bx)
 {
     // g: the coarse site (pixels, output, its own cells cellstart_c / sorted_c); gf: the fine site (cellstart / sorted)
     count += blockIdx.y * g.fs_cnt; out += (size_t)blockIdx.y * g.fs_out;
@@ -1016,7 +1028,7 @@ __global__ void __launch_bounds__(256) k_knn_search_fine(const int *count, int n
     cellstart += (size_t)blockIdx.y * gf.fs_ws;
     sorted = reinterpret_cast<const float4 *>(reinterpret_cast<const int *>(sorted) + (size_t)blockIdx.y * gf.fs_ws);
     const int lane = threadIdx.x & 63;
-    const int pix = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int pix = __builtin_amdgcn_readfirstlane(bx * 4 + (threadIdx.x >> 6));
     const int hw = g.h * g.w;
     if (pix >= hw) return;
     const int i = pix / g.w, j = pix - i * g.w;
@@ -1155,6 +1167,51 @@ __global__ void __launch_bounds__(256) k_knn_search_fine(const int *count, int n
     if (lane == 0) {
 #pragma unroll
         for (int q = 0; q < K; ++q) out[q * hw + pix] = (q < gcnt) ? gi[q] : -1;
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256) k_knn_search_fine(const int *count, int n_max, KnnGrid g, KnnGrid gf, const int *cellstart_c,
+                                                         const float4 *sorted_c, const int *cellstart, const float4 *sorted, float rmax2,
+                                                         int *out, int dense_min)
+{
+    knn_search_fine<K>(count, n_max, g, gf, cellstart_c, sorted_c, cellstart, sorted, rmax2, out, dense_min, blockIdx.x);
+}
+
+// The searches of ALL sites of a dcf_knn_bev_sites call in one launch (round 4): grid.x = the sites' workgroups one after the
+// other, grid.y = frame.  Each site runs the kernel body it would run on its own -- tile kernel with one wave (four tiles per
+// workgroup) or four waves per tile, wave kernel, fine-cell kernel -- so the maps are the same bits; what changes is that the
+// four launches (66 + 66 + 39 + 39 us at cfg2, each waiting for its slowest tile with most of the chip idle) overlap.
+struct KnnSearchSites {
+    KnnGrid g[DCF_MAX_KNN_SITES], gf[DCF_MAX_KNN_SITES];
+    const int *cellstart[DCF_MAX_KNN_SITES], *cellstart_f[DCF_MAX_KNN_SITES];
+    const float4 *sorted[DCF_MAX_KNN_SITES], *sorted_f[DCF_MAX_KNN_SITES];
+    int *out[DCF_MAX_KNN_SITES];
+    int kind[DCF_MAX_KNN_SITES];          // 0 tile kernel, one wave per tile; 1 tile kernel, four waves per tile; 2 wave kernel; 3 fine-cell kernel
+    int first[DCF_MAX_KNN_SITES + 1];     // first workgroup of each site
+    int n, dense_min;
+};
+
+template <int K>
+__global__ void __launch_bounds__(256) k_knn_search_ms(const int *count, int n_max, KnnSearchSites S, float rmax2)
+{
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < DCF_MAX_KNN_SITES; ++k) i += (k < S.n && (int)blockIdx.x >= S.first[k]);
+    const int lb = (int)blockIdx.x - S.first[i];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const KnnGrid &g = S.g[i];
+    const int kind = S.kind[i];
+    if (kind == 0) {
+        const int tile = lb * 4 + wave;
+        if (tile >= g.h8 * g.w8) return;
+        knn_search_tile<K, 1>(count, n_max, g, S.cellstart[i], S.sorted[i], rmax2, S.out[i], tile, 0);
+    } else if (kind == 1) {
+        knn_search_tile<K, 4>(count, n_max, g, S.cellstart[i], S.sorted[i], rmax2, S.out[i], lb, wave);
+    } else if (kind == 2) {
+        knn_search_wave<K>(count, n_max, g, S.cellstart[i], S.sorted[i], rmax2, S.out[i], lb);
+    } else {
+        knn_search_fine<K>(count, n_max, g, S.gf[i], S.cellstart[i], S.sorted[i], S.cellstart_f[i], S.sorted_f[i], rmax2, S.out[i], S.dense_min, lb);
     }
 }
 
@@ -1381,9 +1438,55 @@ struct KnnFine {                 // a finer site of the same batch whose cells a
     size_t ws_stride_bytes;
 };
 
+// What the search of one site runs: which kernel, with what of the finer site (dcf_knn_bev_sites defers the launch and issues
+// all sites' searches as one: k_knn_search_ms).
+struct KnnSearchPlan {
+    KnnGrid g, gf;
+    const int *cellstart, *cellstart_f;
+    const float4 *sorted, *sorted_f;
+    int kind;           // 0 / 1: tile kernel (tile_waves 1 or 2 / 4), 2: wave kernel, 3: fine-cell kernel
+    int tile_waves, dense_min;
+};
+
+static KnnSearchPlan knn_search_plan(const KnnGrid &g, int B, int n_max, int K, const int *cellstart, const float4 *sorted, const KnnFine *fine, bool merged)
+{
+    KnnSearchPlan pl;
+    pl.g = g; pl.gf = g; pl.cellstart = cellstart; pl.sorted = sorted; pl.cellstart_f = nullptr; pl.sorted_f = nullptr;
+    pl.tile_waves = 1; pl.dense_min = KNN_FINE_MIN_POINTS;
+    // coarse sites: one wave per pixel (lanes split the candidates).  DCF_KNN_KERNEL = wave | tile forces one of the two
+    // kernels (dcf_set_option: the parity tests compare them on the same site; both produce the exact (d2, index) order)
+    static DcfOpt force_o("KNN_KERNEL"); const char *force = force_o.str();
+    const bool per_wave = force && force[0] == 'w' ? true : (force && force[0] == 't' ? false : (g.h * g.w <= 20000));
+    // waves per tile of k_knn_search (option KNN_TILE_WAVES = 1 | 2 | 4 forces)
+    static DcfOpt tw_o("KNN_TILE_WAVES"); const char *tw = tw_o.str();
+    // automatic: four waves for a launch of up to 1500 tiles on its own; one in the all-sites launch, which fills the chip anyway
+    // (121 against 127 us at cfg2, 184 with four everywhere)
+    pl.tile_waves = tw && (tw[0] == '1' || tw[0] == '2' || tw[0] == '4') ? tw[0] - '0' : (!merged && g.h8 * g.w8 * B <= 1500 ? 4 : 1);
+    if (fine) {
+        // dense pixels on the fine site's cells, the rest on this site's own blocks (k_knn_search_fine)
+        KnnGrid gf = g;
+        gf.h = fine->h; gf.w = fine->w; gf.stride = fine->stride;
+        int ncf;
+        knn_dims(fine->h, fine->w, gf.h8, gf.w8, ncf);
+        gf.fs_ws = B > 1 ? (int)(fine->ws_stride_bytes / 4) : 0;
+        const int nscf = ncf + 1, nsbf = cdiv(nscf, CP_TILE);
+        size_t intsf = 3 * (size_t)nscf + (size_t)nsbf + 8 + (size_t)n_max;
+        intsf = (intsf + 3) & ~(size_t)3;
+        static DcfOpt dm_o("KNN_FINE_MIN"); const char *dm = dm_o.str();
+        pl.gf = gf;
+        pl.cellstart_f = (const int *)fine->ws + nscf;
+        pl.sorted_f = (const float4 *)((const char *)fine->ws + intsf * sizeof(int));
+        pl.dense_min = dm ? atoi(dm) : KNN_FINE_MIN_POINTS;
+        pl.kind = 3;
+    } else if (per_wave) pl.kind = 2;
+    else pl.kind = pl.tile_waves == 4 ? 1 : 0;
+    (void)K;
+    return pl;
+}
+
 static int knn_bev_impl(const char *who, const float *xyz, const int32_t *count_dev, int B, int n_max, int K, int h, int w, int stride,
                         float xs, float xo, float ys, float yo, float rmax2, int32_t *idx_out, void *ws, size_t ws_stride_bytes, hipStream_t s,
-                        const KnnFine *fine = nullptr, bool presorted = false)
+                        const KnnFine *fine = nullptr, bool presorted = false, KnnSearchPlan *defer = nullptr)
 {
     DCF_REQUIRE(xyz && count_dev && idx_out && ws, "%s: null pointer", who);
     DCF_REQUIRE(K >= 1 && K <= 8, "%s: K must be 1..8 (got %d)", who, K);
@@ -1424,34 +1527,16 @@ static int knn_bev_impl(const char *who, const float *xyz, const int32_t *count_
             DCF_LAUNCH_B("knn_fill", fB * n_max * (12.0 + 4.0 + 16.0), s, hipLaunchKernelGGL(k_knn_fill, dim3(nb, B), dim3(256), 0, s, xyz, count_dev, n_max, pkey, cursor, sorted, g.fs_xyz, g.fs_cnt, g.fs_ws));
         }
     }
-    const int nbp = g.h8 * g.w8;            // one workgroup (four waves) per 8x8 pixel tile
-    // coarse sites: one wave per pixel (lanes split the candidates).  DCF_KNN_KERNEL = wave | tile forces one of the two
-    // kernels (dcf_set_option: the parity tests compare them on the same site; both produce the exact (d2, index) order)
-    static DcfOpt force_o("KNN_KERNEL"); const char *force = force_o.str();
-    const bool per_wave = force && force[0] == 'w' ? true : (force && force[0] == 't' ? false : (h * w <= 20000));
-    const int nbw = cdiv(h * w, 4);
-    // waves per tile of k_knn_search (option KNN_TILE_WAVES = 1 | 2 | 4 forces)
-    static DcfOpt tw_o("KNN_TILE_WAVES"); const char *tw = tw_o.str();
-    const int tile_waves = tw && (tw[0] == '1' || tw[0] == '2' || tw[0] == '4') ? tw[0] - '0' : (nbp * B <= 1500 ? 4 : 1);
-    if (fine) {
-        // dense pixels on the fine site's cells, the rest on this site's own blocks (k_knn_search_fine)
-        KnnGrid gf = g;
-        gf.h = fine->h; gf.w = fine->w; gf.stride = fine->stride;
-        int ncf;
-        knn_dims(fine->h, fine->w, gf.h8, gf.w8, ncf);
-        gf.fs_ws = B > 1 ? (int)(fine->ws_stride_bytes / 4) : 0;
-        const int nscf = ncf + 1, nsbf = cdiv(nscf, CP_TILE);
-        const int *cellstart_f = (const int *)fine->ws + nscf;
-        size_t intsf = 3 * (size_t)nscf + (size_t)nsbf + 8 + (size_t)n_max;
-        intsf = (intsf + 3) & ~(size_t)3;
-        const float4 *sorted_f = (const float4 *)((const char *)fine->ws + intsf * sizeof(int));
-        static DcfOpt dm_o("KNN_FINE_MIN"); const char *dm = dm_o.str();
-        const int dense_min = dm ? atoi(dm) : KNN_FINE_MIN_POINTS;
+    const KnnSearchPlan pl = knn_search_plan(g, B, n_max, K, cellstart, sorted, fine, defer != nullptr);
+    if (defer) { *defer = pl; return DCF_OK; }
+    const int nbp = g.h8 * g.w8;            // one workgroup (one, two or four waves) per 8x8 pixel tile
+    const int nbw = cdiv(h * w, 4);         // one wave per pixel
+    if (pl.kind == 3) {
 #define KNN_FCASE(KK)                                                                                                                       \
     case KK:                                                                                                                                \
         DCF_LAUNCH_B("knn_search_fine", fB * ((double)h * w * K * 4.0 + (double)n_max * 16.0), s,                                           \
-                     hipLaunchKernelGGL(k_knn_search_fine<KK>, dim3(nbw, B), dim3(256), 0, s, count_dev, n_max, g, gf, cellstart, sorted,   \
-                                        cellstart_f, sorted_f, rmax2, idx_out, dense_min));                                                 \
+                     hipLaunchKernelGGL(k_knn_search_fine<KK>, dim3(nbw, B), dim3(256), 0, s, count_dev, n_max, g, pl.gf, cellstart, sorted,   \
+                                        pl.cellstart_f, pl.sorted_f, rmax2, idx_out, pl.dense_min));                                        \
         break;
         switch (K) {
             KNN_FCASE(1) KNN_FCASE(2) KNN_FCASE(3) KNN_FCASE(4) KNN_FCASE(5) KNN_FCASE(6) KNN_FCASE(7) KNN_FCASE(8)
@@ -1461,13 +1546,13 @@ static int knn_bev_impl(const char *who, const float *xyz, const int32_t *count_
     }
 #define KNN_CASE(KK)                                                                                                     \
     case KK:                                                                                                             \
-        if (per_wave)                                                                                                    \
+        if (pl.kind == 2)                                                                                                \
             DCF_LAUNCH_B("knn_search_wave", fB * ((double)h * w * K * 4.0 + (double)n_max * 16.0), s, hipLaunchKernelGGL(k_knn_search_wave<KK>, dim3(nbw, B), dim3(256), 0, s, count_dev, n_max, g, \
                                                                 cellstart, sorted, rmax2, idx_out));                     \
-        else if (tile_waves == 4)                                                                                        \
+        else if (pl.tile_waves == 4)                                                                                     \
             DCF_LAUNCH_B("knn_search", fB * ((double)h * w * K * 4.0 + (double)n_max * 16.0), s, hipLaunchKernelGGL((k_knn_search<KK, 4>), dim3(nbp, B), dim3(256), 0, s, count_dev, n_max, g, \
                                                            cellstart, sorted, rmax2, idx_out));                          \
-        else if (tile_waves == 2)                                                                                        \
+        else if (pl.tile_waves == 2)                                                                                     \
             DCF_LAUNCH_B("knn_search", fB * ((double)h * w * K * 4.0 + (double)n_max * 16.0), s, hipLaunchKernelGGL((k_knn_search<KK, 2>), dim3(nbp, B), dim3(128), 0, s, count_dev, n_max, g, \
                                                            cellstart, sorted, rmax2, idx_out));                          \
         else                                                                                                             \
@@ -1558,6 +1643,13 @@ extern "C" int dcf_knn_bev_sites(const float *xyz, const int32_t *count_dev, int
     DCF_LAUNCH("scan_apply", s, hipLaunchKernelGGL(k_scan_apply_ms, dim3(max_nsb, gy), dim3(CP_THREADS), 0, s, ss));
     if (n_max > 0)
         DCF_LAUNCH_B("knn_fill", (double)gy * n_max * (12.0 + 4.0 + 16.0), s, hipLaunchKernelGGL(k_knn_fill_ms, dim3(cdiv(n_max, 256), gy), dim3(256), 0, s, xyz, count_dev, n_max, ss));
+    // the searches: one launch for all sites (option KNN_MERGED_SEARCH=0: one launch per site, as in round 3)
+    static DcfOpt ms_o("KNN_MERGED_SEARCH"); const char *ms = ms_o.str();
+    const bool merged = !(ms && ms[0] == '0');
+    KnnSearchSites S;
+    S.n = nsites; S.dense_min = KNN_FINE_MIN_POINTS;
+    int blocks = 0;
+    double bytes = 0.0;
     for (int i = 0; i < nsites; ++i) {
         const dcf_knn_site &t = sites[i];
         KnnFine fine;
@@ -1567,10 +1659,32 @@ extern "C" int dcf_knn_bev_sites(const float *xyz, const int32_t *count_dev, int
                         "%s: site %d must lie on the grid of its fine site", who, i);
             fine = {f.h, f.w, f.stride, f.ws, f.ws_stride_bytes};
         }
+        KnnSearchPlan pl;
         int rc = knn_bev_impl(who, xyz, count_dev, B, n_max, K, t.h, t.w, t.stride, xs, xo, ys, yo, rmax2, t.idx_out, t.ws, t.ws_stride_bytes, s,
-                              t.fine >= 0 ? &fine : nullptr, true);
+                              t.fine >= 0 ? &fine : nullptr, true, merged ? &pl : nullptr);
         if (rc) return rc;
+        if (!merged) continue;
+        S.g[i] = pl.g; S.gf[i] = pl.gf; S.cellstart[i] = pl.cellstart; S.sorted[i] = pl.sorted; S.cellstart_f[i] = pl.cellstart_f;
+        S.sorted_f[i] = pl.sorted_f; S.out[i] = t.idx_out; S.kind[i] = pl.kind; S.dense_min = pl.dense_min;
+        S.first[i] = blocks;
+        const int tiles = pl.g.h8 * pl.g.w8;
+        blocks += pl.kind == 0 ? cdiv(tiles, 4) : (pl.kind == 1 ? tiles : cdiv(t.h * t.w, 4));
+        bytes += (double)B * ((double)t.h * t.w * K * 4.0 + (double)n_max * 16.0);
     }
+    if (!merged) return DCF_OK;
+    for (int i = nsites; i < DCF_MAX_KNN_SITES; ++i) {
+        S.g[i] = S.g[0]; S.gf[i] = S.gf[0]; S.cellstart[i] = S.cellstart[0]; S.sorted[i] = S.sorted[0]; S.cellstart_f[i] = S.cellstart_f[0];
+        S.sorted_f[i] = S.sorted_f[0]; S.out[i] = S.out[0]; S.kind[i] = S.kind[0];
+    }
+    for (int i = nsites; i <= DCF_MAX_KNN_SITES; ++i) S.first[i] = blocks;
+#define KNN_MCASE(KK)                                                                                                                  \
+    case KK:                                                                                                                           \
+        DCF_LAUNCH_B("knn_search_sites", bytes, s, hipLaunchKernelGGL(k_knn_search_ms<KK>, dim3(blocks, B), dim3(256), 0, s, count_dev, n_max, S, rmax2)); \
+        break;
+    switch (K) {
+        KNN_MCASE(1) KNN_MCASE(2) KNN_MCASE(3) KNN_MCASE(4) KNN_MCASE(5) KNN_MCASE(6) KNN_MCASE(7) KNN_MCASE(8)
+    }
+#undef KNN_MCASE
     return DCF_OK;
 }
 

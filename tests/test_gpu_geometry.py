@@ -540,6 +540,21 @@ def test_knn_all_sites_in_one_call_equal_the_per_site_calls(K, B, rmax):
     ops.knn_bev_sites(d, cnt, K, sites, g.aff, rmax)
     for i in range(4):
         assert torch.equal(sites[i][5], again[i])
+    # round 4: the four searches are ONE launch (k_knn_search_ms: every site runs the kernel body it would run alone).  Every
+    # body of that launch -- tile kernel with one / four waves per tile, wave kernel, fine-cell kernel -- and the per-site
+    # launches of round 3 (KNN_MERGED_SEARCH=0) give the same bits.
+    try:
+        for opt, val in (("KNN_TILE_WAVES", "1"), ("KNN_TILE_WAVES", "4"), ("KNN_KERNEL", "wave"), ("KNN_KERNEL", "tile"), ("KNN_MERGED_SEARCH", "0")):
+            H.set_option(opt, val)
+            for t in sites:
+                t[5].fill_(-7)
+            ops.knn_bev_sites(d, cnt, K, sites, g.aff, rmax)
+            H.set_option(opt, None)
+            for i in range(4):
+                assert torch.equal(sites[i][5], again[i]), (opt, val, i)
+    finally:
+        for opt in ("KNN_TILE_WAVES", "KNN_KERNEL", "KNN_MERGED_SEARCH"):
+            H.set_option(opt, None)
     with pytest.raises(H.DcfError):             # `fine` must name an earlier site
         bad = list(sites)
         bad[1] = bad[1][:3] + (2,) + bad[1][4:]

@@ -58,15 +58,17 @@ for si in range(1, 5):
     h, w = 704 // s, 800 // s
     sites.append((h, w, s, 0 if h * w <= 20000 else -1, torch.empty((B, ops.knn_ws_stride(n_max, h, w)), dtype=torch.uint8, device="cuda"),
                   torch.empty((B, 3, h, w), dtype=torch.int32, device="cuda")))
-for tw in ("1", "2", "4", None):
-    H.set_option("KNN_TILE_WAVES", tw)
+for tw in ("unmerged", "1", "4", None):
+    H.set_option("KNN_MERGED_SEARCH", "0" if tw == "unmerged" else None)
+    H.set_option("KNN_TILE_WAVES", None if tw == "unmerged" else tw)
     ops.knn_bev_sites(pts, cnts, 3, sites, g.aff, None)
     H.call("dcf_prof_reset"); H.call("dcf_prof_enable", 1)
     for _ in range(5):
         ops.knn_bev_sites(pts, cnts, 3, sites, g.aff, None)
     torch.cuda.synchronize(); H.call("dcf_prof_enable", 0)
     pr = H.prof_read()
-    print("sites call, B=2, waves per tile %s: total %.1f us;" % (tw or "auto", sum(v[0] for v in pr.values()) / 5 * 1e3),
+    print("sites call, B=2, %s: total %.1f us;" % ({"unmerged": "one search launch per site", None: "one search launch, waves per tile automatic"}.get(tw, "one search launch, waves per tile %s" % tw), sum(v[0] for v in pr.values()) / 5 * 1e3),
           {k: (round(v[0] / v[1] * 1e3, 1), v[1] // 5) for k, v in pr.items()})
     print("   whole call on the GPU timeline: %.1f us" % timeit(lambda: ops.knn_bev_sites(pts, cnts, 3, sites, g.aff, None)))
 H.set_option("KNN_TILE_WAVES", None)
+H.set_option("KNN_MERGED_SEARCH", None)
