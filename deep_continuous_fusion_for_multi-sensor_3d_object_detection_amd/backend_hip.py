@@ -489,7 +489,8 @@ class HipBackend(object):
     # ------------------------------------------------------------------ fusion
     def point_sample_fwd(self, fmap, uv, cnt, n_max):
         B = fmap.shape[0]
-        fp = torch.zeros((B, max(n_max, 1), fmap.shape[-1]), dtype=fmap.dtype, device=fmap.device)      # frames side by side: one fill, no stack copy
+        # frames side by side; the kernel writes every row (zeros past a frame's point count): no fill
+        fp = (torch.empty if n_max > 0 else torch.zeros)((B, max(n_max, 1), fmap.shape[-1]), dtype=fmap.dtype, device=fmap.device)
         if uv.is_contiguous() and cnt.is_contiguous() and n_max > 0:
             return ops.point_sample_fwd_batch(self.dtype, fmap, uv, cnt, n_max, fp)               # one launch for the batch
         for b in range(B):

@@ -51,7 +51,10 @@ __global__ void __launch_bounds__(256) k_point_sample_fwd(const T *fmap, int Hf,
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int n = min(*count, n_max);
     const int64_t p = e / C4;
-    if (p >= n) return;
+    if (p >= n) {                               // rows past the frame's point count are written as zeros (no pre-zeroed output)
+        if (p < n_max) st4(fp + e * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+        return;
+    }
     const int c = (int)(e - p * C4) * 4;
     const Taps t = make_taps(uv[2 * p], uv[2 * p + 1], Hf, Wf);
     const int C = C4 * 4;

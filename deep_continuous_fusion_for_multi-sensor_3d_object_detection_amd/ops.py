@@ -439,9 +439,9 @@ def knn_bev_sites(xyz, cnt, K, sites, aff, rmax=None):
 
 # ------------------------------------------------------------------ fusion
 def point_sample_fwd(dtype, fmap, uv, cnt, n_max, out=None):
-    """out: optional ZEROED [n_max, Cf] tensor to write into (a frame's slice of a batch tensor)."""
+    """out: optional [n_max, Cf] tensor to write into (a frame's slice of a batch tensor); every row is written (zeros past cnt)."""
     Hf, Wf, Cf = fmap.shape
-    fp = torch.zeros((max(n_max, 1), Cf), dtype=fmap.dtype, device=fmap.device) if out is None else _chk(out, "out")
+    fp = (torch.empty if n_max > 0 else torch.zeros)((max(n_max, 1), Cf), dtype=fmap.dtype, device=fmap.device) if out is None else _chk(out, "out")
     H.call("dcf_point_sample_fwd", dtype, fmap, Hf, Wf, Cf, uv, cnt, n_max, fp, H.stream_ptr())
     return fp
 
@@ -453,7 +453,7 @@ def point_sample_bwd(dtype, gfp, uv, cnt, n_max, gfmap):
 
 
 def point_sample_fwd_batch(dtype, fmap, uv, cnt, n_max, out):
-    """All frames in one launch: fmap [B,Hf,Wf,Cf], uv [B,rows,2], cnt int32 [B], out ZEROED [B,n_max,Cf]."""
+    """All frames in one launch: fmap [B,Hf,Wf,Cf], uv [B,rows,2], cnt int32 [B], out [B,n_max,Cf] (every row is written: zeros past a frame's count)."""
     B, Hf, Wf, Cf = fmap.shape
     H.call("dcf_point_sample_fwd_batch", dtype, _chk(fmap, "fmap"), Hf, Wf, Cf, _chk(uv, "uv"), uv.stride(0), cnt, n_max, _chk(out, "out"), B, H.stream_ptr())
     return out

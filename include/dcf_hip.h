@@ -326,7 +326,8 @@ int dcf_bn_train_bwd(int dtype, const void *g, const void *x, const float *mean,
 
 /* ------------------------------------------------------------------ fusion
  * SURVEY.md App. D (reference: model.py:199-203 TODO).  Per sample.
- * (1) per-point camera feature: fp [n][Cf] = bilinear(F [Hf][Wf][Cf], u/4-0.5, v/4-0.5), border clamp */
+ * (1) per-point camera feature: fp [n][Cf] = bilinear(F [Hf][Wf][Cf], u/4-0.5, v/4-0.5), border clamp; all n_max rows of fp are
+ *     written (zeros from *count_dev on: fp needs no clearing) */
 int dcf_point_sample_fwd(int dtype, const void *fmap, int Hf, int Wf, int Cf, const float *uv, const int32_t *count_dev,
                          int n_max, void *fp, dcf_stream_t stream);
 /*     backward: gF[tap] += w_tap * gfp (fp32 atomics into gfmap fp32 [Hf][Wf][Cf]) */

@@ -417,7 +417,11 @@ def test_batched_fusion_kernels_equal_per_frame_calls(dtype):
     cnt = torch.tensor(ns, dtype=torch.int32, device="cuda")
     fmap = (torch.rand(B, Hf, Wf, Cf, generator=g) - 0.5).cuda().to(tdt)
     # point sampling forward / backward
-    fp_b = ops.point_sample_fwd_batch(dtype, fmap, uv, cnt, n_max, torch.zeros(B, n_max, Cf, device="cuda", dtype=tdt))
+    # (the output needs no clearing since round 4: rows past a frame's point count are written as zeros)
+    fp_b = ops.point_sample_fwd_batch(dtype, fmap, uv, cnt, n_max, torch.full((B, n_max, Cf), float("nan"), device="cuda", dtype=tdt))
+    for b in range(B):
+        assert float(fp_b[b, ns[b]:].float().abs().max()) == 0.0 if ns[b] < n_max else True
+    assert bool(torch.isfinite(fp_b.float()).all())
     gfp = (torch.rand(B, n_max, Cf, generator=g) - 0.5).cuda().to(tdt)
     gF_b = ops.point_sample_bwd_batch(dtype, gfp, uv, cnt, n_max, torch.zeros(B, Hf, Wf, Cf, device="cuda"))
     for b in range(B):
