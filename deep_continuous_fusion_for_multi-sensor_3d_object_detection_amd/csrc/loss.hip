@@ -18,13 +18,28 @@ __device__ __forceinline__ float block_sum(float v, float *red)
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// the same for a 1024-thread workgroup (16 waves), in a fixed order
+__device__ __forceinline__ float block_sum16(float v, float *red)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t += (red[4 * q] + red[4 * q + 1]) + (red[4 * q + 2] + red[4 * q + 3]);
+    return t;
+}
+
 // ints  = [B x {off_int, npos, nneg, nrow, off_float, nbox}] then per sample: pos cells, neg cells, reg cells, box of each reg cell
 // floats = per sample: weight of each reg cell, then nbox x 7 box parameters
-__global__ void __launch_bounds__(256) k_loss_fwd_bwd(const float *cls, int64_t cls_bs, const float *reg, int64_t reg_bs, const float *anc,
+// (1024 threads: with the reference's 'last' reduction ONE workgroup does all the work, and its entries are chains of dependent
+// loads -- list item -> cell -> scores -> atomics; at 256 threads the launch took 40 us between forward and backward)
+__global__ void __launch_bounds__(1024) k_loss_fwd_bwd(const float *cls, int64_t cls_bs, const float *reg, int64_t reg_bs, const float *anc,
                                                       const int64_t *ints, const float *floats, int B, int HW, float gain, int reduction,
                                                       float *loss, float *gcls, int64_t gcls_bs, float *greg, int64_t greg_bs)
 {
-    __shared__ float red[4];
+    __shared__ float red[16];
     const int b = blockIdx.x;
     // reduction 0 = 'last' (reference behaviour: only the last sample counts), 1 = 'sum', 2 = 'mean'
     if (reduction == 0 && b != B - 1) return;
@@ -78,7 +93,7 @@ __global__ void __launch_bounds__(256) k_loss_fwd_bwd(const float *cls, int64_t 
         accr += (ad < 1.f ? 0.5f * d * d : ad - 0.5f) * wrow[row];
         atomicAdd(gr + (int64_t)q * HW + cell, (ad < 1.f ? d : (d > 0.f ? 1.f : -1.f)) * wrow[row] * gain * wsample);
     }
-    const float tot = block_sum(acc + gain * accr, red);
+    const float tot = block_sum16(acc + gain * accr, red);
     if (threadIdx.x == 0) atomicAdd(loss, tot * wsample);
 }
 
@@ -293,7 +308,7 @@ extern "C" int dcf_loss_fwd_bwd(const float *cls, int64_t cls_bstride, const flo
     DCF_REQUIRE(cls && reg && anchors && ints && floats && loss && gcls && greg && B > 0 && HW > 0, "dcf_loss_fwd_bwd: bad arguments");
     DCF_REQUIRE(reduction >= 0 && reduction <= 2, "dcf_loss_fwd_bwd: reduction must be 0 (last), 1 (sum) or 2 (mean)");
     hipStream_t s = S(stream);
-    DCF_LAUNCH("loss_fwd_bwd", s, hipLaunchKernelGGL(k_loss_fwd_bwd, dim3(B), dim3(256), 0, s, cls, cls_bstride, reg, reg_bstride, anchors, ints,
+    DCF_LAUNCH("loss_fwd_bwd", s, hipLaunchKernelGGL(k_loss_fwd_bwd, dim3(B), dim3(1024), 0, s, cls, cls_bstride, reg, reg_bstride, anchors, ints,
                                                      floats, B, HW, reg_gain, reduction, loss, gcls, gcls_bstride, greg, greg_bstride));
     return DCF_OK;
 }
