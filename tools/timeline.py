@@ -21,14 +21,18 @@ for q, rs in sorted(byq.items()):
     busy = sum(r["e"] - r["s"] for r in rs)
     gaps = []
     prev = None
+    pname = ""
     for r in rs:
         if prev is not None and r["s"] > prev:
-            gaps.append((r["s"] - prev, r["Kernel_Name"][:60]))
+            gaps.append((r["s"] - prev, "%s  (after %s, %.2f ms into the step)" % (r["Kernel_Name"].replace("(anonymous namespace)::", "")[:48],
+                                                                                 pname.replace("(anonymous namespace)::", "")[:40], (r["s"] - t0) / 1e6)))
+        if prev is None or r["e"] >= prev:
+            pname = r["Kernel_Name"]
         prev = max(prev or 0, r["e"])
     print("queue %s: %d kernels, busy %.3f ms, span %.3f ms, idle inside span %.3f ms" % (
         q, len(rs), busy / 1e6, (rs[-1]["e"] - rs[0]["s"]) / 1e6, sum(g for g, _ in gaps) / 1e6))
     gaps.sort(reverse=True)
-    for g, n in gaps[:8]:
+    for g, n in gaps[:12]:
         print("     gap %.1f us before %s" % (g / 1e3, n))
 # union busy over all queues
 ev = sorted([(r["s"], 1) for r in step] + [(r["e"], -1) for r in step])
