@@ -172,7 +172,6 @@ class HipBackend(object):
         else:
             self.grads.zero_()
         self._wq = []                      # weight gradients collected by a backward that did not finish are dropped
-        self._wside_open = self._wside_on
         self._gp_pool = None               # the fusion backward's fp32 accumulators: one buffer, one fill per backward
         self.__dict__.pop("_done", None)   # ... and so is its half-finished bucket state (a backward that raised after bucket_ready)
 
@@ -245,10 +244,6 @@ class HipBackend(object):
         """The backward tells that every weight gradient of bucket `which` has been queued: with a hook installed, flush the queue,
         finalise those layers and hand their arena ranges over (their all-reduce starts under the rest of the backward)."""
         if self.bucket_hook is None:
-            if self._wside_on and which == "lidar_hi" and self._wside_open:
-                if self._wq and not torch.cuda.is_current_stream_capturing():
-                    self._flush_wgrads_side()
-                self._wside_open = False           # from LiDAR stage 3 down the launches fill the chip: collected for the end again
             return
         rng = self._bucket_layers(layers, which)
         if rng is None:
@@ -259,9 +254,6 @@ class HipBackend(object):
             self.bucket_hook(out)
 
     def end_backward(self, layers):
-        if self.__dict__.get("_wkeep"):
-            torch.cuda.current_stream().wait_stream(self._wside_stream)
-            self._wkeep = []
         self._flush_wgrads()
         if self.__dict__.get("_done") is None:
             self._finalize(0, self.nconv)
@@ -396,7 +388,7 @@ class HipBackend(object):
             for i, (L, x, gy) in enumerate(q):
                 B, Hh, W, Cin = x.shape
                 items[i] = H.WgradItem(self.dtype, L.nsplit, 0, 0, self._slbase + 4 * L.slab_off, self._gs(L), B, Hh, W, Cin, L.cout_pad, L.kh, L.kw, L.stride, L.pad, 0)
-            if len(self._wtab) > 96:
+            if len(self._wtab) > 16:
                 self._wtab.clear()
             ent = self._wtab[key] = (items, shapes, sig)
         items = ent[0]
@@ -425,49 +417,8 @@ class HipBackend(object):
             if q is None:
                 q = self._wq = []
             q.append((L, x, gy))
-            if self._wside_on and self._wside_open and len(q) >= self._wside_n and self.bucket_hook is None \
-                    and not torch.cuda.is_current_stream_capturing():
-                self._flush_wgrads_side()
             return
         ops.conv2d_wgrad(self.dtype, x, gy, self._slbase + 4 * L.slab_off, L.nsplit, L.kh, L.kw, L.stride, L.pad, self._gs(L))
-
-    # Experiment (DCF_WGRAD_SIDE=<CUs>): while the backward walks the small-M layers (LiDAR stages 5-4, FPN, heads: single rounds
-    # of 35-140 workgroups), their weight gradients go out every few layers on a second stream that is confined to <CUs> compute
-    # units (hipExtStreamCreateWithCUMask), beside the input-gradient chain instead of after it.
-    _wside_cus = int(os.environ.get("DCF_WGRAD_SIDE", "0"))
-    _wside_on = _wside_cus > 0
-    _wside_n = int(os.environ.get("DCF_WGRAD_SIDE_N", "2"))
-    _wside_open = False
-    _wside_stream = None
-
-    def _wside_make(self):
-        import ctypes as C
-        hip = C.CDLL("libamdhip64.so")
-        n = self._wside_cus
-        bits = [0] * 256
-        if os.environ.get("DCF_WGRAD_SIDE_MODE", "block") == "stride":
-            per8 = max(1, min(8, round(n / 32)))
-            for i in range(256):
-                bits[i] = 1 if (i % 8) < per8 else 0
-        else:
-            for i in range(256 - n, 256):
-                bits[i] = 1
-        words = [sum(bits[32 * w + b] << b for b in range(32)) for w in range(8)]
-        st = C.c_void_p()
-        rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), 8, (C.c_uint32 * 8)(*words))
-        if rc != 0:
-            raise H.DcfError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
-        return torch.cuda.ExternalStream(st.value)
-
-    def _flush_wgrads_side(self):
-        main = torch.cuda.current_stream()
-        if self._wside_stream is None:
-            self._wside_stream = self._wside_make()
-        keep = self.__dict__.setdefault("_wkeep", [])
-        keep.extend(self._wq)                      # x / gy stay allocated until the main stream has joined the second one
-        self._wside_stream.wait_stream(main)
-        with torch.cuda.stream(self._wside_stream):
-            self._flush_wgrads()
 
     def stem_fwd(self, L, img4, Hh, W):
         if self.bn_train:
