@@ -150,7 +150,8 @@ def roofline_leg(trainer, pool, B, steps):
     Hm.call("dcf_prof_reset")
     empty = prof.pop("__empty_bracket__", (0.0, 1, 0.0, 0.0))
     bracket_ms = empty[0] / max(empty[1], 1)             # cost of the event pair itself, subtracted per launch
-    prof = {n: [max(v[0] - bracket_ms * v[1], 1e-9), v[1], v[2], v[3]] for n, v in prof.items()}
+    # entry: [ms with the bracket cost taken out, launches, flops, bytes, ms as measured]
+    prof = {n: [max(v[0] - bracket_ms * v[1], 1e-9), v[1], v[2], v[3], v[0]] for n, v in prof.items()}
     # table-driven launches cannot see their sizes inside the library: priced here from the model
     K = trainer.model._backend
     P = float(trainer.model.flat_params.numel())
@@ -170,17 +171,19 @@ def roofline_leg(trainer, pool, B, steps):
         bound = "mfma" if (fh is None or (fm is not None and fm >= fh)) else "hbm"
         return tf, gb, bound, (fm if bound == "mfma" else fh)
 
-    table = sorted(((n, v[0], v[1], v[2], v[3]) for n, v in prof.items()), key=lambda t: -t[1])
+    table = sorted(((n, v[0], v[1], v[2], v[3], v[4]) for n, v in prof.items()), key=lambda t: -t[1])
     # The dominant kernel is the GPU FUNCTION with the most time, as rocprofv3's kernel stats count it: launch names that
     # differ only in run-time arguments (the row-sharing convolution's position tiles per workgroup; forward / input
     # gradient = the same function on two weight images) are one row there, so they are summed here too.
+    # Ranked by the time AS MEASURED (bracket cost included): subtracting ~4.5 us per launch first would push functions made of
+    # many short launches down the list and name another row than rocprofv3's kernel stats do.
     groups = {}
-    for n, m, c, w, by in table:
+    for n, m, c, w, by, raw in table:
         rk = rocprof_kernel(n)
         key = "%s<%s>" % (rk[0], ",".join(rk[1])) if rk else n
-        g = groups.setdefault(key, [n, 0.0, 0, 0.0, 0.0, []])
-        g[1] += m; g[2] += c; g[3] += w; g[4] += by; g[5].append(n)
-    symbol, (name, ms, calls, work, byts, members) = max(groups.items(), key=lambda kv: kv[1][1])
+        g = groups.setdefault(key, [n, 0.0, 0, 0.0, 0.0, [], 0.0])
+        g[1] += m; g[2] += c; g[3] += w; g[4] += by; g[5].append(n); g[6] += raw
+    symbol, (name, ms, calls, work, byts, members, raw_ms) = max(groups.items(), key=lambda kv: kv[1][6])
     tf, gb, bound, frac = rates(name, ms, work, byts)
     if bound == "hbm":
         roof = {"kernel": name, "bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac, 4), "traffic": None}
@@ -190,12 +193,13 @@ def roofline_leg(trainer, pool, B, steps):
     roof.update({"avg_launch_us": round(ms * 1e3 / max(calls, 1), 2), "launches_per_step": calls / steps,
                  "share_of_gpu_time": round(ms / total_ms, 3) if total_ms else None, "flops_per_step": work / steps,
                  "algorithmic_bytes_per_launch": round(byts / max(calls, 1)) if byts else None,
-                 "gpu_ms_per_step_all_kernels": round(total_ms / steps, 3), "event_bracket_us_subtracted": round(bracket_ms * 1e3, 2)})
+                 "gpu_ms_per_step_all_kernels": round(total_ms / steps, 3), "event_bracket_us_subtracted": round(bracket_ms * 1e3, 2),
+                 "avg_launch_us_with_bracket": round(raw_ms * 1e3 / max(calls, 1), 2), "ranked_by": "time as measured (bracket included)"})
     roof["traffic"], roof["traffic_source"], roof["traffic_stale"] = pmc_traffic(name)
     roof["kernel"] = symbol
     roof["launch_names"] = members
     breakdown = []
-    for n, m, c, w, by in table[:48]:
+    for n, m, c, w, by, _raw in table[:48]:
         tf, gb, bound, frac = rates(n, m, w, by)
         breakdown.append({"kernel": n, "ms_per_step": round(m / steps, 4), "calls_per_step": c / steps, "tflops": round(tf, 1) if tf else None,
                           "gbps": round(gb, 1) if gb else None, "bound": bound, "frac": round(frac, 4) if frac else None})
@@ -304,6 +308,23 @@ def cpu_model_name():
     return "unknown"
 
 
+def host_core_counts():
+    """(physical cores, logical CPUs) of the host: /proc/cpuinfo's distinct (physical id, core id) pairs, os.cpu_count()."""
+    phys, cur = set(), {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [t.strip() for t in line.split(":", 1)]
+                cur[k] = v
+            elif not line.strip():
+                if "core id" in cur:
+                    phys.add((cur.get("physical id", "0"), cur["core id"]))
+                cur = {}
+    except OSError:
+        pass
+    return (len(phys) or None), os.cpu_count()
+
+
 def cpu_baseline(cfg, pool_seed):
     """The CPU restatement (oracle/, kind 'port': the reference has no camera stream / KNN / fusion code to run, SURVEY.md
     F1) on a bounded sample of the same workload: ONE cfg2 frame through the whole step on all host cores (<= 32 threads) --
@@ -373,7 +394,10 @@ def cpu_baseline(cfg, pool_seed):
         t_one = (time.time() - t0) * ratio
         del p1, l1
     torch.set_num_threads(threads)
-    return {"value": round(1.0 / total, 4), "unit": "frames/s", "cores": threads, "kind": "port", "cpu": cpu_model_name(),
+    phys, logical = host_core_counts()
+    # `cores` = the threads the baseline actually ran on (the bench contract's meaning); the host's own size next to it
+    return {"value": round(1.0 / total, 4), "unit": "frames/s", "cores": threads, "threads": threads, "host_physical_cores": phys,
+            "host_logical_cpus": logical, "kind": "port", "cpu": cpu_model_name(),
             "one_thread_lidar_stream_fwd_bwd_frames_per_s": round(1.0 / t_one, 4),
             "seconds": {"geometry": round(t_geo, 3), "knn_bruteforce": round(t_knn, 3), "forward": round(t_fwd, 3), "loss_backward_adam": round(t_bwd, 3)},
             "sample": "1 cfg2 frame, whole step on %d threads, second (warm) pass of the network part: C geometry %.2fs + brute-force KNN of the 4 sites "

@@ -52,10 +52,6 @@ SIGNATURES = {
     "dcf_conv2d_fwd_rowscale": (c_int, [c_int, P, P, P, P, P, P] + [c_int] * 12 + [P]),
     "dcf_conv2d_dgrad": (c_int, [c_int, P, P, P, P, P] + [c_int] * 11 + [P]),
     "dcf_conv2d_dgrad_halfres": (c_int, [c_int, P, P, P, P, P, P] + [c_int] * 11 + [P]),
-    "dcf_conv3x3_wf_supported": (c_int, [c_int] * 6),
-    "dcf_conv3x3_weight_frag": (c_int, [c_int, P, P, c_int, c_int, P]),
-    "dcf_conv3x3_fwd_wf": (c_int, [c_int, P, P, P, P, P] + [c_int] * 6 + [P]),
-    "dcf_conv3x3_dgrad_wf": (c_int, [c_int, P, P, P, P, P] + [c_int] * 5 + [P]),
     "dcf_fp8_act_scale": (c_int, [c_float, P]),
     "dcf_cast_fp8": (c_int, [c_int, P, P, P, P, c_i64, P]),
     "dcf_weight_prep_fp8": (c_int, [P, P, c_int, c_int, P, P, P, P, P, c_float, P]),

@@ -20,9 +20,10 @@ void dcf_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *dcf_last_error(void) { return g_err; }
-// 101: dcf_fusion_gather_bwd_inv gained its workspace argument (round 3), the dcf_conv3x3_*_wf entry points and the
-// DCF_CONV_FRAG table flag were added (round 4) -- INTEGRATION.md, "Versions"
-extern "C" int dcf_version(void) { return 101; }
+// 101: dcf_fusion_gather_bwd_inv gained its workspace argument (round 3); the CONV_LC / KNN_TILE_WAVES options (round 4).
+// 102 (round 5): the four experimental dcf_conv3x3_*_wf entry points of 101 are GONE from the library (no caller outside
+// tools/; they live in tools/variants/ now) -- INTEGRATION.md, "Versions"
+extern "C" int dcf_version(void) { return 102; }
 
 // ------------------------------------------------------------------ tuning options (dcf_common.h)
 std::atomic<int> g_dcf_opt_epoch{0};

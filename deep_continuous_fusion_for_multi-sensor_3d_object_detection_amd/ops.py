@@ -115,31 +115,6 @@ def conv2d_dgrad_halfres(dtype, gy, wt, res, resq, in_shape, kh, kw, stride, pad
     return gx
 
 
-def conv3x3_weight_frag(dtype, w):
-    """w [Cout,3,3,Cin] (16-bit) -> the same weights in MFMA-fragment order (dcf_hip.h: dcf_conv3x3_weight_frag), same shape."""
-    Cout, kh, kw, Cin = w.shape
-    wf = torch.empty_like(w)
-    H.call("dcf_conv3x3_weight_frag", dtype, _chk(w, "w"), wf, Cout, Cin, H.stream_ptr())
-    return wf
-
-
-def conv3x3_fwd_wf(dtype, x, wf, shift, res, relu, cout):
-    """3x3 / stride 1 / pad 1 forward with fragment-ordered weights (conv_rw.hip); same result as conv2d_fwd."""
-    B, Hh, W, Cin = x.shape
-    y = torch.empty((B, Hh, W, cout), dtype=x.dtype, device=x.device)
-    H.call("dcf_conv3x3_fwd_wf", dtype, x, wf, shift, res, y, B, Hh, W, Cin, cout, int(relu), H.stream_ptr())
-    return y
-
-
-def conv3x3_dgrad_wf(dtype, gy, wtf, res, in_shape, mask=None):
-    """Input gradient of the same layers; wtf = conv3x3_weight_frag of wt [Cin,3,3,Cout]."""
-    B, Hh, W, Cin = in_shape
-    Cout = gy.shape[3]
-    gx = torch.empty((B, Hh, W, Cin), dtype=gy.dtype, device=gy.device)
-    H.call("dcf_conv3x3_dgrad_wf", dtype, gy, wtf, res, mask, gx, B, Hh, W, Cin, Cout, H.stream_ptr())
-    return gx
-
-
 def conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, kh, kw, stride=1):
     return H.lib().dcf_conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, kh, kw, stride)
 

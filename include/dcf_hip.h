@@ -172,22 +172,6 @@ int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const void *res,
 int dcf_conv2d_dgrad_halfres(int dtype, const void *gy, const void *wt, const void *res, const void *resq,
                              const void *mask, void *gx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
                              int kh, int kw, int stride, int pad, dcf_stream_t stream);
-/* ---- 3x3 / stride-1 / pad-1 layers with the weights in MFMA-fragment order (csrc/conv_rw.hip): the same nn.Conv2d
- * (model.py:15-28 ResidualBlock bodies, :153 conv3) as dcf_conv2d_fwd / dcf_conv2d_dgrad, bit-identical results, for the
- * 16-bit dtypes with Cin and Cout multiples of 64.  The kernel keeps its weights in registers (global -> VGPR, never LDS),
- * which needs them laid out as the matrix instruction consumes them:
- *   wf block (channel tile ct, tap, 64-channel chunk cc, k-step ks) = 1 KiB = 64 lanes x 16 bytes at byte offset
- *   (((ct * 9 + tap) * (Cin / 64) + cc) * 4 + ks) * 1024; lane (r = lane % 32, h = lane / 32) holds output channel
- *   32 ct + r, input channels 64 cc + 16 ks + 8 h + {0..7} of that tap.
- * dcf_conv3x3_weight_frag converts w [Cout][3][3][Cin] (what dcf_weight_prep writes) into that order; dcf_weight_prep
- * writes it directly for table rows with DCF_CONV_FRAG set in flags.  For the input gradient pass the fragment image of
- * wt [Cin][3][3][Cout] (Cout and Cin swapped in the call to dcf_conv3x3_weight_frag). */
-int dcf_conv3x3_wf_supported(int dtype, int B, int H, int W, int Cin, int Cout);
-int dcf_conv3x3_weight_frag(int dtype, const void *w, void *wf, int Cout, int Cin, dcf_stream_t stream);
-int dcf_conv3x3_fwd_wf(int dtype, const void *x, const void *wf, const float *shift, const void *res, void *y,
-                       int B, int H, int W, int Cin, int Cout, int relu, dcf_stream_t stream);
-int dcf_conv3x3_dgrad_wf(int dtype, const void *gy, const void *wtf, const void *res, const void *mask, void *gx,
-                         int B, int H, int W, int Cin, int Cout, dcf_stream_t stream);
 /* Weight gradient, split over pixel ranges: slabs fp32 [nsplit][Cout][kh][kw][Cin] (plain stores,
  * reduced in fixed order by dcf_wgrad_finalize => bitwise reproducible).
  * gsum (optional) fp32 [4*nsplit][Cout]: per-wave sums over pixels of gy (dL/dbeta of a folded BN),

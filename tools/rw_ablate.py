@@ -8,6 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from conv_bench import LIDAR, IMAGE, timeit
+sys.path.insert(0, os.path.join(ROOT, "tools", "variants"))
+import rw_api          # the register-weight kernel lives in a variant library (tools/rw_variants.sh), not in libdcf_hip.so
 PKG = "deep_continuous_fusion_for_multi-sensor_3d_object_detection_amd"
 ops = importlib.import_module(PKG + ".ops")
 H = importlib.import_module(PKG + "._hip")
@@ -29,11 +31,11 @@ def main():
             continue
         x = (torch.rand((B, Hh, W, Ci), device="cuda") - 0.5).bfloat16()
         w = ((torch.rand((Co, 3, 3, Ci), device="cuda") - 0.5) * 0.1).bfloat16()
-        wf = ops.conv3x3_weight_frag(1, w)
+        wf = rw_api.conv3x3_weight_frag(1, w)
         out = []
         for dbg, label in MODES:
             H.set_option("RW_DBG", dbg)
-            t = timeit(lambda: ops.conv3x3_fwd_wf(1, x, wf, None, None, False, Co), iters=30)
+            t = timeit(lambda: rw_api.conv3x3_fwd_wf(1, x, wf, None, None, False, Co), iters=30)
             out.append("%s %.1f" % (label, t * 1e6))
         H.set_option("RW_DBG", None)
         print("%-6s %s" % (name, " | ".join(out)), flush=True)

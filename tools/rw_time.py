@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from conv_bench import LIDAR, IMAGE, timeit
+sys.path.insert(0, os.path.join(ROOT, "tools", "variants"))
+import rw_api          # the register-weight kernel lives in a variant library (tools/rw_variants.sh), not in libdcf_hip.so
 PKG = "deep_continuous_fusion_for_multi-sensor_3d_object_detection_amd"
 ops = importlib.import_module(PKG + ".ops")
 
@@ -26,15 +28,15 @@ def main():
             continue
         x = (torch.rand((B, Hh, W, Ci), device="cuda") - 0.5).bfloat16()
         w = ((torch.rand((Co, 3, 3, Ci), device="cuda") - 0.5) * 0.1).bfloat16()
-        wf = ops.conv3x3_weight_frag(1, w)
+        wf = rw_api.conv3x3_weight_frag(1, w)
         if args.dgrad:
             res = (torch.rand((B, Hh, W, Co), device="cuda") - 0.5).bfloat16()
             mask = (torch.rand((B, Hh, W, Co), device="cuda") - 0.3).bfloat16()
-            t = timeit(lambda: ops.conv3x3_dgrad_wf(1, x, wf, res, (B, Hh, W, Co), mask=mask), iters=30)
+            t = timeit(lambda: rw_api.conv3x3_dgrad_wf(1, x, wf, res, (B, Hh, W, Co), mask=mask), iters=30)
         elif args.std:
             t = timeit(lambda: ops.conv2d_fwd(1, x, w, None, None, 3, 3, 1, 1, False, Co), iters=30)
         else:
-            t = timeit(lambda: ops.conv3x3_fwd_wf(1, x, wf, None, None, False, Co), iters=30)
+            t = timeit(lambda: rw_api.conv3x3_fwd_wf(1, x, wf, None, None, False, Co), iters=30)
         out.append("%s %.1f" % (name, t * 1e6))
     print("%-10s b%d %s" % (args.tag, B, " | ".join(out)), flush=True)
 

@@ -30,8 +30,9 @@
 #include <algorithm>
 #include <type_traits>
 
-#include "dcf_common.h"
+#include "dcf_common.h"          // -I <pkg>/csrc (tools/rw_variants.sh)
 #include "conv_common.h"
+#include "conv_rw.h"             // the four entry points: not part of include/dcf_hip.h
 
 // Timing ablations, COMPILE-TIME only (tools/rw_variants.sh builds one library per mask; a run-time switch changed the register
 // allocation of the whole kernel -- the 128-channel kind spilled -- and measured a different kernel): 1 no MFMAs, 2 pixel DMA
