@@ -577,7 +577,12 @@ __global__ void __launch_bounds__(512) k_conv3x3_lc(LcArgs a)
                     kstep(true, wsl, xsl, 2);
                     kstep(true, wsl, xsl, 3);
                     // barrier g + 1: tap g + 1's weights (and after a chunk's last tap the next chunk's pixels) have landed; every
-                    // consumer has issued its last read of this tap's weight slot (and of the chunk's pixel slot)
+                    // consumer has COMPLETED its last read of this tap's weight slot (and of the chunk's pixel slot): the loaders
+                    // refill those slots right behind the barrier, and s_barrier alone orders nothing against LDS reads that
+                    // are still queued (gfx950 barriers do not wait for lgkmcnt) -- the explicit wait makes the slot hand-over a
+                    // dependency instead of a race that the L2 latency happened to win.  The fragments are
+                    // needed by the first MFMA behind the barrier anyway.
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     LC_BARRIER(gtap + 1);
                     ++gtap;
                     __builtin_amdgcn_sched_barrier(0);

@@ -394,6 +394,25 @@ class ObjectDetection_DCF(_FlatParamModule):
         self._graphs = None
         self._plan._anc_key = None
 
+    def set_grid(self, voxel_length, voxel_width):
+        """Re-plan for another BEV grid IN PLACE.  No parameter depends on the grid (model.py:140-157: convolutions only), so the
+        flat parameter / gradient / buffer arenas, every nn.Parameter object (optimizers, hooks and requires_grad flags created
+        before the first forward keep pointing at live storage) and the backend with its weight images stay; what depends on the
+        grid -- the anchor tensor, the voxel-index affine map, captured graphs -- is rebuilt."""
+        L, W = int(voxel_length), int(voxel_width)
+        if (L, W) == (self.config["voxel_length"], self.config["voxel_width"]):
+            return
+        if L % 16 or W % 16:
+            raise ValueError("voxel_length and voxel_width must be multiples of 16 (FPN add, model.py:151)")
+        cfg = dict(self.config, voxel_length=L, voxel_width=W)
+        from .ops import GridSpec
+        grid = GridSpec(cfg)                         # validates the new grid before anything is changed
+        self.config = cfg
+        self._plan.cfg = cfg
+        self._plan._anc_key = None
+        self._grid = grid
+        self._graphs = None
+
     def load_state_dict(self, state_dict, strict=True):
         """Accepts the reference's checkpoints with or without DDP's 'module.' prefix (train.py:79)."""
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
@@ -673,7 +692,7 @@ class LidarBackboneNetwork(nn.Module):
 
     Like the reference's, the constructor needs no config (`LidarBackboneNetwork()`, model.py:139): the parameters do not
     depend on the BEV grid, only the engine's plan does, so the net is built on the packaged config's grid and re-planned
-    -- same parameters -- for the grid of the first input that differs (L and W multiples of 16, model.py:151)."""
+    IN PLACE (`ObjectDetection_DCF.set_grid`: same arenas, same nn.Parameter objects) for the grid of an input that differs (L and W multiples of 16, model.py:151)."""
 
     def __init__(self, out_feature=(32, 64, 128, 192, 256), num_res_block=(1, 2, 4, 6, 6), Num_anchor=2, config=None):
         super(LidarBackboneNetwork, self).__init__()
@@ -695,10 +714,8 @@ class LidarBackboneNetwork(nn.Module):
     def forward(self, x):
         L, W = int(x.shape[2]), int(x.shape[3])
         if (L, W) != (self._cfg["voxel_length"], self._cfg["voxel_width"]):
-            cfg = dict(self._cfg, voxel_length=L, voxel_width=W)
-            net = ObjectDetection_DCF(cfg).to(x.device)
-            net.load_state_dict(self.net.state_dict())
-            net.train(self.net.training)
-            self._cfg, self.net = cfg, net
+            # same module, same Parameter objects: an optimizer built before this forward keeps training the live weights
+            self.net.set_grid(L, W)
+            self._cfg = self.net.config
         pred = self.net(x, None)
         return pred[:, 0:4], pred[:, 4:18]

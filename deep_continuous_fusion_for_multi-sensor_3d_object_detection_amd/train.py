@@ -344,12 +344,26 @@ class Train(nn.Module):
         return self.loss_value.item(), pred_cls, pred_reg
 
 
-def _eval_barrier():
+_HOST_PG = None        # gloo side group of init_distributed(): host-side fences that never touch RCCL
+
+
+def _eval_barrier(timeout_s=None):
     """All ranks meet before and after rank 0's evaluation (train.main): no rank enters a gradient all-reduce while rank 0 is
-    still evaluating.  The device is drained first, so that the barrier is not queued behind this rank's own work."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    still evaluating.  The device is drained first; the fence itself is a HOST barrier on the gloo side group
+    (dist.monitored_barrier: TCP store round trips, its own timeout, names the rank that did not arrive) -- with the product's
+    `nccl` backend a plain dist.barrier() is itself an RCCL all-reduce, i.e. the waiting ranks would sit in a pending collective
+    under the RCCL watchdog for as long as rank 0 evaluates.  Timeout: DCF_EVAL_BARRIER_TIMEOUT_S (default
+    3600 s, an evaluation pass over the whole test set)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    if torch.cuda.is_available():
         torch.cuda.synchronize()
-        dist.barrier()
+    if _HOST_PG is not None:
+        import datetime
+        t = float(timeout_s if timeout_s is not None else os.environ.get("DCF_EVAL_BARRIER_TIMEOUT_S", "3600"))
+        dist.monitored_barrier(group=_HOST_PG, timeout=datetime.timedelta(seconds=t))
+    else:
+        dist.barrier()          # the default group is gloo already (functional runs) or no side group could be made
 
 
 def init_distributed():
@@ -366,6 +380,10 @@ def init_distributed():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend=backend)
+    global _HOST_PG
+    if dist.is_available() and dist.is_initialized() and _HOST_PG is None and dist.get_world_size() > 1:
+        # host-side fences (evaluation barriers) go through a gloo group of their own: created once, by every rank, here
+        _HOST_PG = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else dist.group.WORLD
     return ws
 
 
@@ -437,7 +455,7 @@ def main():
             if batch_ndx % 500 == 0 and batch_ndx != 0:                    # train.py:87-100
                 # Rank 0 evaluates, the others WAIT HERE: without the barriers they would walk into the next step's gradient
                 # all-reduce and sit in it for as long as the evaluation takes (minutes: an RCCL watchdog hazard).  A barrier on
-                # the host (monitored_barrier where the backend has it) has no such timeout coupling to a pending collective.
+                # the host (monitored_barrier on the gloo side group of init_distributed) has no such timeout coupling to a pending collective.
                 _eval_barrier()
                 if rank0:
                     mean, cum, npos, nt, tp = evaluate(training, tester, test_dataset, test_loader, max_batches=int(config.get("eval_batches", 7)))           # `batch_ndx_ > 5`

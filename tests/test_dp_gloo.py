@@ -45,6 +45,13 @@ def _worker(rank, world, port, out):
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
     assert sorted(sum(gathered, [])) == list(range(world * B))
+    # 3b) the evaluation fences are host barriers on the side group init_distributed() makes (never an RCCL collective)
+    os.environ["WORLD_SIZE"] = str(world)
+    assert train.init_distributed() == world and train._HOST_PG is not None
+    import time
+    if rank == 1:
+        time.sleep(0.3)                     # rank 0 "evaluates" meanwhile: the others just wait on the host
+    train._eval_barrier(timeout_s=60)
     # 4) timing: the bench reports MAX over ranks
     t = torch.tensor([0.010 * (rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

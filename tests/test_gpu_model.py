@@ -623,3 +623,28 @@ def test_lidar_backbone_network_bare_constructor_replans_for_the_input_grid():
         c1, r1 = bare(x)
     assert c1.shape == (2, 4, 16, 8) and r1.shape == (2, 14, 16, 8)
     assert float((c0 - c1).abs().max()) < 1e-5 and float((r0 - r1).abs().max()) < 1e-5
+
+
+def test_lidar_backbone_network_optimizer_built_before_the_first_forward_trains_the_live_parameters():
+    """the reference's order is model -> optimizer -> forward (train.py:23-28).  A bare `LidarBackboneNetwork()`
+    re-plans for the input's grid at its first forward; the optimizer created BEFORE that must still own the parameters the
+    forward and backward use (in-place re-plan: same nn.Parameter objects, same arenas)."""
+    m = pkg("model")
+    widths, blocks = (32, 64, 96, 128, 160), (1, 1, 2, 1, 1)
+    net = m.LidarBackboneNetwork(widths, blocks).cuda()
+    pkg("detfill").fill_state_dict(net.net)
+    params = list(net.parameters())
+    opt = torch.optim.Adam(params, lr=1e-3)
+    ids = [id(p) for p in params]
+    w0 = [p.detach().clone() for p in params]
+    x = torch.from_numpy(pkg("detfill").uniform((1, 32, 64, 32), 5, 0.0, 1.0)).cuda()     # not the packaged config's 384x256 grid
+    cls, reg = net(x)
+    assert cls.shape == (1, 4, 16, 8)
+    (cls.square().sum() + reg.square().sum()).backward()
+    opt.step()
+    assert [id(p) for p in net.parameters()] == ids
+    moved = sum(int((p.detach() != q).any()) for p, q in zip(net.parameters(), w0))
+    assert moved >= len(ids) - 2, "only %d of %d parameter tensors moved" % (moved, len(ids))
+    with torch.no_grad():
+        cls2, _ = net(x)
+    assert float((cls2 - cls).abs().max()) > 0          # the forward reads the updated weights
