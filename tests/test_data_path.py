@@ -222,3 +222,63 @@ def test_frame_loader_feeds_train_steps(tmp_path):
         losses.append(float(trainer.loss_value.item()))
         seen += len(batch["points"])
     assert seen == 4 and all(np.isfinite(l) for l in losses)
+
+
+class _RawFrames(torch.utils.data.Dataset):
+    """In-memory raw-mode dataset: frame i has counts[i] points; item `bad` raises."""
+    raw = True
+
+    def __init__(self, counts, hw=(24, 40), bad=None):
+        g = torch.Generator().manual_seed(5)
+        self.pts = [torch.rand((n, 3), generator=g) for n in counts]
+        self.img = [torch.randint(0, 256, (3,) + hw, dtype=torch.uint8, generator=g) for _ in counts]
+        self.bad = bad
+
+    def __len__(self):
+        return len(self.pts)
+
+    def __getitem__(self, i):
+        if i == self.bad:
+            raise RuntimeError("frame %d is unreadable" % i)
+        return {"image": self.img[i], "bboxes": torch.zeros((20, 9)), "num_bboxes": 0, "lidar_points": self.pts[i], "crt": None}
+
+
+@pytest.mark.gpu
+def test_frame_loader_background_staging_equals_inline_staging():
+    """The staging thread (three sets, two-deep hand-off) delivers the same device batches, in order, as staging on the calling
+    thread -- also when a later frame is larger than the sets sized from the first one, and with work enqueued on the consumer's
+    stream between batches (the `consumed` event is what keeps the copy stream off buffers that are still being read)."""
+    FL = pkg("frame_loader")
+    counts = [700, 300, 512, 900, 4096, 5000, 120, 6000, 8000, 100, 9000, 4500, 777]
+    ds = _RawFrames(counts)
+    ref = [(ds.pts[i], ds.img[i]) for i in range(len(counts))]
+    for threaded in (True, False):
+        seen = 0
+        sink = torch.zeros((), device="cuda")
+        for batch in FL.FrameLoader(ds, 2, threaded=threaded):
+            batch.wait()
+            for b, p in enumerate(batch["points"]):
+                # a slow reader on the consumer's stream: the next-but-one batch must not overwrite what it still reads
+                for _ in range(20):
+                    sink = sink + p.sum() * 1e-9
+                assert torch.equal(p.cpu(), ref[seen + b][0]), (threaded, seen + b)
+                assert torch.equal(batch["image"][b].cpu(), ref[seen + b][1])
+            seen += len(batch["points"])
+        assert seen == len(counts)
+        torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_frame_loader_thread_stops_on_early_exit_and_reports_dataset_errors():
+    import threading
+    FL = pkg("frame_loader")
+    n0 = threading.active_count()
+    it = iter(FL.FrameLoader(_RawFrames([256] * 12), 2))
+    next(it); next(it)
+    it.close()                                   # a `break` out of the for loop: the generator's finally stops the worker
+    assert threading.active_count() <= n0
+    with pytest.raises(RuntimeError) as e:
+        for _ in FL.FrameLoader(_RawFrames([256] * 8, bad=5), 2):
+            pass
+    assert "unreadable" in str(e.value)
+    assert threading.active_count() <= n0
