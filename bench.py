@@ -241,9 +241,10 @@ def rocprof_kernel(name):
         return "k_conv3x3_sp", [dt, c, "8" if c == "32" else "4", "2" if c == "32" else "3"]
     if t and t[0].startswith("lc"):                          # loader / consumer kernel over 2-D tiles: 'conv_fwd_bf16<lc0,6x50>'
         return "k_conv3x3_lc", [dt] + {0: ["2", "5", "2", "2", "3", "440"], 1: ["1", "5", "2", "2", "4", "504"]}[int(t[0][2:])]
-    if t and t[0].startswith("rs"):                          # row-sharing kernel: 'conv_fwd_bf16<rs0,9>' = tile kind 0, 9 position tiles
+    if t and t[0].startswith("rs"):                          # row-sharing kernel: 'conv_fwd_bf16<rs0,9>' = tile kind 0, 9 position tiles;
+        chain = "true" if any(x.startswith("x") for x in t[1:]) else "false"      # 'conv_fwd_bf16<rs2,4,x21>' = a chain of 21 layers in one launch
         return "k_conv3x3_rs", [dt] + {0: ["1", "5", "4", "2", "2", "1", "false"], 1: ["1", "3", "2", "4", "2", "1", "false"],
-                                       2: ["1", "1", "2", "4", "6", "2", "true"]}[int(t[0][2:])]
+                                       2: ["1", "1", "2", "4", "6", "2", "true"]}[int(t[0][2:])] + [chain]
     if kind.startswith("conv_fwd") or kind.startswith("conv_dgrad") or kind.startswith("stem_fwd"):
         tr = "true" if "dgrad" in kind else "false"
         if t and t[-1].startswith("dma"):

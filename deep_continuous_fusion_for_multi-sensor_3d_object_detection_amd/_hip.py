@@ -52,6 +52,9 @@ SIGNATURES = {
     "dcf_conv2d_fwd_rowscale": (c_int, [c_int, P, P, P, P, P, P] + [c_int] * 12 + [P]),
     "dcf_conv2d_dgrad": (c_int, [c_int, P, P, P, P, P] + [c_int] * 11 + [P]),
     "dcf_conv2d_dgrad_halfres": (c_int, [c_int, P, P, P, P, P, P] + [c_int] * 11 + [P]),
+    "dcf_conv3x3_chain_supported": (c_int, [c_int] * 6),
+    "dcf_conv3x3_chain_workspace_bytes": (c_size_t, [c_int] * 6),
+    "dcf_conv3x3_chain": (c_int, [c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "dcf_fp8_act_scale": (c_int, [c_float, P]),
     "dcf_cast_fp8": (c_int, [c_int, P, P, P, P, c_i64, P]),
     "dcf_weight_prep_fp8": (c_int, [P, P, c_int, c_int, P, P, P, P, P, c_float, P]),
@@ -131,6 +134,15 @@ class WgradItem(ctypes.Structure):
                 ("pad_", ctypes.c_int32)]
 
 
+CHAIN_MAX_LAYERS = 24        # DCF_CHAIN_MAX_LAYERS
+
+
+class ChainLayer(ctypes.Structure):
+    """struct dcf_chain_layer of include/dcf_hip.h."""
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("shift", c_void_p), ("res", c_void_p), ("mask", c_void_p), ("y", c_void_p),
+                ("relu", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
 class KnnMap(ctypes.Structure):
     """struct dcf_knn_map of include/dcf_hip.h."""
     _fields_ = [("idx", c_void_p), ("h", ctypes.c_int32), ("w", ctypes.c_int32)]
@@ -203,7 +215,7 @@ def stream_ptr():
 
 
 _FN = {}                # name -> (bound foreign function, raises on a non-zero status)
-_NO_RAISE = ("dcf_version", "dcf_conv2d_wgrad_splits", "dcf_prof_read", "dcf_conv2d_wgrad_groupable")
+_NO_RAISE = ("dcf_version", "dcf_conv2d_wgrad_splits", "dcf_prof_read", "dcf_conv2d_wgrad_groupable", "dcf_conv3x3_chain_supported")
 
 
 def call(name, *args):

@@ -32,6 +32,7 @@ class HipBackend(object):
         self.dev = params.device
         self._fus_dws = {}                 # fusion backward: boundary-row workspaces per (pairs, channels, frames)
         self._wtab = {}                    # grouped weight gradients: ctypes tables per layer sequence
+        self._chain_ok, self._chain_ws, self._chain_tab = {}, {}, {}     # chain launches: support per shape, arrival counters per shape, ctypes tables per length
         self._fn_fwd, self._fn_dgrad = H.fn("dcf_conv2d_fwd"), H.fn("dcf_conv2d_dgrad")
         self._pbase, self._gbase = params.data_ptr(), grads.data_ptr()     # (arena slices go to the C ABI as raw addresses: a view costs ~2.5 us)
         self.bn_train = False          # batch statistics instead of running statistics (train-mode BatchNorm)
@@ -357,6 +358,63 @@ class HipBackend(object):
         if rc:
             H.fail("dcf_conv2d_dgrad", rc)
         return gx
+
+    # ------------------------------------------------------------------ chains (one launch per residual stage)
+    chain_enabled = os.environ.get("DCF_CHAIN", "1") != "0"
+
+    def can_chain(self, shape, n):
+        """Can `n` consecutive 3x3 / stride-1 layers on activations of `shape` [B,H,W,C] run as chain launches
+        (dcf_conv3x3_chain: 16-bit storage, eval-mode BatchNorm folded into the weights, no fp8 images, one round of tiles)?"""
+        if not self.chain_enabled or n < 2 or self.bn_train or self.has_fp8 or self.dtype == H.F32:
+            return False
+        key = tuple(shape)
+        ok = self._chain_ok.get(key)
+        if ok is None:
+            B, Hh, W, C = key
+            ok = self._chain_ok[key] = ops.conv3x3_chain_supported(self.dtype, B, Hh, W, C, 1)
+        return ok
+
+    def _chain(self, x, layers, flip):
+        """layers: (weight address, shift address, res, mask, relu) per layer, res / mask = tensor, None or the index of an
+        earlier layer of this call.  Chains longer than the ABI's limit are split (an index that then points into an earlier
+        launch becomes that launch's tensor)."""
+        B, Hh, W, C = x.shape
+        key = (B, Hh, W, C)
+        ws = self._chain_ws.get(key)
+        if ws is None:
+            ws = self._chain_ws[key] = ops.conv3x3_chain_workspace(self.dtype, B, Hh, W, C, H.CHAIN_MAX_LAYERS, x.device)
+        outs, cur, pos = [], x, 0
+        while pos < len(layers):
+            part = layers[pos:pos + H.CHAIN_MAX_LAYERS]
+            fix = []
+            for (w, sh, r, m, relu) in part:
+                r = (outs[r] if r < pos else r - pos) if type(r) is int else r
+                m = (outs[m] if m < pos else m - pos) if type(m) is int else m
+                fix.append((w, sh, r, m, relu))
+            tab = self._chain_tab.get(len(fix))
+            if tab is None:
+                tab = self._chain_tab[len(fix)] = (H.ChainLayer * len(fix))()
+            got = ops.conv3x3_chain(self.dtype, cur, fix, flip, ws, tab)
+            outs.extend(got)
+            cur = got[-1]
+            pos += len(part)
+        return outs
+
+    def chain_fwd(self, x, specs):
+        """specs: (layer, res, relu) per layer, each layer reading the previous one's output (the first reads x).  Same results
+        as conv_fwd layer by layer.  Returns the list of outputs."""
+        outs = self._chain(x, [(self._wbase + L.wfwd_off, self._shift(L), r, None, relu) for (L, r, relu) in specs], 0)
+        shp = (x.shape[0], x.shape[1], x.shape[2])
+        for (L, _, _) in specs:
+            L.out_shape = shp
+        return outs
+
+    def chain_dgrad(self, g, specs):
+        """specs: (layer, res, mask) per layer = conv_dgrad(layer, previous output, shape, res, mask) layer by layer."""
+        for (L, _, _) in specs:
+            if L.wdgrad_off < 0:
+                raise H.DcfError("layer %s was planned without an input gradient" % L.name)
+        return self._chain(g, [(self._wbase + L.wdgrad_off, None, r, m, False) for (L, r, m) in specs], 1)
 
     def shortcut_dgrad(self, Ld, dd, L1, g1, in_shape, mask=None):
         """Input gradient of a strided block whose shortcut is a 1x1 / stride-2 conv Ld and whose main path starts with the

@@ -117,6 +117,10 @@ class Block(object):
         d2 = K.bn_bwd(self.conv2, g2)                                                 # identity with folded (eval) BN
         K.conv_wgrad(self.conv2, y1, d2)                                              # also dbeta(bn2) = sum g2
         g1 = K.bn_bwd(self.conv1, K.conv_dgrad(self.conv2, d2, tuple(y1.shape), None, y1))   # fused ReLU mask of y1
+        return self.backward_tail(K, x, g2, g1, extra, need_gx, prev)
+
+    def backward_tail(self, K, x, g2, g1, extra, need_gx, prev):
+        """The rest of backward() from g1 = dL/d(conv1 output, masked) on: conv1's weight gradient, the shortcut, dL/dx."""
         K.conv_wgrad(self.conv1, x, g1)
         pm = x if prev is not None else None
         if self.down is not None:
@@ -134,6 +138,112 @@ class Block(object):
             return None
         assert extra is None, "an identity-shortcut block cannot take an extra gradient"
         return K.conv_dgrad(self.conv1, g1, tuple(x.shape), g2, pm)
+
+
+def blocks_forward(K, blocks, x, save=True):
+    """The blocks of one residual stage, in order (model.py:48-60).  Where the backend can (16-bit storage, folded eval-mode
+    BatchNorm, a layer's tiles in one round of workgroups: HipBackend.can_chain), every 3x3 / stride-1 convolution of the
+    stage behind its first strided one -- block 0's conv2, then conv1 / conv2 of every following block -- runs as ONE chain
+    launch (dcf_conv3x3_chain) instead of one launch each: same kernels, same results, no kernel boundary between layers."""
+    n = len(blocks)
+    ok = (n >= 1 and getattr(K, "can_chain", None) is not None and all(type(b) is Block for b in blocks)
+          and all(b.down is None and b.conv1.stride == 1 for b in blocks[1:]))
+    if ok:
+        b0 = blocks[0]
+        strided = b0.down is not None or b0.conv1.stride != 1 or b0.conv1.cin != b0.conv1.cout
+        nchain = 2 * n - 1 if strided else 2 * n
+        B, Hh, W, _ = x.shape
+        s0 = b0.conv1.stride
+        shape = (B, (Hh + 2 - 3) // s0 + 1, (W + 2 - 3) // s0 + 1, b0.conv1.cout) if strided else tuple(x.shape)
+        ok = nchain >= 2 and all(L.kh == 3 and L.kw == 3 and L.pad == 1 and L.cout == L.cout_pad == shape[3]
+                                 for b in blocks for L in (b.conv1, b.conv2)) and K.can_chain(shape, nchain)
+    if not ok:
+        for b in blocks:
+            x = b.forward(K, x, save)
+        return x
+    specs, ins = [], []                   # per chain layer: (layer, residual, relu); ins[k] = block k's input (tensor or chain index)
+    if strided:
+        r = K.conv_fwd(b0.down, x, None, False) if b0.down is not None else x
+        y1 = K.conv_fwd(b0.conv1, x, None, True)
+        x0 = y1                            # the chain's input
+        specs.append((b0.conv2, r, True))
+        first = 1
+    else:
+        x0 = x
+        first = 0
+    xin = len(specs) - 1                   # chain index of the current block's input (-1: the chain's own input, only when not strided)
+    for b in blocks[first:]:
+        specs.append((b.conv1, None, True))
+        specs.append((b.conv2, xin if xin >= 0 else x, True))
+        xin = len(specs) - 1
+    outs = K.chain_fwd(x0, specs)
+    if save:
+        k = 0
+        if strided:
+            b0.saved = (x, y1, outs[0])
+            k = 1
+        prev = outs[0] if strided else x
+        for b in blocks[first:]:
+            b.saved = (prev, outs[k], outs[k + 1])
+            prev = outs[k + 1]
+            k += 2
+    else:
+        for b in blocks:
+            b.saved = None
+    return outs[-1]
+
+
+def blocks_backward(K, blocks, g, masked, extra0=None, prev0=None, need_gx0=True):
+    """Backward of one stage's blocks, last block first (what the callers' loops over Block.backward did): g = dL/d(stage output),
+    masked = its producer already applied the last block's ReLU mask, extra0 / prev0 / need_gx0 = block 0's `extra`, `prev`
+    and `need_gx`.  Returns (dL/d(stage input) or None, whether it is already masked by prev0's output).  With a chain-capable
+    backend the input-gradient convolutions of the stage -- dgrad(conv2) and dgrad(conv1) of every identity block, last block
+    first, and block 0's dgrad(conv2) -- are one chain launch; the weight gradients are queued as before."""
+    n = len(blocks)
+    ok = (n >= 1 and getattr(K, "can_chain", None) is not None and all(type(b) is Block and b.saved is not None for b in blocks)
+          and all(b.down is None and b.conv1.stride == 1 for b in blocks[1:]))
+    if ok:
+        b0 = blocks[0]
+        strided = b0.down is not None or b0.conv1.stride != 1 or b0.conv1.cin != b0.conv1.cout
+        ident0 = not strided and need_gx0 and extra0 is None       # block 0's dgrad(conv1) joins the chain too
+        nchain = 2 * (n - 1) + 1 + (1 if ident0 else 0)
+        ok = nchain >= 2 and all(L.kh == 3 and L.kw == 3 and L.pad == 1 and L.cout == L.cout_pad == g.shape[3]
+                                 for b in blocks for L in (b.conv1, b.conv2)) and K.can_chain(tuple(g.shape), nchain)
+    if not ok:
+        for bi in range(n - 1, -1, -1):
+            prev = blocks[bi - 1] if bi > 0 else prev0
+            g = blocks[bi].backward(K, g, extra0 if bi == 0 else None, need_gx=(need_gx0 if bi == 0 else True), g_masked=masked, prev=prev)
+            masked = prev is not None
+        return g, masked
+    g2 = g if masked else K.relu_mask(g, blocks[-1].saved[2])
+    specs, wq = [], []                     # chain layers (layer, residual, mask); queued weight gradients (layer, x, gy) with gy a tensor or a chain index
+    cur = g2                               # dL/d(block output), masked: tensor (the chain's input) or chain index
+    for bi in range(n - 1, 0, -1):
+        b = blocks[bi]
+        x, y1, _ = b.saved
+        b.saved = None
+        specs.append((b.conv2, None, y1))                          # g1 = dgrad(conv2, g2) * (y1 > 0)
+        wq.append((b.conv2, y1, cur))
+        ig1 = len(specs) - 1
+        specs.append((b.conv1, cur, x))                            # gx = (dgrad(conv1, g1) + g2) * (x > 0): x is blocks[bi - 1]'s output
+        wq.append((b.conv1, x, ig1))
+        cur = len(specs) - 1
+    x, y1, _ = b0.saved
+    b0.saved = None
+    specs.append((b0.conv2, None, y1))
+    wq.append((b0.conv2, y1, cur))
+    ig1 = len(specs) - 1
+    if ident0:
+        specs.append((b0.conv1, cur, x if prev0 is not None else None))
+    outs = K.chain_dgrad(g2, specs)
+    for (L, xx, gy) in wq:
+        K.conv_wgrad(L, xx, outs[gy] if type(gy) is int else gy)
+    g2_0 = outs[cur] if type(cur) is int else cur
+    if ident0:
+        K.conv_wgrad(b0.conv1, x, outs[ig1])
+        return outs[-1], prev0 is not None
+    gx = b0.backward_tail(K, x, g2_0, outs[ig1], extra0, need_gx0, prev0)
+    return gx, prev0 is not None
 
 
 class Bottleneck(object):
@@ -211,8 +321,7 @@ class StackPlan(object):
         x = K.nchw_to_nhwc(x_nchw)
         outs = {}
         for si, blocks in enumerate(self.stages):
-            for b in blocks:
-                x = b.forward(K, x, save)
+            x = blocks_forward(K, blocks, x, save)
             outs[si] = x
         self.ctx = True if save else None
         return [K.nhwc_to_nchw(outs[t]) for t in self.taps]
@@ -240,11 +349,7 @@ class StackPlan(object):
             blocks = self.stages[si]
             if g is None:
                 g, masked = gmap.get(si), False
-            for bi in range(len(blocks) - 1, -1, -1):
-                extra = gmap.get(si - 1) if bi == 0 else None
-                prev = blocks[bi - 1] if bi > 0 else (self.stages[si - 1][-1] if si > 0 else None)
-                g = blocks[bi].backward(K, g, extra, need_gx=True, g_masked=masked, prev=prev)
-                masked = prev is not None
+            g, masked = blocks_backward(K, blocks, g, masked, gmap.get(si - 1), self.stages[si - 1][-1] if si > 0 else None, True)
         K.end_backward(self.layers)
         return None if g is None else K.nhwc_to_nchw(g)
 
@@ -420,8 +525,7 @@ class Plan(object):
             # a 16-bit x_lidar is already the input image [B,L,W,Cz] (train.geometry_async: written by the voxeliser)
             x = x_lidar if x_lidar.dtype != torch.float32 else K.nchw_to_nhwc(x_lidar)
             for si in (0, 1):
-                for b in self.stages[si]:
-                    x = b.forward(K, x, save)
+                x = blocks_forward(K, self.stages[si], x, save)
             if phase == 1:
                 return x
         else:
@@ -432,8 +536,7 @@ class Plan(object):
         outs = []
         for si in range(1, 5):
             if si > 1:
-                for b in self.stages[si]:
-                    x = b.forward(K, x, save)
+                x = blocks_forward(K, self.stages[si], x, save)
             if fmap is not None:
                 x = self._fusion_forward(K, self.fusion[si - 1], x, fmap, geom, si - 1, save)
             outs.append(x)
@@ -486,20 +589,10 @@ class Plan(object):
         for si in range(4, -1, -1):
             if si >= 1 and c["fused"]:
                 gF = self._fusion_backward(K, self.fusion[si - 1], g, si - 1, gF)
-            blocks = self.stages[si]
-            for bi in range(len(blocks) - 1, -1, -1):
-                first = (si == 0 and bi == 0)
-                extra = extras.get(si - 1) if bi == 0 else None
-                # the block feeding this one: same stage, or the previous stage's last block when no
-                # fusion site sits in between (the fusion backward needs the unmasked gradient)
-                if bi > 0:
-                    prev = blocks[bi - 1]
-                elif si > 0 and not (c["fused"] and si - 1 >= 1):
-                    prev = self.stages[si - 1][-1]
-                else:
-                    prev = None
-                g = blocks[bi].backward(K, g, extra, need_gx=not first, g_masked=masked, prev=prev)
-                masked = prev is not None
+            # the block feeding this stage's first one: the previous stage's last block when no fusion site sits in between
+            # (the fusion backward needs the unmasked gradient)
+            prev0 = self.stages[si - 1][-1] if (si > 0 and not (c["fused"] and si - 1 >= 1)) else None
+            g, masked = blocks_backward(K, self.stages[si], g, masked, extras.get(si - 1), prev0, need_gx0=(si != 0))
             if si == 3:
                 # stages 4-5, the FPN and the heads are complete: two thirds of the LiDAR stream's parameters (data-parallel
                 # runs start that bucket's all-reduce here)
@@ -524,8 +617,7 @@ class Plan(object):
             x, pool_idx = K.maxpool_fwd(c1), None
         feats = []
         for blocks in self.img_stages:
-            for b in blocks:
-                x = b.forward(K, x, save)
+            x = blocks_forward(K, blocks, x, save)
             feats.append(x)
         c2, c3, c4, c5 = feats
         p = K.conv_fwd(self.img_lat[3], c5, None, False)
@@ -554,12 +646,8 @@ class Plan(object):
         g = K.conv_dgrad(self.img_lat[3], gp, tuple(feats[3].shape), None)
         masked = False
         for li in range(3, -1, -1):
-            blocks = self.img_stages[li]
-            for bi in range(len(blocks) - 1, -1, -1):
-                extra = gfeat[li - 1] if (bi == 0 and li > 0) else None
-                prev = blocks[bi - 1] if bi > 0 else (self.img_stages[li - 1][-1] if li > 0 else None)
-                g = blocks[bi].backward(K, g, extra, need_gx=True, g_masked=masked, prev=prev)
-                masked = prev is not None
+            g, masked = blocks_backward(K, self.img_stages[li], g, masked, gfeat[li - 1] if li > 0 else None,
+                                        self.img_stages[li - 1][-1] if li > 0 else None, True)
             if li == 3:
                 K.bucket_ready(self.layers, "image_hi")        # camera layer4 + FPN: three quarters of the camera stream's parameters
         # g = gradient at the max-pool output

@@ -98,6 +98,8 @@ class FrameLoader(object):
         self.device = torch.device(device) if device is not None else None
         if self.device is not None and self.device.type == "cuda" and not torch.cuda.is_available():
             raise RuntimeError("FrameLoader(device='cuda') needs a GPU; pass device=None for host-side batches")
+        if self.device is not None and self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())      # (the staging thread selects it by index)
         kw = dict(batch_size=self.batch_size, sampler=sampler, shuffle=(shuffle and sampler is None), num_workers=num_workers,
                   collate_fn=collate_raw, drop_last=drop_last)
         if num_workers > 0:

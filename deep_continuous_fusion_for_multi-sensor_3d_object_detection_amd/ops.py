@@ -115,6 +115,49 @@ def conv2d_dgrad_halfres(dtype, gy, wt, res, resq, in_shape, kh, kw, stride, pad
     return gx
 
 
+def conv3x3_chain_supported(dtype, B, Hh, W, C, nlayers):
+    """Can dcf_conv3x3_chain run `nlayers` 3x3 / stride-1 layers of C channels on [B,Hh,W,C] in one launch?"""
+    return bool(H.lib().dcf_conv3x3_chain_supported(dtype, B, Hh, W, C, nlayers))
+
+
+def conv3x3_chain_workspace(dtype, B, Hh, W, C, nlayers, device):
+    """Arrival counters of a chain launch, zeroed ONCE here (every launch leaves them zero); int32 tensor."""
+    n = H.lib().dcf_conv3x3_chain_workspace_bytes(dtype, B, Hh, W, C, nlayers)
+    if n == 0:
+        raise H.DcfError("conv3x3_chain: unsupported shape %s x %d layers" % ((B, Hh, W, C), nlayers))
+    return torch.zeros((n // 4,), dtype=torch.int32, device=device)
+
+
+def conv3x3_chain(dtype, x, layers, flip, ws, table=None):
+    """A chain of 3x3 / stride-1 / pad-1 layers with C channels in and out, each reading the one before it, in ONE launch
+    (dcf_hip.h: dcf_conv3x3_chain).  x [B,H,W,C]; layers = list of (w, shift, res, mask, relu) where w / shift are tensors or
+    raw device addresses and res / mask are tensors, None, or an int k = "the output of chain layer k" (k <= l - 2).
+    flip = 1: input gradients (w = the [Cin][tap][Cout] images).  Returns the list of outputs (new tensors).
+    table: a ctypes (H.ChainLayer * n) to reuse between calls (the caller keeps it alive)."""
+    B, Hh, W, C = x.shape
+    n = len(layers)
+    outs = [torch.empty((B, Hh, W, C), dtype=x.dtype, device=x.device) for _ in range(n)]
+    tab = table if table is not None else (H.ChainLayer * n)()
+    cur = x.data_ptr()
+    for l, (w, shift, res, mask, relu) in enumerate(layers):
+        it = tab[l]
+        it.x = cur
+        it.w = H._ptr(w)
+        it.shift = H._ptr(shift)
+        it.res = outs[res].data_ptr() if type(res) is int else H._ptr(res)
+        it.mask = outs[mask].data_ptr() if type(mask) is int else H._ptr(mask)
+        cur = it.y = outs[l].data_ptr()
+        it.relu = 1 if relu else 0
+    import ctypes
+    H.call("dcf_conv3x3_chain", dtype, ctypes.addressof(tab), n, B, Hh, W, C, int(flip), ws, H.stream_ptr())
+    return outs
+
+
+def conv3x3_chain_status(ws):
+    """The give-up record of the last chain launches on workspace ws (0 = every wait was satisfied); synchronises."""
+    return int(ws[1].item())
+
+
 def conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, kh, kw, stride=1):
     return H.lib().dcf_conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, kh, kw, stride)
 

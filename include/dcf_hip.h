@@ -172,6 +172,33 @@ int dcf_conv2d_dgrad(int dtype, const void *gy, const void *wt, const void *res,
 int dcf_conv2d_dgrad_halfres(int dtype, const void *gy, const void *wt, const void *res, const void *resq,
                              const void *mask, void *gx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
                              int kh, int kw, int stride, int pad, dcf_stream_t stream);
+/* ---- A CHAIN of 3x3 / stride-1 / pad-1 layers with C channels in and out, each reading the one before it, in ONE launch
+ * (csrc/conv_rs.hip, chain mode): the bodies of a residual stage -- /root/reference/model.py:32-41, conv1 -> bn1 -> relu ->
+ * conv2 -> bn2 -> += shortcut -> relu, block after block (model.py:48-60) -- forward, or (flip = 1, weights = the
+ * [Cin][tap][Cout] images) the same list backwards for the input gradients.  Layer l computes exactly what
+ *   dcf_conv2d_fwd(dtype, x, w, shift, res, y, B, H, W, C, H, W, C, 3, 3, 1, 1, relu)            (flip = 0)
+ *   dcf_conv2d_dgrad(dtype, x, w, res, mask, y, B, H, W, C, H, W, C, 3, 3, 1, 1)                 (flip = 1; shift / relu unused)
+ * computes with its row-sharing kernel -- bit-identical results -- but a workgroup moves from its tile of layer l to its tile of
+ * layer l + 1 as soon as the neighbouring tiles of layer l are complete (per-tile arrival counters, write-through stores, sc1
+ * loads: no kernel boundary, no grid-wide wait).  layers is a HOST array; layers[l].x must be layers[l - 1].y; res may be
+ * any tensor written before the launch or the y of a layer at least two back; outputs must be distinct tensors.
+ * ws: dcf_conv3x3_chain_workspace_bytes(...) bytes, ZEROED ONCE by the caller when allocated (the launch leaves it zero);
+ * one workspace per stream of launches.  dcf_conv3x3_chain_supported: 16-bit dtypes, C % 64 == 0, a layer's tiles fit one
+ * round of workgroups (option CONV_CHAIN=0 answers no).  A workgroup whose bounded wait expires writes a record to
+ * ((int32_t *)ws)[1] (0 = none; 0x40000000 | layer << 16 | position tile) and stops waiting: results are then wrong, the GPU
+ * is not hung; callers that want to know copy that word back (tests do after every launch). */
+#define DCF_CHAIN_MAX_LAYERS 24
+typedef struct {
+    const void *x, *w;
+    const float *shift;        /* fp32 [C] or NULL */
+    const void *res, *mask;    /* dtype [B,H,W,C] or NULL */
+    void *y;
+    int32_t relu, pad_;
+} dcf_chain_layer;
+int dcf_conv3x3_chain_supported(int dtype, int B, int H, int W, int C, int nlayers);
+size_t dcf_conv3x3_chain_workspace_bytes(int dtype, int B, int H, int W, int C, int nlayers);
+int dcf_conv3x3_chain(int dtype, const dcf_chain_layer *layers, int nlayers, int B, int H, int W, int C, int flip,
+                      void *ws, dcf_stream_t stream);
 /* Weight gradient, split over pixel ranges: slabs fp32 [nsplit][Cout][kh][kw][Cin] (plain stores,
  * reduced in fixed order by dcf_wgrad_finalize => bitwise reproducible).
  * gsum (optional) fp32 [4*nsplit][Cout]: per-wave sums over pixels of gy (dL/dbeta of a folded BN),

@@ -648,3 +648,54 @@ def test_lidar_backbone_network_optimizer_built_before_the_first_forward_trains_
     with torch.no_grad():
         cls2, _ = net(x)
     assert float((cls2 - cls).abs().max()) > 0          # the forward reads the updated weights
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_chain_launches_equal_per_layer_launches_at_cfg2_size(fused):
+    """the 3x3 / stride-1 layers of a residual stage as ONE chain launch (dcf_conv3x3_chain) against the
+    same layers as one launch each, on the cfg2 step shape (704x800 grid, batch 2, bf16): forward outputs and the whole
+    gradient arena.  LiDAR stream alone: bit for bit (same kernels, same summation order; nothing else in that path is
+    order-dependent).  With the camera stream and the four fusion sites: the fusion backward's float atomics leave ~1e-5 of
+    run-to-run noise on an fp32 model, more through bf16 -- bounded at 2e-2 of the largest gradient, forward still bit-exact.
+    Also checks that the chain launches really ran (profile names) and that no workgroup gave up waiting."""
+    det, calib, D, T, H = pkg("detfill"), pkg("calib"), pkg("data_import_carla"), pkg("train"), pkg("_hip")
+    lim6 = (0.0, 70.4, -40.0, 40.0, -2.4, 0.8)
+    crt = calib.kitti_like_crt()
+    pts = [torch.from_numpy(det.synthetic_points(100000, lim6, 51 + b)).cuda() for b in range(2)]
+    img = torch.stack([torch.from_numpy(det.synthetic_image(375, 1242, 51 + b)) for b in range(2)], 0).cuda()
+    cfg = _cfg2_config("bf16", batch=2, fusion=fused)
+    tr = T.Train(cfg)
+    det.fill_state_dict(tr.model)
+    geo = D.FrameGeometry(cfg, crt)
+    R, out = None, {}
+    for chain in (False, True):
+        x_lidar, geom = tr.geometry_async(geo, pts)
+        torch.cuda.synchronize()
+        K = tr.model._ensure_backend(x_lidar.device)
+        K.chain_enabled = chain
+        H.call("dcf_prof_reset")
+        H.call("dcf_prof_enable", 1)
+        try:
+            pred = tr.model(x_lidar, img, geom=geom)
+            if R is None:
+                R = torch.from_numpy(det.uniform(tuple(pred.shape), 99, -1.0, 1.0)).cuda()
+                R[:, 18:] = 0
+            (pred * R).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            H.call("dcf_prof_enable", 0)
+        names = list(H.prof_read())
+        H.call("dcf_prof_reset")
+        nchain = [n for n in names if n.startswith(("conv_fwd", "conv_dgrad")) and ",x" in n]
+        assert bool(nchain) == chain, names
+        if chain:
+            assert any(n.startswith("conv_fwd") for n in nchain) and any(n.startswith("conv_dgrad") for n in nchain), nchain
+            for ws in K._chain_ws.values():
+                assert int(ws[1].item()) == 0, "a chain workgroup gave up waiting"
+        out[chain] = (pred.detach().clone(), tr.model.flat_grads.clone())
+    (p0, g0), (p1, g1) = out[False], out[True]
+    assert torch.equal(p0, p1), "forward differs: max abs %g" % float((p0 - p1).abs().max())
+    if not fused:
+        assert torch.equal(g0, g1), "gradient arena differs: max abs %g of %g" % (float((g0 - g1).abs().max()), float(g0.abs().max()))
+    else:
+        assert float((g0 - g1).abs().max() / g0.abs().max()) < 2e-2
