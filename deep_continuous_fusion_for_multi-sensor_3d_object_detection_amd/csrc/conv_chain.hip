@@ -99,3 +99,17 @@ extern "C" int dcf_conv3x3_chain(int dtype, const dcf_chain_layer *layers, int n
 #undef DCF_RSC
     return DCF_OK;
 }
+
+#ifdef RS_STAMP
+// (variant builds only; tools/chain_stamps.py)
+extern "C" int dcf_rs_stamps_read(long long *dst, int *dims)
+{
+    dims[0] = RS_STAMP_WGS; dims[1] = RS_STAMP_ITEMS; dims[2] = 10;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rs_stamps), sizeof(g_rs_stamps)) == hipSuccess ? 0 : -1;
+}
+extern "C" int dcf_rs_stamps_clear(void)
+{
+    static long long zero[RS_STAMP_WGS][RS_STAMP_ITEMS][10];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_rs_stamps), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -75,6 +75,19 @@ struct RsArgs {
 //     host reports DCF_ELAUNCH-class failure through dcf_conv3x3_chain_status -- wrong results, never a hung GPU;
 //   * the counters are zero at every launch: the host zeroes the workspace once when it is created, the workgroup that
 //     finishes last (ws[0]) zeroes them again.
+// -DRS_STAMP (variant builds only: KFILE=conv_chain bash tools/rw_variants.sh stamp="-DRS_STAMP"; tools/chain_stamps.py): wave 0 of
+// every workgroup keeps s_memtime stamps of a work item's phases in scalar registers and writes them out when the item is done:
+//   0 item start (before the wait for the previous layer's tiles)   1 wait satisfied   2 first DMA groups issued
+//   3 first stage's data landed (first MFMAs)   4 last MFMA issued   5 DMA tail drained   6 epilogue stores issued
+//   7 stores drained   8 arrival published
+#ifdef RS_STAMP
+#define RS_STAMP_WGS 256
+#define RS_STAMP_ITEMS 32
+__device__ long long g_rs_stamps[RS_STAMP_WGS][RS_STAMP_ITEMS][10];
+#define RS_T(k) do { if constexpr (CHAIN) { if (wid == 0) stamp[k] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define RS_T(k) do { } while (0)
+#endif
 #define RS_CHAIN_MAX 24
 struct RsChainLayer {
     const char *x, *w;
@@ -290,6 +303,15 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(typename std::condi
         res = reinterpret_cast<const T *>(pr);
         mask = reinterpret_cast<const T *>(pm);
     };
+    auto bind_weights = [&](int l) __attribute__((always_inline)) {          // chain mode: the weights of layer l only (prefetch)
+        if constexpr (CHAIN) {
+            typedef const __attribute__((address_space(4))) char *kconst_t;
+            const kconst_t kp = (kconst_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(RsChainArgs, L) +
+                                (size_t)__builtin_amdgcn_readfirstlane(l) * sizeof(RsChainLayer);
+            pw = (const char *)((const __attribute__((address_space(4))) unsigned long long *)kp)[1];
+            srcW = __builtin_amdgcn_make_buffer_rsrc((void *)rs_uniform(pw), 0, a.wbytes, 0x00020000);
+        }
+    };
     bind_layer(0);
     constexpr unsigned OOB = 0xFFFFFF00u;
     const unsigned ldsW0 = lds_addr(lds), ldsX0 = ldsW0 + NSW * WSLOT;
@@ -347,6 +369,10 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(typename std::condi
     // chain mode: wait until the tiles of the previous layer that tile (layer, q0) reads are complete.  Wave 0 polls, one counter
     // per lane; the others wait at the barrier it joins afterwards.
     bool gave_up = false;
+#ifdef RS_STAMP
+    long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int item = 0;
+#endif
     auto chain_wait = [&]() __attribute__((always_inline)) {
         if constexpr (CHAIN) {
             if (layer == 0) return;
@@ -544,33 +570,46 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(typename std::condi
                     gldsX(srcX, (((xok[j] >> ki) & 1) && !(DCF_DBG(a) & 2)) ? (unsigned)(xbase[j] + xst[d]) : OOB, dst);
                 }
         };
-        auto begin_tile = [&]() __attribute__((always_inline)) {                                      // stage bookkeeping of a fresh tile + its first groups
-            lki = 0; lcc = 0;
+        // stage bookkeeping of a fresh tile + its first groups.  WPART / XPART: issue the weight / the pixel pieces of those groups
+        // (both: the plain kernel's prologue; chain mode issues the weights of the next item before it stores the current one --
+        // they depend on nothing -- and the pixels once the tiles they come from have been published)
+        auto begin_tile_parts = [&](auto WPART, auto XPART) __attribute__((always_inline)) {
+            constexpr bool DOW = decltype(WPART)::value, DOX = decltype(XPART)::value;
+            if constexpr (DOW) {
+                lki = 0; lcc = 0;
 #pragma unroll
-            for (int d = 0; d <= DS; ++d) stage_entry(d);
+                for (int d = 0; d <= DS; ++d) stage_entry(d);
+            }
         // prologue: groups -3 DX .. -1, then everything landed (the first taps need their data at once anyway)
             {
                 int wsl = 0, xsl = 0;
                 if constexpr (S3) {
 #pragma unroll
                     for (int sv = 0; sv < DX; ++sv) {
-                        issue_x(sv, sv, 0, CX);
+                        if constexpr (DOX) issue_x(sv, sv, 0, CX);
+                        if constexpr (DOW)
 #pragma unroll
-                        for (int kw = 0; kw < 3; ++kw) issue_w(sv, kw, sv * 3 + kw);
+                            for (int kw = 0; kw < 3; ++kw) issue_w(sv, kw, sv * 3 + kw);
                     }
                 } else
 #pragma unroll
                 for (int u = -3 * DX; u < 0; ++u) {
                     const int v = u + 3 * DX, sv = v / 3, kj = v - 3 * sv;                 // pixel tile of stage sv < DX
-                    if (kj == 0) issue_x(sv, xsl, 0, PXA);
-                    if (kj == 1) { issue_x(sv, xsl, PXA, CX); ++xsl; }
-                    if (u + DW >= 0) { issue_w((u + DW) / 3, (u + DW) % 3, wsl); ++wsl; }
+                    if constexpr (DOX) {
+                        if (kj == 0) issue_x(sv, xsl, 0, PXA);
+                        if (kj == 1) issue_x(sv, xsl, PXA, CX);
+                    }
+                    if (kj == 1) ++xsl;
+                    if (u + DW >= 0) { if constexpr (DOW) issue_w((u + DW) / 3, (u + DW) % 3, wsl); ++wsl; }
                 }
             }
         };
+        auto begin_tile = [&]() __attribute__((always_inline)) { begin_tile_parts(std::true_type(), std::true_type()); };
+        RS_T(0); RS_T(1);
         begin_tile();
 #pragma unroll
         for (int k = 0; k < ST; ++k) gst16_dummy(dstY);      // stand-ins for a previous tile's stores
+        RS_T(2);
         for (;;) {
         if constexpr (CHAIN) make_descs();
         int wsr = 0, wsi = DW % NSW, xsr = 0, xsi = DX % NSX;         // ring slots: read / issue
@@ -581,6 +620,9 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(typename std::condi
                     if (kj == 0) {
                         if (s < DX) wait_vmcnt<AS + ST>(); else wait_vmcnt<AS>();
                         __builtin_amdgcn_s_barrier();
+#ifdef RS_STAMP
+                        if (s == 0) RS_T(3);
+#endif
                     }
                 } else {
                     const bool early = 3 * s + kj < (kj == 0 ? BK0 : DW);       // the group this step needs went out before the stores
@@ -588,6 +630,9 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(typename std::condi
                     else if (kj == 1) { if (early) wait_vmcnt<A1 + ST>(); else wait_vmcnt<A1>(); }
                     else { if (early) wait_vmcnt<A2 + ST>(); else wait_vmcnt<A2>(); }
                     __builtin_amdgcn_s_barrier();
+#ifdef RS_STAMP
+                    if (s == 0 && kj == 0) RS_T(3);
+#endif
                 }
                 // (issuing the second half-workgroup's DMA after its MFMAs instead -- waves w and w + 4 share a SIMD -- was
                 // measured: no gain, 26.7 -> 27.3 us on the 128-channel stage)
@@ -671,28 +716,52 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(typename std::condi
             for (int d = 0; d < DS; ++d) { wst[d] = wst[d + 1]; xst[d] = xst[d + 1]; kis[d] = kis[d + 1]; }
             stage_entry(DS);
         }
+        RS_T(4);
         wait_vmcnt<0>();              // the trailing dummy pieces still target this workgroup's LDS
+        RS_T(5);
         const int q0c = q0, n0c = n0;
         if constexpr (CHAIN) {
-            // publish this tile, then move on to the next work item -- (layer, next tile of this workgroup) or (layer + 1, its
-            // first tile) -- once the tiles that one reads have been published.  Nothing of the next tile is prefetched under
-            // this epilogue: its pixels may not exist yet (every tile of a chain starts like the first tile of a launch).
+            // Publish this tile, then move on to the next work item -- (layer, next tile of this workgroup) or (layer + 1, its
+            // first tile) -- once the tiles that one reads have been published.  The next item's first WEIGHT groups go out
+            // before this tile's epilogue (they depend on nothing and land under the epilogue, the store drain and the wait);
+            // its pixels may not exist yet and follow the wait.
+            int ngidx = gidx + wpx, nlayer = layer;
+            if (ngidx >= chunk_hi) { nlayer = __builtin_amdgcn_readfirstlane(layer + 1); ngidx = gidx_first; }
+            const bool more = nlayer < arg.nlayers;
+            if (more) {
+                __builtin_amdgcn_s_barrier();                          // every wave is done with the rings
+                if (nlayer != layer) bind_weights(nlayer);
+                if (ngidx != gidx) setup_tile(ngidx);                  // (one tile per layer: the DMA offsets of the tile stay)
+                begin_tile_parts(std::true_type(), std::false_type());
+            }
             store_tile(q0c, n0c);
+            RS_T(6);
             wait_vmcnt<0>();                                           // EVERY storing wave drains its write-through stores ...
+            RS_T(7);
             __builtin_amdgcn_s_barrier();                              // ... before one lane signals for all (and the rings are idle)
             if (tid == 0) __hip_atomic_fetch_add(arg.ws + 4 + layer * a.mtiles + q0c / BM, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            gidx += wpx;
-            if (gidx >= chunk_hi) {
-                layer = __builtin_amdgcn_readfirstlane(layer + 1);
-                if (layer == arg.nlayers) break;
-                gidx = gidx_first;
-                bind_layer(layer);
-            }
-            setup_tile(gidx);
-            chain_wait();
-            begin_tile();
+            RS_T(8);
+#ifdef RS_STAMP
+            if (tid == 0 && blockIdx.x < RS_STAMP_WGS && item < RS_STAMP_ITEMS) {
 #pragma unroll
-            for (int k = 0; k < ST; ++k) gst16_dummy(dstY);
+                for (int k9 = 0; k9 < 9; ++k9) g_rs_stamps[blockIdx.x][item][k9] = stamp[k9];
+                g_rs_stamps[blockIdx.x][item][9] = ((long long)layer << 32) | (unsigned)(q0c / BM * nt + n0c / BN);
+            }
+            ++item;
+#endif
+            if (!more) break;
+            gidx = ngidx;
+            if (nlayer != layer) { layer = nlayer; bind_layer(layer); }
+            RS_T(0);
+            chain_wait();
+            RS_T(1);
+            begin_tile_parts(std::false_type(), std::true_type());
+            RS_T(2);
+            // Everything of the first groups has to have landed before the loop's counted waits take over: they price the
+            // prologue's groups in the plain kernel's issue order (weights and pixels interleaved, then the stores), which this
+            // split order is not; with nothing outstanding here every such wait is trivially met, and the waits of the later
+            // steps count main-loop groups only.
+            wait_vmcnt<0>();
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
