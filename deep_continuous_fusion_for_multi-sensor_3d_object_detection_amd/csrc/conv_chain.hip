@@ -17,6 +17,11 @@ bool rs_chain_plan(int dtype, int B, int H, int W, int C, RsPlan *plan, int *nwg
     const int BN = RS_KINDS[p.kind].BN, BM = 32 * p.npt;
     const int64_t mtiles = (Q + BM - 1) / BM, nblk = mtiles * (C / BN);
     if (nblk > 256 * RS_KINDS[p.kind].per_cu) return false;                   // more than one round: the plain launches do better
+    // More than four channel tiles per position tile: a tile then waits for 3 x 8 or more of a layer's ~90 tiles, which is a
+    // grid-wide wait in all but name -- measured on the 512-channel 12x39 camera layers: 21.6 us per layer chained against 19.8
+    // as separate launches (profiles/r05e_chain_time.txt); the other cfg2 stages are level or ahead.  Option CHAIN_WIDE=1 lifts it.
+    static DcfOpt wide_o("CHAIN_WIDE"); const char *wide = wide_o.str();
+    if (C / BN > 4 && !(wide && atoi(wide) == 1)) return false;
     if ((2 * (W + 3) + BM - 1) / BM + 2 > 64) return false;                   // halo tiles polled one per lane
     *plan = p;
     *nwg = (int)((nblk + 7) / 8 * 8);

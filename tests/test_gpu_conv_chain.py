@@ -28,6 +28,16 @@ SHAPES = [
 ]
 
 
+@pytest.fixture(autouse=True)
+def _wide_chains():
+    """The 512-channel shapes are outside the automatic policy (conv_chain.hip: more than four channel tiles); the hand-off is
+    tested on them all the same."""
+    H = pkg("_hip")
+    H.set_option("CHAIN_WIDE", 1)
+    yield
+    H.set_option("CHAIN_WIDE", None)
+
+
 def _weights(C, n, dtype, seed):
     return [to_dev(q(rnd((C, C, 3, 3), seed + i, -0.05, 0.05), dtype), dtype).contiguous() for i in range(n)]    # [Cout][kh][kw][Cin]
 
@@ -156,6 +166,10 @@ def test_chain_rejects_what_it_cannot_run():
     assert not ops.conv3x3_chain_supported(1, 2, 44, 50, 96, 4)             # channels not a multiple of 64
     assert not ops.conv3x3_chain_supported(1, 8, 176, 200, 128, 4)          # more than one round of workgroups
     assert not ops.conv3x3_chain_supported(1, 2, 44, 50, 256, H.CHAIN_MAX_LAYERS + 1)
+    H.set_option("CHAIN_WIDE", None)
+    assert not ops.conv3x3_chain_supported(1, 2, 12, 39, 512, 3)           # eight channel tiles per position tile: not automatic
+    H.set_option("CHAIN_WIDE", 1)
+    assert ops.conv3x3_chain_supported(1, 2, 12, 39, 512, 3)
     x = torch.zeros((2, 44, 50, 256), device="cuda", dtype=torch.bfloat16)
     w = torch.zeros((256, 3, 3, 256), device="cuda", dtype=torch.bfloat16)
     ws = ops.conv3x3_chain_workspace(1, 2, 44, 50, 256, 2, "cuda")
