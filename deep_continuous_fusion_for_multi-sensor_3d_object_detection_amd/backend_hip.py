@@ -123,8 +123,38 @@ class HipBackend(object):
         return self._ssbase + 4 * (L.shift_off + L.cout_pad)
 
     # ------------------------------------------------------------------ step phases
+    def check_chains(self):
+        """Chain launches bound their waits (a workgroup that gives up records it in its workspace and the results of that launch
+        are wrong): once per step the give-up words of every chain workspace are copied to pinned memory asynchronously, and the
+        copies of the PREVIOUS step are looked at -- no synchronisation on the step's own path, an error one step late at worst."""
+        if not self._chain_ws or torch.cuda.is_current_stream_capturing():
+            return
+        pend = self.__dict__.get("_chain_pending")
+        if pend is not None and pend[1].query():
+            bad = pend[0][:pend[2]].nonzero()
+            if bad.numel():
+                rec = int(pend[0][int(bad[0])])
+                self._chain_pending = None
+                for ws in self._chain_ws.values():
+                    ws[1:2].zero_()                     # reported once: the next steps start clean
+                raise H.DcfError("a chain launch (dcf_conv3x3_chain) gave up waiting at layer %d, position tile %d: the results of that "
+                                 "step are wrong (another kernel kept part of the launch's workgroups off the GPU for longer than its spin "
+                                 "limit?  DCF_CHAIN=0 runs every layer as its own launch)" % ((rec >> 16) & 0x3fff, rec & 0xffff))
+            self._chain_pending = pend = None
+        if pend is None:
+            wss = list(self._chain_ws.values())
+            host = self.__dict__.get("_chain_host")
+            if host is None or host.numel() < len(wss):
+                host = self._chain_host = torch.zeros((max(16, len(wss)),), dtype=torch.int32).pin_memory()
+            for i, ws in enumerate(wss):
+                host[i:i + 1].copy_(ws[1:2], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._chain_pending = (host, ev, len(wss))
+
     def prepare(self):
         """Once per step, before forward: fold BN into the compute-dtype weight images."""
+        self.check_chains()
         H.call("dcf_weight_prep", self.dtype, self.table, self.nconv, self.params, self.buffers, self.warena, self.ssarena,
                BN_EPS, H.stream_ptr())
         if self.has_fp8 and not self.bn_train:

@@ -6,7 +6,7 @@
 // flop/B, below the chip's ridge, so what bounds them is how few bytes move and how well the moves overlap.  The implicit-GEMM
 // kernels walk K tap by tap and stage a pixel once per tap (conv.hip) or once per kernel row (conv_rs.hip): 9x / 3x the
 // tensor through the L2 -> LDS path, and each workgroup's fetch latency, nine tap steps and store burst serialise (measured
-// 2.5-2.8 TB/s).  Here:
+// 2.5-2.8 TB/s, EXPERIMENTS.md, round 3).  Here:
 //
 //   * ONE staging per pixel.  A workgroup owns a TH x 32 output tile of one frame and DMAs the (TH + 2) x 34 input pixels
 //     (`buffer_load ... lds`, image borders and tile tails as out-of-range offsets = zeros) into LDS once; all nine taps read

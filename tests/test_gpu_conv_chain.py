@@ -175,3 +175,32 @@ def test_chain_rejects_what_it_cannot_run():
     ws = ops.conv3x3_chain_workspace(1, 2, 44, 50, 256, 2, "cuda")
     with pytest.raises(H.DcfError):
         ops.conv3x3_chain(1, x, [(w, None, 1, None, True), (w, None, None, None, True)], 0, ws)       # layer 0's residual is layer 1's output
+
+
+def test_give_up_is_reported_one_step_later():
+    """HipBackend.check_chains: a chain workgroup that gives up leaves a record in its workspace; the backend copies the records out
+    asynchronously once per step and raises when the previous step's copy shows one."""
+    import copy
+    import yaml, os
+    from _util import ROOT, PKG
+    cfg = yaml.safe_load(open(os.path.join(ROOT, PKG, "config", "config_carla.yaml")))
+    cfg.update(dict(voxel_length=64, voxel_width=64, dtype="bf16"))
+    cfg["lidar_module"] = dict(out_feature1=32, out_feature2=64, out_feature3=128, out_feature4=192, out_feature5=256,
+                               num_res_block1=1, num_res_block2=2, num_res_block3=2, num_res_block4=2, num_res_block5=2)
+    net = pkg("model").ObjectDetection_DCF(cfg).cuda()
+    pkg("detfill").fill_state_dict(net)
+    x = torch.rand((1, 32, 64, 64), device="cuda")
+    img = torch.zeros((1, 3, 8, 8), dtype=torch.uint8, device="cuda")
+    with torch.no_grad():
+        net(x, img)
+        K = net._backend
+        assert K._chain_ws, "the stages of this model should run as chain launches"
+        net(x, img); torch.cuda.synchronize(); net(x, img)          # clean steps: nothing raised
+        next(iter(K._chain_ws.values()))[1] = 0x40000000 | (3 << 16) | 5      # what a workgroup that gave up would leave
+        torch.cuda.synchronize()
+        K._chain_pending = None
+        net(x, img)                                                 # copies the record out
+        torch.cuda.synchronize()
+        with pytest.raises(pkg("_hip").DcfError) as e:
+            net(x, img)
+        assert "layer 3" in str(e.value) and "tile 5" in str(e.value)

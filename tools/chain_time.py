@@ -37,4 +37,6 @@ def run(shape, n, chain):
 
 for shape, n in (((2, 44, 50, 256), 11), ((2, 88, 100, 192), 11), ((2, 176, 200, 128), 7), ((2, 94, 311, 64), 4), ((2, 47, 156, 128), 3),
                  ((2, 24, 78, 256), 3), ((2, 12, 39, 512), 3), ((1, 44, 50, 256), 11), ((1, 88, 100, 192), 11), ((1, 176, 200, 128), 7)):
+    if not ops.conv3x3_chain_supported(1, shape[0], shape[1], shape[2], shape[3], n):
+        importlib.import_module(PKG + "._hip").set_option("CHAIN_WIDE", 1)          # (outside the automatic policy: timed all the same)
     print(shape, n, "us/layer: separate %.2f  chain %.2f" % (run(shape, n, False), run(shape, n, True)))
