@@ -397,6 +397,12 @@ class HipBackend(object):
         (dcf_conv3x3_chain: 16-bit storage, eval-mode BatchNorm folded into the weights, no fp8 images, one round of tiles)?"""
         if not self.chain_enabled or n < 2 or self.bn_train or self.has_fp8 or self.dtype == H.F32:
             return False
+        # Data-parallel runs (a gradient-bucket hook is installed: RCCL kernels then run beside the backward) keep the per-layer
+        # launches: a chain launch needs all its workgroups resident at once, and what RCCL's persistent kernels leave free on a CU
+        # has never been measured here (no multi-GPU box); the chains are level on time (DESIGN.md section 9), so nothing is lost.
+        # DCF_CHAIN=force overrides.
+        if self.bucket_hook is not None and os.environ.get("DCF_CHAIN") != "force":
+            return False
         key = tuple(shape)
         ok = self._chain_ok.get(key)
         if ok is None:
