@@ -432,6 +432,8 @@ def main():
     ap.add_argument("--no-other-leg", action="store_true", help="skip the second leg (the input mode that is not timed as `value`)")
     ap.add_argument("--loss-sampling", default="compat", help="compat = host target assignment on numpy's generator exactly like the reference's "
                     "loss.py:74-127 (default, the mode pinned to the reference); device = assignment + loss in one launch (csrc/loss.hip)")
+    ap.add_argument("--chain", action="store_true", help="run the residual stages' 3x3 layers as chain launches (dcf_conv3x3_chain: one launch per "
+                    "stage; needs the GPU to itself; level on time with the per-layer launches, DESIGN.md section 9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -444,6 +446,8 @@ def main():
     image_wh = tuple(int(v) for v in args.image.lower().split("x"))
     cfg = kitti_config(args.batch, args.dtype, args.points, args.knn, args.image_stream, image_wh)
     cfg["bn_mode"] = args.bn_mode
+    if args.chain:
+        cfg["conv_chain"] = True
     cfg["loss_sampling"] = args.loss_sampling
     global PMC_TAG
     key = (args.points, args.knn, args.image_stream, args.batch, args.dtype, args.image.lower())
@@ -566,7 +570,7 @@ def main():
                           "from_host_ms_per_step": from_host["ms_per_step"] if from_host else (round(dt / args.steps * 1e3, 3) if args.from_host else None),
                           "resident_frames_per_s": resident["value"] if resident else (None if args.from_host else round(frames / dt, 3)),
                           "resident_ms_per_step": resident["ms_per_step"] if resident else (None if args.from_host else round(dt / args.steps * 1e3, 3)),
-                          "loss_sampling": args.loss_sampling},
+                          "loss_sampling": args.loss_sampling, "conv_chain": bool(args.chain or os.environ.get("DCF_CHAIN") in ("1", "force"))},
                "roofline": roof, "cpu_baseline": cpu, "from_host": from_host, "resident": resident, "kernel_classes": classes, "kernel_breakdown": breakdown}
         print(json.dumps(out))
     if ws > 1:

@@ -390,19 +390,26 @@ class HipBackend(object):
         return gx
 
     # ------------------------------------------------------------------ chains (one launch per residual stage)
-    chain_enabled = os.environ.get("DCF_CHAIN", "1") != "0"
+    # OFF unless asked for (config `conv_chain: true`, or DCF_CHAIN=1 / force in the environment).  A chain launch needs ALL its
+    # workgroups resident at once, which holds when the process has the GPU to itself; two processes sharing one GPU (the
+    # two-ranks-on-one-GPU functional test, MPS-style serving) each get part of the CUs and their chain launches starve each other
+    # until the bounded spins give up -- found by exactly that test once give-ups were reported (check_chains).  The chains are level
+    # with the per-layer launches on time, so the safe form is the default.
+    chain_enabled = os.environ.get("DCF_CHAIN", "0") in ("1", "force")
 
     def can_chain(self, shape, n):
         """Can `n` consecutive 3x3 / stride-1 layers on activations of `shape` [B,H,W,C] run as chain launches
         (dcf_conv3x3_chain: 16-bit storage, eval-mode BatchNorm folded into the weights, no fp8 images, one round of tiles)?"""
         if not self.chain_enabled or n < 2 or self.bn_train or self.has_fp8 or self.dtype == H.F32:
             return False
-        # Data-parallel runs (a gradient-bucket hook is installed: RCCL kernels then run beside the backward) keep the per-layer
-        # launches: a chain launch needs all its workgroups resident at once, and what RCCL's persistent kernels leave free on a CU
-        # has never been measured here (no multi-GPU box); the chains are level on time (DESIGN.md section 9), so nothing is lost.
-        # DCF_CHAIN=force overrides.
-        if self.bucket_hook is not None and os.environ.get("DCF_CHAIN") != "force":
-            return False
+        # Data-parallel runs (RCCL kernels run beside the backward; functional runs may even put two ranks on one GPU) keep the
+        # per-layer launches: a chain launch needs all its workgroups resident at once, and what RCCL's persistent kernels leave
+        # free on a CU has never been measured here (no multi-GPU box); the chains are level on time (DESIGN.md section 9), so
+        # nothing is lost.  DCF_CHAIN=force overrides.
+        if os.environ.get("DCF_CHAIN") != "force":
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                return False
         key = tuple(shape)
         ok = self._chain_ok.get(key)
         if ok is None:

@@ -428,6 +428,8 @@ class ObjectDetection_DCF(_FlatParamModule):
             self._backend = HipBackend(self._plan, self._flat, self._gradflat, self._bufflat, self.dtype,
                                        fp8_min_cin=int(self.config.get("fp8_min_cin", 128)) if self.fp8 else 0,
                                        fp8_min_blocks=int(self.config.get("fp8_min_blocks", 512)))
+            if self.config.get("conv_chain") is not None:          # residual stages as chain launches (exclusive use of the GPU only)
+                self._backend.chain_enabled = bool(self.config["conv_chain"])
         return self._backend
 
     KNN_SHARED_MAX_PIXELS = 20000      # sites up to this many pixels (stride 8 and 16 at cfg2) are searched on the finest site's cells

@@ -184,7 +184,7 @@ def test_give_up_is_reported_one_step_later():
     import yaml, os
     from _util import ROOT, PKG
     cfg = yaml.safe_load(open(os.path.join(ROOT, PKG, "config", "config_carla.yaml")))
-    cfg.update(dict(voxel_length=64, voxel_width=64, dtype="bf16"))
+    cfg.update(dict(voxel_length=64, voxel_width=64, dtype="bf16", conv_chain=True))
     cfg["lidar_module"] = dict(out_feature1=32, out_feature2=64, out_feature3=128, out_feature4=192, out_feature5=256,
                                num_res_block1=1, num_res_block2=2, num_res_block3=2, num_res_block4=2, num_res_block5=2)
     net = pkg("model").ObjectDetection_DCF(cfg).cuda()
