@@ -421,7 +421,8 @@ def main():
     ap.add_argument("--bn-mode", default="eval", help="eval = what the reference's train.py really does (F4); train = batch statistics")
     ap.add_argument("--graphs", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
                     help="captured forward/backward HIP graphs instead of eager launches: auto (default) = at batch 1 on one GPU, where "
-                    "the step runs at the host's pace (251 against 200 frames/s); at batch >= 2 the step is kernel-bound")
+                    "eager launches leave the GPU waiting for the host on slower hosts (round 5, two boxes: 254.9 against 250.4 and 250.4 against 216.6 "
+                    "frames/s, profiles/r05a_* / r05b_*; the compute queue is 96 % busy under replay, profiles/r05f_timeline_b1.txt); at batch >= 2 the step is kernel-bound")
     ap.add_argument("--input", default="host", choices=["host", "resident"],
                     help="where the timed steps' frames start: host (default) = host memory -> pinned staging on FrameLoader's background "
                     "thread -> H2D on a copy stream one batch ahead (SURVEY.md 8(d): the metric starts at the H2D copy of the raw frame; "

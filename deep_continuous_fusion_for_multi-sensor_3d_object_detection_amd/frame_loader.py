@@ -245,9 +245,15 @@ class FrameLoader(object):
             th.join(timeout=5.0)
 
     def __iter__(self):
+        if self.device is not None and getattr(self, "_active", False):
+            raise RuntimeError("FrameLoader: one iteration at a time (the staging sets belong to the running one; close it or finish it first)")
         if self.device is None:
             for host in self.loader:
                 host["image"] = torch.stack(host["image"], 0)
                 yield Batch(host)
             return
-        yield from (self._iter_threaded() if self.threaded else self._iter_inline())
+        self._active = True
+        try:
+            yield from (self._iter_threaded() if self.threaded else self._iter_inline())
+        finally:
+            self._active = False

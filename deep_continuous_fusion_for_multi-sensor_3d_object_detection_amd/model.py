@@ -377,8 +377,9 @@ class ObjectDetection_DCF(_FlatParamModule):
         if self.fusion_enabled and stream not in IMAGE_ARCHS:
             raise NotImplementedError("image_stream=%r (one of %s)" % (stream, sorted(IMAGE_ARCHS)))
         # hip_graphs: True / False (default), or "auto" (bench.py's default) = replay captured graphs for batches of ONE frame in a single-rank run -- the
-        # one configuration where the step runs at the host's pace (measured: batch 1 251 frames/s replayed against 200 eager on
-        # the same box, profiles/r04e_*; at batch 2 the step is kernel-bound and eager launches keep the gradient buckets' overlap)
+        # one configuration where eager launches can leave the GPU waiting for the host (round 5, two boxes: 254.9 frames/s replayed
+        # against 250.4 eager, and 250.4 against 216.6 on a slower host: profiles/r05a_* / r05b_*; under replay the compute queue is
+        # 96 % busy, profiles/r05f_timeline_b1.txt); at batch 2 the step is kernel-bound and eager launches keep the gradient buckets' overlap
         hg = config.get("hip_graphs", False)
         self.use_graphs = "auto" if str(hg).lower() == "auto" else bool(hg)
         self._graphs = None
