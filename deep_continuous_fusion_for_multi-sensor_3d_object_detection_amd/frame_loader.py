@@ -6,8 +6,8 @@ crosses PCIe is the point list (12 B/point) and the uint8 image; the voxeliser /
 (Train.geometry_async).
 
 Staging runs on a BACKGROUND THREAD (round 5): it pulls the next host batch, packs it into one of
-three pinned staging sets with a GIL-releasing memcpy, enqueues the H2D copies on the copy stream and hands the batch over
-through a two-deep queue.  The thread that enqueues the train step only takes a finished Batch out of the queue and, when it
+six pinned staging sets with a GIL-releasing memcpy, enqueues the H2D copies on the copy stream and hands the batch over
+through a four-deep queue.  The thread that enqueues the train step only takes a finished Batch out of the queue and, when it
 comes back for the next one, records ONE event on its stream ("everything that read this set's device buffers has been
 enqueued") that the copy stream waits for before it overwrites the set.  Until round 5 the packing, the copy enqueue and an
 event synchronise ran on the enqueue thread itself: ~1 ms of a 5.3 ms step on a host that is not ahead of the GPU.
@@ -172,11 +172,15 @@ class FrameLoader(object):
             yield cur
         yield nxt
 
-    NSETS = 3          # one being read by the running step, one staged and waiting, one being packed
+    # staging sets: one being read by the running step, DEPTH staged and waiting, one being packed.  Four batches of look-ahead
+    # (~20 ms of steps at cfg2) ride out a staging thread that the host deschedules for a while (a shared box showed single 45 ms
+    # steps with two: profiles/r05c_*); the sets are a few MB each.
+    DEPTH = 4
+    NSETS = DEPTH + 2
 
     def _iter_threaded(self):
         free = queue.Queue()            # staging-set indices the worker may fill
-        ready = queue.Queue(maxsize=2)  # staged batches (two deep), then a sentinel: None = end, an exception = re-raise
+        ready = queue.Queue(maxsize=self.DEPTH)  # staged batches, then a sentinel: None = end, an exception = re-raise
         stop = threading.Event()
         dev = self.device
 
