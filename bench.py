@@ -481,6 +481,11 @@ def main():
         train_step(trainer, pool, pool.batch(s, args.batch))
     barrier()
     log("warm-up done")
+    # everything allocated so far (model, plans, frame pool) goes to the permanent generation: a full cyclic collection over it in
+    # the middle of the timed region is a host pause of tens of ms that has nothing to do with the step (collection stays on)
+    import gc
+    gc.collect()
+    gc.freeze()
     loader = None
     if args.from_host:
         loader = iter(pkg("frame_loader").FrameLoader(HostFrames(pool, args.steps + 2, args.batch), args.batch))
@@ -499,7 +504,9 @@ def main():
         marks[s + 1].record()
     barrier()
     dt = time.perf_counter() - t0
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    raw_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    slowest = max(range(args.steps), key=lambda i: raw_ms[i])
+    step_ms = sorted(raw_ms)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     if ws > 1:
         # (a host tensor under gloo: DCF_DIST_BACKEND=gloo lets several ranks share one GPU for functional runs)
@@ -551,6 +558,7 @@ def main():
         out = {"metric": "frames/sec (train step) 100k-pt LiDAR + 1242x375 RGB", "value": round(frames / dt, 3), "unit": "frames/s",
                "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "ms_per_step_median": round(median_ms, 3), "ms_per_step_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)],
+               "slowest_step_index": slowest,
                "ms_first_steps": [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(min(args.steps, 8))],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "%s: grid 32x704x800, %d pts/frame, %s RGB, %s image stream, K=%d fusion x4 sites, "

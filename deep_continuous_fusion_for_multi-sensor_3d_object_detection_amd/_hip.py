@@ -40,6 +40,7 @@ SIGNATURES = {
     "dcf_voxelize_batch": (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, P, P, P]),
     "dcf_voxelize_batch_nhwc": (c_int, [c_int, P, P, c_int, P, P, c_int, c_int, c_int, P, P, P]),
     "dcf_project_filter": (c_int, [P, c_int, P, P, c_float, c_float, c_int, P, P, P, P, P, P]),
+    "dcf_project_filter_batch": (c_int, [P, P, c_int, P, P, c_float, c_float, c_int, P, P, c_int, P, P, P]),
     "dcf_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dcf_knn_bev": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, P, P, P]),
     "dcf_knn_bev_batch": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, P, P, c_size_t, P]),

@@ -158,6 +158,104 @@ __global__ void __launch_bounds__(CP_THREADS) k_compact_scatter(const float *pts
     }
 }
 
+// ---- the frames of a batch in one launch per phase (round 5: dcf_project_filter_batch): blockIdx.y = frame, every frame with its
+// own points, count and projection matrix (KITTI calibrates per frame); the bodies are the per-frame kernels' own.
+#define DCF_PROJ_BATCH_MAX 8
+struct ProjBatch {
+    const float *pts[DCF_PROJ_BATCH_MAX];
+    int n[DCF_PROJ_BATCH_MAX];
+    Crt12 c[DCF_PROJ_BATCH_MAX];
+};
+__device__ __forceinline__ ProjPred proj_pred_of(const ProjBatch &pb, int b, const Lim6 &lim, float ulim, float vlim, int mode)
+{
+    ProjPred p;
+    p.lim = lim; p.ulim = ulim; p.vlim = vlim; p.mode = mode;
+#pragma unroll
+    for (int f = 0; f < DCF_PROJ_BATCH_MAX; ++f)             // (static indices: a run-time index into the by-value argument would go through scratch)
+        if (f == b)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) p.c.v[k] = pb.c[f].v[k];
+    return p;
+}
+__device__ __forceinline__ const float *proj_pts_of(const ProjBatch &pb, int b, int &n)
+{
+    const float *q = nullptr;
+    n = 0;
+#pragma unroll
+    for (int f = 0; f < DCF_PROJ_BATCH_MAX; ++f)
+        if (f == b) { q = pb.pts[f]; n = pb.n[f]; }
+    return q;
+}
+
+__global__ void __launch_bounds__(CP_THREADS) k_proj_count_b(ProjBatch pb, Lim6 lim, float ulim, float vlim, int mode, int *blocksum, int bstride)
+{
+    const int b = blockIdx.y;
+    int n;
+    const float *pts = proj_pts_of(pb, b, n);
+    const ProjPred pred = proj_pred_of(pb, b, lim, ulim, vlim, mode);
+    const int base = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS;
+    int c = 0;
+    float u, v;
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k) {
+        const int i = base + k;
+        if (i < n && pred(pts, i, &u, &v)) ++c;
+    }
+    int tot;
+    block_excl_scan(c, &tot);
+    if (threadIdx.x == 0) blocksum[(size_t)b * bstride + blockIdx.x] = tot;
+}
+
+// one block per frame: exclusive scan of the frame's nb block sums in place; total -> count[frame]
+__global__ void __launch_bounds__(CP_THREADS) k_proj_scan_b(int *blocksum, int nb, int bstride, int *count)
+{
+    blocksum += (size_t)blockIdx.y * bstride;
+    int carry = 0;
+    for (int b0 = 0; b0 < nb; b0 += CP_THREADS) {
+        const int i = b0 + threadIdx.x;
+        const int v = i < nb ? blocksum[i] : 0;
+        int tot;
+        const int ex = block_excl_scan(v, &tot);
+        if (i < nb) blocksum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) count[blockIdx.y] = carry;
+}
+
+__global__ void __launch_bounds__(CP_THREADS) k_proj_scatter_b(ProjBatch pb, Lim6 lim, float ulim, float vlim, int mode, const int *blockoff, int bstride,
+                                                               float *out_uv, float *out_xyz, int rows)
+{
+    const int b = blockIdx.y;
+    int n;
+    const float *pts = proj_pts_of(pb, b, n);
+    const ProjPred pred = proj_pred_of(pb, b, lim, ulim, vlim, mode);
+    out_uv += (size_t)b * rows * 2; out_xyz += (size_t)b * rows * 3;
+    const int base = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS;
+    bool keep[CP_ITEMS];
+    float u[CP_ITEMS], v[CP_ITEMS];
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k) {
+        const int i = base + k;
+        keep[k] = (i < n) && pred(pts, i, &u[k], &v[k]);
+        c += keep[k] ? 1 : 0;
+    }
+    int tot;
+    int pos = blockoff[(size_t)b * bstride + blockIdx.x] + block_excl_scan(c, &tot);
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k) {
+        if (keep[k]) {
+            const int i = base + k;
+            out_xyz[3 * pos] = pts[3 * i];
+            out_xyz[3 * pos + 1] = pts[3 * i + 1];
+            out_xyz[3 * pos + 2] = pts[3 * i + 2];
+            out_uv[2 * pos] = u[k];
+            out_uv[2 * pos + 1] = v[k];
+            ++pos;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------
 // Voxeliser.  data_import_carla.py:236-258.
 // ------------------------------------------------------------------------------
@@ -313,6 +411,125 @@ __global__ void __launch_bounds__(256) k_voxel_cell_gather(VoxBatch vb, Lim6 lim
         if (NHWC) {
             const int vz = v / (L * W), r = v - vz * (L * W);
             DT<TO>::st(grid + (size_t)r * Cz + vz, sum);                                       // r = vx*W + vy
+        } else {
+            DT<TO>::st(grid + v, sum);
+        }
+    }
+}
+
+// ---- the same three steps over a HASH of the occupied cells (round 5).  The dense claim map above is 2 x Cz x L x W ints per frame
+// (144 MB at cfg2) of which a frame's points touch 0.5 %: the gather's 27 neighbour lookups per cell winner are 27 random 64-byte
+// sector reads in a table far larger than the L2s (73 us per cfg2 step).  Here the claims live in an open-addressing table of
+// 4 x n slots (4 MB for 100 k points: L2-resident), slot = {cell + 1, last point of the cell + 1} in one 64-bit word: insert =
+// compare-and-swap on an empty slot or a 64-bit atomic max on the cell's own slot (equal high words: the max is the max of the
+// point indices), linear probing otherwise.  Same claims, same ordered sums: the grids are bit-identical to the dense path's
+// (option VOXEL_HASH=0 selects it; tests/test_gpu_geometry.py compares the two).  The table region is cleared afterwards, so the
+// workspace contract (zero on entry, returned zero) holds.
+struct VoxHash { int bits; unsigned mask; };
+__device__ __forceinline__ unsigned vox_slot(int cell, const VoxHash &h) { return ((unsigned)cell * 0x9E3779B1u) >> (32 - h.bits); }
+
+__global__ void __launch_bounds__(256) k_voxel_hash_claim(VoxBatch vb, Lim6 lim, Aff6 aff, int L, int W, int nvox, int *owners, VoxHash hp)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= vb.n[b]) return;
+    const float *pts = vb.pts[b];
+    const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    if (!in_range(x, y, z, lim)) return;
+    const int xl = (int)__fadd_rn(__fmul_rn(x, aff.v[0]), aff.v[1]), yl = (int)__fadd_rn(__fmul_rn(y, aff.v[2]), aff.v[3]),
+              zl = (int)__fadd_rn(__fmul_rn(z, aff.v[4]), aff.v[5]);
+    const int cell = (zl * L + xl) * W + yl;
+    unsigned long long *tab = reinterpret_cast<unsigned long long *>(owners + (size_t)b * 2 * nvox);
+    const unsigned long long mine = ((unsigned long long)(unsigned)(cell + 1) << 32) | (unsigned)(i + 1);
+    unsigned slot = vox_slot(cell, hp);
+    for (;;) {
+        unsigned long long cur = tab[slot];
+        if (cur == 0ull) {
+            cur = atomicCAS(&tab[slot], 0ull, mine);
+            if (cur == 0ull) return;                      // the slot was empty: this cell's now
+        }
+        if ((unsigned)(cur >> 32) == (unsigned)(cell + 1)) { atomicMax(&tab[slot], mine); return; }
+        slot = (slot + 1) & hp.mask;
+    }
+}
+
+__device__ __forceinline__ int vox_lookup(const unsigned long long *tab, int cell, unsigned long long first, unsigned slot, const VoxHash &hp)
+{
+    unsigned long long cur = first;
+    for (;;) {
+        if (cur == 0ull) return 0;
+        if ((unsigned)(cur >> 32) == (unsigned)(cell + 1)) return (int)(unsigned)cur;
+        slot = (slot + 1) & hp.mask;
+        cur = tab[slot];
+    }
+}
+
+template <typename TO, bool NHWC>
+__global__ void __launch_bounds__(256) k_voxel_hash_gather(VoxBatch vb, Lim6 lim, Aff6 aff, int Cz, int L, int W, int nvox, TO *grids,
+                                                           const int *owners, VoxHash hp)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= vb.n[b]) return;
+    const float *pts = vb.pts[b];
+    const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    if (!in_range(x, y, z, lim)) return;
+    const int xl = (int)__fadd_rn(__fmul_rn(x, aff.v[0]), aff.v[1]), yl = (int)__fadd_rn(__fmul_rn(y, aff.v[2]), aff.v[3]),
+              zl = (int)__fadd_rn(__fmul_rn(z, aff.v[4]), aff.v[5]);
+    const unsigned long long *tab = reinterpret_cast<const unsigned long long *>(owners + (size_t)b * 2 * nvox);
+    const int cell = (zl * L + xl) * W + yl;
+    {
+        const unsigned s0 = vox_slot(cell, hp);
+        if (vox_lookup(tab, cell, tab[s0], s0, hp) != i + 1) return;          // not the last point of its cell
+    }
+    TO *grid = grids + (size_t)b * nvox;
+    // the 27 neighbours' first probes go out together (independent loads), then each lookup is resolved; the rest is
+    // k_voxel_cell_gather's arithmetic, word for word
+    unsigned long long first[27];
+    unsigned slot0[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        const int oz = t / 9 - 1, ox = (t / 3) % 3 - 1, oy = t % 3 - 1;
+        const int nc = cell + (oz * L + ox) * W + oy;
+        const bool ok = nc >= 0 && nc < nvox;
+        slot0[t] = vox_slot(ok ? nc : 0, hp);
+        first[t] = ok ? tab[slot0[t]] : 0ull;
+    }
+    float contrib[8][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) contrib[k][c] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        const int oz = t / 9 - 1, ox = (t / 3) % 3 - 1, oy = t % 3 - 1;
+        const int nc = cell + (oz * L + ox) * W + oy;
+        if (nc < 0 || nc >= nvox) continue;
+        const int j1 = vox_lookup(tab, nc, first[t], slot0[t], hp);
+        if (j1 <= 0) continue;
+        const float *q = pts + 3 * (size_t)(j1 - 1);
+        const float fx = __fadd_rn(__fmul_rn(q[0], aff.v[0]), aff.v[1]);
+        const float fy = __fadd_rn(__fmul_rn(q[1], aff.v[2]), aff.v[3]);
+        const float fz = __fadd_rn(__fmul_rn(q[2], aff.v[4]), aff.v[5]);
+        const float dx = __fsub_rn(fx, (float)(int)fx), dy = __fsub_rn(fy, (float)(int)fy), dz = __fsub_rn(fz, (float)(int)fz);
+        const float wxs[2] = {__fsub_rn(1.0f, dx), dx}, wys[2] = {__fsub_rn(1.0f, dy), dy}, wzs[2] = {__fsub_rn(1.0f, dz), dz};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ez = (k & 1) - oz, ex = ((k >> 1) & 1) - ox, ey = ((k >> 2) & 1) - oy;     // e_c = e_k - offset
+            if (ez < 0 || ez > 1 || ex < 0 || ex > 1 || ey < 0 || ey > 1) continue;
+            contrib[k][ez | (ex << 1) | (ey << 2)] = __fmul_rn(__fmul_rn(wxs[ex], wys[ey]), wzs[ez]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) sum = __fadd_rn(sum, contrib[k][c]);                       // pass order
+        const int v = cell + ((k & 1) * L + ((k >> 1) & 1)) * W + ((k >> 2) & 1);
+        if (v >= nvox) continue;
+        if (NHWC) {
+            const int vz = v / (L * W), r = v - vz * (L * W);
+            DT<TO>::st(grid + (size_t)r * Cz + vz, sum);
         } else {
             DT<TO>::st(grid + v, sum);
         }
@@ -1264,14 +1481,30 @@ __global__ void __launch_bounds__(256) k_zero_rows(int *p, int n, int64_t stride
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[blockIdx.y * stride + (n4 << 2) + threadIdx.x] = 0;
 }
 
+// (map, index inside the map) of pair slot e.  A block of 256 slots almost never straddles two maps (a map has K*h*w slots): the
+// map of the block's first and last slot are found with block-uniform (scalar) arithmetic, and only a straddling block pays the
+// 31 compares per thread -- they were a third of these kernels' instructions (round 5).
+__device__ __forceinline__ int inv_load(const InvMaps &m, int e, int &g)
+{
+    const int e0 = blockIdx.x * blockDim.x;
+    const int gA = __builtin_amdgcn_readfirstlane(inv_map_of(m, e0));
+    const int gB = __builtin_amdgcn_readfirstlane(inv_map_of(m, min(e0 + (int)blockDim.x, m.first[m.n]) - 1));
+    if (gA == gB) {
+        g = gA;
+        return m.idx[gA][e - m.first[gA]];
+    }
+    g = inv_map_of(m, e);
+    return m.idx[g][e - m.first[g]];
+}
+
 __global__ void __launch_bounds__(256) k_inv_hist(InvMaps m, int n_max, int *cnt)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int key = -1;
     if (e < m.first[m.n]) {
-        const int g = inv_map_of(m, e);
-        const int id = m.idx[g][e - m.first[g]];
+        int g;
+        const int id = inv_load(m, e, g);
         if (id >= 0 && id < n_max) key = g * (n_max + 1) + id;
     }
     const InvRun r = inv_run(key, lane);
@@ -1284,8 +1517,7 @@ __global__ void __launch_bounds__(256) k_inv_fill(InvMaps m, int n_max, int *cur
     const int lane = threadIdx.x & 63;
     int key = -1, g = 0, id = 0;
     if (e < m.first[m.n]) {
-        g = inv_map_of(m, e);
-        id = m.idx[g][e - m.first[g]];
+        id = inv_load(m, e, g);
         if (id >= 0 && id < n_max) key = g * (n_max + 1) + id;
     }
     const InvRun r = inv_run(key, lane);
@@ -1341,7 +1573,52 @@ extern "C" int dcf_project_filter(const float *pts, int n, const float *lim, con
     return DCF_OK;
 }
 
+// The same for the B frames of a batch in one launch per phase.  pts / n / crt: HOST arrays (B device pointers, B counts, B x 12
+// floats); uv_out [B][rows][2], xyz_out [B][rows][3] (rows >= every n[b]; rows past a frame's count are left untouched), count_dev
+// [B]; ws: B * dcf_compact_workspace_bytes(max n).  Same results as B dcf_project_filter calls, bit for bit.
+extern "C" int dcf_project_filter_batch(const float *const *pts, const int *n, int B, const float *lim, const float *crt, float ulim, float vlim,
+                                        int mode, float *uv_out, float *xyz_out, int rows, int32_t *count_dev, void *ws, dcf_stream_t stream)
+{
+    const char *who = "dcf_project_filter_batch";
+    DCF_REQUIRE(pts && n && lim && crt && count_dev && ws && uv_out && xyz_out, "%s: bad arguments", who);
+    DCF_REQUIRE(B >= 1 && B <= DCF_PROJ_BATCH_MAX, "%s: 1..%d frames per call", who, DCF_PROJ_BATCH_MAX);
+    hipStream_t s = S(stream);
+    ProjBatch pb;
+    int nmax = 0;
+    for (int b = 0; b < DCF_PROJ_BATCH_MAX; ++b) {
+        pb.pts[b] = b < B ? pts[b] : nullptr;
+        pb.n[b] = b < B ? n[b] : 0;
+        DCF_REQUIRE(b >= B || (n[b] >= 0 && n[b] <= rows && (n[b] == 0 || pts[b])), "%s: frame %d: bad point count / null points", who, b);
+        memcpy(pb.c[b].v, crt + 12 * (b < B ? b : 0), sizeof(pb.c[b].v));
+        if (b < B && n[b] > nmax) nmax = n[b];
+    }
+    if (nmax == 0) { DCF_HIP(hipMemsetAsync(count_dev, 0, sizeof(int) * B, s)); return DCF_OK; }
+    Lim6 l;
+    memcpy(l.v, lim, sizeof(l.v));
+    const int nb = cdiv(nmax, CP_TILE);
+    const int bstride = (int)(dcf_compact_workspace_bytes(nmax) / sizeof(int));
+    int *bs = (int *)ws;
+    DCF_LAUNCH_B("project_count", (double)nmax * B * 12.0, s, hipLaunchKernelGGL(k_proj_count_b, dim3(nb, B), dim3(CP_THREADS), 0, s, pb, l, ulim, vlim, mode, bs, bstride));
+    DCF_LAUNCH("compact_scan", s, hipLaunchKernelGGL(k_proj_scan_b, dim3(1, B), dim3(CP_THREADS), 0, s, bs, nb, bstride, count_dev));
+    DCF_LAUNCH_B("project_scatter", (double)nmax * B * (12.0 + 20.0), s, hipLaunchKernelGGL(k_proj_scatter_b, dim3(nb, B), dim3(CP_THREADS), 0, s, pb, l, ulim, vlim, mode, bs, bstride,
+                                                                                    uv_out, xyz_out, rows));
+    return DCF_OK;
+}
+
 extern "C" size_t dcf_voxelize_workspace_bytes(int Cz, int L, int W) { return sizeof(int) * 2 * (size_t)Cz * L * W; }
+
+// Hash table of the occupied cells inside a frame's claim workspace (2 x nvox ints): 4 slots of 8 bytes per point, a power of two,
+// when that fits (it does unless the cloud is dense on a tiny grid: then the dense claim map); option VOXEL_HASH=0 = always dense.
+static bool vox_hash_plan(int nmax, int nvox, VoxHash *hp)
+{
+    static DcfOpt off_o("VOXEL_HASH"); const char *off = off_o.str();
+    if (off && atoi(off) == 0) return false;
+    int bits = 10;
+    while (bits < 30 && (1ll << bits) < 4ll * nmax) ++bits;
+    if ((8ll << bits) > 8ll * nvox || (nvox & 1)) return false;       // (frames 2 * nvox ints apart: 16-byte aligned rows for the clearing kernel)
+    hp->bits = bits; hp->mask = (1u << bits) - 1u;
+    return true;
+}
 
 extern "C" int dcf_voxelize(const float *pts, int n, const float *lim, const float *aff, int Cz, int L, int W,
                             int mode, float *grid, void *owner_ws, dcf_stream_t stream)
@@ -1361,6 +1638,13 @@ extern "C" int dcf_voxelize(const float *pts, int n, const float *lim, const flo
         VoxBatch vb;
         for (int b = 0; b < DCF_MAX_VOXEL_BATCH; ++b) { vb.pts[b] = b == 0 ? pts : nullptr; vb.n[b] = b == 0 ? n : 0; }
         const dim3 g1(nb, 1);
+        VoxHash hp;
+        if (vox_hash_plan(n, nvox, &hp) && ((uintptr_t)owner_ws & 15) == 0) {
+            DCF_LAUNCH("voxel_hash_claim", s, hipLaunchKernelGGL(k_voxel_hash_claim, g1, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, hp));
+            DCF_LAUNCH("voxel_hash_gather", s, hipLaunchKernelGGL((k_voxel_hash_gather<float, false>), g1, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, grid, (const int *)owner_ws, hp));
+            DCF_HIP(hipMemsetAsync(owner_ws, 0, (size_t)8 << hp.bits, s));
+            return DCF_OK;
+        }
         DCF_LAUNCH("voxel_cell_claim", s, hipLaunchKernelGGL(k_voxel_cell_claim, g1, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, 0));
         DCF_LAUNCH("voxel_cell_gather", s, hipLaunchKernelGGL((k_voxel_cell_gather<float, false>), g1, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, grid, (const int *)owner_ws));
         DCF_LAUNCH("voxel_cell_claim", s, hipLaunchKernelGGL(k_voxel_cell_claim, g1, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, 1));
@@ -1402,6 +1686,18 @@ static int voxelize_batch_impl(const char *who, int dtype, bool nhwc, const floa
     memcpy(l.v, lim, sizeof(l.v));
     memcpy(a.v, aff, sizeof(a.v));
     const dim3 grid(cdiv(nmax, 256), B);
+    VoxHash hp;
+    if (vox_hash_plan(nmax, nvox, &hp) && ((uintptr_t)owner_ws & 15) == 0) {
+        DCF_LAUNCH_B("voxel_hash_claim", (double)nmax * B * 20.0, s, hipLaunchKernelGGL(k_voxel_hash_claim, grid, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, hp));
+        if (!nhwc) {
+            DCF_LAUNCH_B("voxel_hash_gather", (double)nmax * B * (12.0 + 27 * 8.0 + 8 * 4.0), s, hipLaunchKernelGGL((k_voxel_hash_gather<float, false>), grid, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, (float *)grids, (const int *)owner_ws, hp));
+        } else {
+            DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("voxel_hash_gather", (double)nmax * B * (12.0 + 27 * 8.0 + 8.0 * sizeof(T)), s, hipLaunchKernelGGL((k_voxel_hash_gather<T, true>), grid, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, (T *)grids, (const int *)owner_ws, hp)); })
+        }
+        const int tints = 2 << hp.bits;                    // the tables' ints, one row per frame
+        DCF_LAUNCH_B("voxel_hash_clear", (double)B * tints * 4.0, s, hipLaunchKernelGGL(k_zero_rows, dim3(std::min(cdiv(tints, 1024), 256), B), dim3(256), 0, s, (int *)owner_ws, tints, (int64_t)2 * nvox));
+        return DCF_OK;
+    }
     DCF_LAUNCH_B("voxel_cell_claim", (double)nmax * B * 16.0, s, hipLaunchKernelGGL(k_voxel_cell_claim, grid, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, 0));
     if (!nhwc) {
         DCF_LAUNCH_B("voxel_cell_gather", (double)nmax * B * (12.0 + 27 * 4.0 + 8 * 4.0), s, hipLaunchKernelGGL((k_voxel_cell_gather<float, false>), grid, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, (float *)grids, (const int *)owner_ws));

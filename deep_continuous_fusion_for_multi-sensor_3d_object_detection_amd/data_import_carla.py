@@ -102,6 +102,21 @@ class FrameGeometry(object):
         mp = int(self.config["max_num_pc"])
         return xyz[:mp], uv[:mp], cnt
 
+    def project_batch(self, points_list, crts, xyz_all, uv_all, cnt_all):
+        """project() for the frames of a batch in one launch per phase (dcf_project_filter_batch): frames with at most max_num_pc
+        points, <= 8 of them; xyz_all [B,max_num_pc,3], uv_all [B,max_num_pc,2] zero-filled, cnt_all int32 [B].  Returns False when
+        the batch does not qualify (the caller then projects frame by frame)."""
+        mp_ = int(self.config["max_num_pc"])
+        pts = [self._pts(p) for p in points_list]
+        if not (1 <= len(pts) <= 8) or any(p.shape[0] > mp_ for p in pts):
+            return False
+        ulim, vlim = self.limits()
+        mats = np.stack([np.ascontiguousarray(self.crt if (crts is None or crts[b] is None) else crts[b], dtype=np.float32).reshape(12)
+                         for b in range(len(pts))], 0)
+        self._proj_ws = ops.project_filter_batch(pts, self.grid.lim, mats, ulim, vlim, self.proj_mode, uv_all, xyz_all, cnt_all,
+                                                 getattr(self, "_proj_ws", None))
+        return True
+
     def __call__(self, lidar_points, want_ids=False, voxel_out=None, voxel_mode=None):
         """lidar_points [N,3] f32 (any device) -> (voxel [Cz,L,W], pointcloud_raw [max_num_pc,3],
         uv [max_num_pc,2], n_valid int32[1] on device, ids or None).  voxel_out: optional [Cz,L,W] slice of a

@@ -379,6 +379,27 @@ def project_filter(pts, lim, crt, ulim, vlim, mode=H.PROJ_COMPAT, n_out=None, wa
     return uv, xyz, cnt, src
 
 
+def project_filter_batch(pts_list, lim, crts, ulim, vlim, mode, uv_all, xyz_all, cnt_all, ws=None):
+    """dcf_project_filter for the (<= 8) frames of a batch in one launch per phase: pts_list = B device tensors [n_b,3]; crts [B,4,3]
+    (or [B,12]) host floats, one matrix per frame; uv_all [B,rows,2], xyz_all [B,rows,3] (zero-filled by the caller: rows past a
+    frame's count are left untouched), cnt_all int32 [B].  Same values as one project_filter per frame."""
+    import ctypes
+    B = len(pts_list)
+    rows = xyz_all.shape[1]
+    ns = [int(p.shape[0]) for p in pts_list]
+    if max(ns) > rows or uv_all.shape[1] != rows or not (uv_all.is_contiguous() and xyz_all.is_contiguous() and cnt_all.is_contiguous()):
+        raise H.DcfError("project_filter_batch: contiguous outputs with at least %d rows per frame" % max(ns))
+    ptrs = (ctypes.c_void_p * B)(*[_chk(p, "pts").data_ptr() if p.shape[0] else None for p in pts_list])
+    cnts = (ctypes.c_int32 * B)(*ns)
+    crt = np.ascontiguousarray(np.asarray(crts, dtype=np.float32).reshape(B, 12))
+    need = B * H.lib().dcf_compact_workspace_bytes(max(max(ns), 1))
+    if ws is None or ws.numel() < need:
+        ws = torch.empty((need,), dtype=torch.uint8, device=xyz_all.device)
+    H.call("dcf_project_filter_batch", ctypes.addressof(ptrs), ctypes.addressof(cnts), B, H.host_f32(lim), crt, float(ulim), float(vlim), int(mode),
+           uv_all, xyz_all, rows, cnt_all, ws, H.stream_ptr())
+    return ws
+
+
 def knn_bev(xyz, cnt, K, h, w, stride, aff, rmax=None, ws=None, out=None):
     """out: optional int32 [K,h,w] tensor to write into (e.g. a frame's slice of a batch tensor)."""
     n_max = xyz.shape[0]

@@ -191,11 +191,14 @@ class Train(nn.Module):
             # still run; the engine sizes the per-point fusion tensors by them instead of max_num_pc (Plan._fusion_rows)
             # the frames' projections land side by side in batch tensors (no per-frame allocations, no stack copies)
             inplace = True
-            for b, pts in enumerate(points_list):
-                pc, uv, cnt = frame_geometry.project(pts, crt=None if crts is None else crts[b],
-                                                     out=(xyz_all[b], uv_all[b], cnt_all[b:b + 1]))
-                inplace = inplace and pc.data_ptr() == xyz_all[b].data_ptr()
-                pcs.append(pc); uvs.append(uv); cnts.append(cnt)
+            if getattr(frame_geometry, "project_batch", None) is not None and frame_geometry.project_batch(points_list, crts, xyz_all, uv_all, cnt_all):
+                pass                                    # every frame in one launch per phase (count / scan / scatter)
+            else:
+                for b, pts in enumerate(points_list):
+                    pc, uv, cnt = frame_geometry.project(pts, crt=None if crts is None else crts[b],
+                                                         out=(xyz_all[b], uv_all[b], cnt_all[b:b + 1]))
+                    inplace = inplace and pc.data_ptr() == xyz_all[b].data_ptr()
+                    pcs.append(pc); uvs.append(uv); cnts.append(cnt)
             cnt_dev = cnt_all if inplace else torch.cat(cnts, 0)
             cnt_host = st["cnt_host"] if st is not None else torch.empty(Bn, dtype=torch.int32).pin_memory()
             cnt_host.copy_(cnt_dev, non_blocking=True)

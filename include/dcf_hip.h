@@ -93,6 +93,11 @@ int dcf_voxelize_batch_nhwc(int dtype, const float *const *pts, const int *n, in
 int dcf_project_filter(const float *pts, int n, const float *lim, const float *crt, float ulim, float vlim,
                        int mode, float *uv_out, float *xyz_out, int32_t *src_out, int32_t *count_dev,
                        void *ws, dcf_stream_t stream);
+/* The same for the B (<= 8) frames of a batch in one launch per phase (count / scan / scatter), every frame with its own points,
+ * count and matrix: pts / n HOST arrays of B device pointers / point counts, crt HOST float[B][12]; uv_out [B][rows][2], xyz_out
+ * [B][rows][3] (rows >= every n[b]), count_dev [B]; ws: B * dcf_compact_workspace_bytes(max n).  Bit-identical to B calls. */
+int dcf_project_filter_batch(const float *const *pts, const int *n, int B, const float *lim, const float *crt, float ulim, float vlim,
+                             int mode, float *uv_out, float *xyz_out, int rows, int32_t *count_dev, void *ws, dcf_stream_t stream);
 
 /* BEV K-nearest-neighbour (reference: model.py:199-203 TODO; spec SURVEY.md App. D).
  * xyz [n_max][3], first *count_dev rows valid.  idx_out int32 [K][h][w], -1 padding.

@@ -245,6 +245,25 @@ def test_voxel_cell_formulation_equals_nine_rounds(case):
     a = ops.voxelize(pts, g.lim, g.aff, g.dims, H.VOXEL_COMPAT)
     b = ops.voxelize(pts, g.lim, g.aff, g.dims, H.VOXEL_COMPAT_ROUNDS)
     assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and float(a.sum()) > 0
+    # round 5: the claims live in a hash of the occupied cells by default (csrc/geometry.hip, k_voxel_hash_*); the dense claim map
+    # (option VOXEL_HASH=0; also the automatic choice when the table would not fit the workspace) must give the same bits, through
+    # the single-frame and the batched entry points, and both must hand the workspace back zero
+    Cz, L, W = g.dims
+    owner = torch.zeros((2, 2, Cz * L * W), dtype=torch.int32, device="cuda")
+    outs = {}
+    for hashed in (1, 0):
+        H.set_option("VOXEL_HASH", hashed)
+        try:
+            outs[hashed] = ops.voxelize(pts, g.lim, g.aff, g.dims, H.VOXEL_COMPAT)
+            bt = torch.full((2, Cz, L, W), float("nan"), device="cuda")
+            ops.voxelize_batch([pts, pts[: pts.shape[0] // 3]], g.lim, g.aff, g.dims, owner, bt)
+            assert int(owner.abs().max()) == 0
+            assert torch.equal(bt[0].view(torch.int32), b.view(torch.int32))
+            outs[(hashed, "part")] = bt[1].clone()
+        finally:
+            H.set_option("VOXEL_HASH", None)
+    assert torch.equal(outs[1].view(torch.int32), b.view(torch.int32)) and torch.equal(outs[0].view(torch.int32), b.view(torch.int32))
+    assert torch.equal(outs[(1, "part")].view(torch.int32), outs[(0, "part")].view(torch.int32))
 
 
 @pytest.mark.parametrize("dtype", [1, 2, 0])
@@ -559,3 +578,30 @@ def test_knn_all_sites_in_one_call_equal_the_per_site_calls(K, B, rmax):
         bad = list(sites)
         bad[1] = bad[1][:3] + (2,) + bad[1][4:]
         ops.knn_bev_sites(d, cnt, K, bad, g.aff, rmax)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_project_filter_batch_equals_per_frame(mode):
+    """dcf_project_filter_batch (round 5: count / scan / scatter once for all frames of a batch, blockIdx.y = frame) against one
+    dcf_project_filter per frame, bit for bit: frames of different sizes (one empty, one smaller than a compaction tile), every
+    frame with its own projection matrix, compat and correct bounds; rows past a frame's count stay untouched (zero)."""
+    ops, H, det, calib = pkg("ops"), pkg("_hip"), pkg("detfill"), pkg("calib")
+    cfg = golden_cfg(load_golden("geometry_carla.npz"))
+    g = _spec(cfg)
+    lim6 = (cfg["lidar_x_min"], cfg["lidar_x_max"], cfg["lidar_y_min"], cfg["lidar_y_max"], cfg["lidar_z_min"], cfg["lidar_z_max"])
+    sizes = (30000, 0, 700, 12345, 100000)
+    frames = [torch.from_numpy(det.synthetic_points(n, lim6, 90 + i)).cuda() if n else torch.zeros(0, 3, device="cuda") for i, n in enumerate(sizes)]
+    base = np.asarray(load_golden("geometry_carla.npz")["crt"], dtype=np.float32)
+    crts = [base * np.float32(1.0 + 0.01 * b) for b in range(len(sizes))]
+    rows = 100000
+    B = len(sizes)
+    uv = torch.zeros((B, rows, 2), device="cuda"); xyz = torch.zeros((B, rows, 3), device="cuda")
+    cnt = torch.full((B,), -7, dtype=torch.int32, device="cuda")
+    ops.project_filter_batch(frames, g.lim, np.stack(crts, 0), float(cfg["image_height"]), float(cfg["image_width"]), mode, uv, xyz, cnt)
+    for b, p in enumerate(frames):
+        if p.shape[0] == 0:
+            assert int(cnt[b]) == 0 and not uv[b].any() and not xyz[b].any()
+            continue
+        uv1, xyz1, c1, _ = ops.project_filter(p, g.lim, crts[b], cfg["image_height"], cfg["image_width"], mode=mode, n_out=rows)
+        assert int(cnt[b]) == int(c1.item()) and int(c1.item()) > 0
+        assert torch.equal(uv[b].view(torch.int32), uv1.view(torch.int32)) and torch.equal(xyz[b].view(torch.int32), xyz1.view(torch.int32))
