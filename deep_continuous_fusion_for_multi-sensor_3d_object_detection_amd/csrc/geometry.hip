@@ -417,125 +417,6 @@ __global__ void __launch_bounds__(256) k_voxel_cell_gather(VoxBatch vb, Lim6 lim
     }
 }
 
-// ---- the same three steps over a HASH of the occupied cells (round 5).  The dense claim map above is 2 x Cz x L x W ints per frame
-// (144 MB at cfg2) of which a frame's points touch 0.5 %: the gather's 27 neighbour lookups per cell winner are 27 random 64-byte
-// sector reads in a table far larger than the L2s (73 us per cfg2 step).  Here the claims live in an open-addressing table of
-// 4 x n slots (4 MB for 100 k points: L2-resident), slot = {cell + 1, last point of the cell + 1} in one 64-bit word: insert =
-// compare-and-swap on an empty slot or a 64-bit atomic max on the cell's own slot (equal high words: the max is the max of the
-// point indices), linear probing otherwise.  Same claims, same ordered sums: the grids are bit-identical to the dense path's
-// (option VOXEL_HASH=0 selects it; tests/test_gpu_geometry.py compares the two).  The table region is cleared afterwards, so the
-// workspace contract (zero on entry, returned zero) holds.
-struct VoxHash { int bits; unsigned mask; };
-__device__ __forceinline__ unsigned vox_slot(int cell, const VoxHash &h) { return ((unsigned)cell * 0x9E3779B1u) >> (32 - h.bits); }
-
-__global__ void __launch_bounds__(256) k_voxel_hash_claim(VoxBatch vb, Lim6 lim, Aff6 aff, int L, int W, int nvox, int *owners, VoxHash hp)
-{
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= vb.n[b]) return;
-    const float *pts = vb.pts[b];
-    const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
-    if (!in_range(x, y, z, lim)) return;
-    const int xl = (int)__fadd_rn(__fmul_rn(x, aff.v[0]), aff.v[1]), yl = (int)__fadd_rn(__fmul_rn(y, aff.v[2]), aff.v[3]),
-              zl = (int)__fadd_rn(__fmul_rn(z, aff.v[4]), aff.v[5]);
-    const int cell = (zl * L + xl) * W + yl;
-    unsigned long long *tab = reinterpret_cast<unsigned long long *>(owners + (size_t)b * 2 * nvox);
-    const unsigned long long mine = ((unsigned long long)(unsigned)(cell + 1) << 32) | (unsigned)(i + 1);
-    unsigned slot = vox_slot(cell, hp);
-    for (;;) {
-        unsigned long long cur = tab[slot];
-        if (cur == 0ull) {
-            cur = atomicCAS(&tab[slot], 0ull, mine);
-            if (cur == 0ull) return;                      // the slot was empty: this cell's now
-        }
-        if ((unsigned)(cur >> 32) == (unsigned)(cell + 1)) { atomicMax(&tab[slot], mine); return; }
-        slot = (slot + 1) & hp.mask;
-    }
-}
-
-__device__ __forceinline__ int vox_lookup(const unsigned long long *tab, int cell, unsigned long long first, unsigned slot, const VoxHash &hp)
-{
-    unsigned long long cur = first;
-    for (;;) {
-        if (cur == 0ull) return 0;
-        if ((unsigned)(cur >> 32) == (unsigned)(cell + 1)) return (int)(unsigned)cur;
-        slot = (slot + 1) & hp.mask;
-        cur = tab[slot];
-    }
-}
-
-template <typename TO, bool NHWC>
-__global__ void __launch_bounds__(256) k_voxel_hash_gather(VoxBatch vb, Lim6 lim, Aff6 aff, int Cz, int L, int W, int nvox, TO *grids,
-                                                           const int *owners, VoxHash hp)
-{
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= vb.n[b]) return;
-    const float *pts = vb.pts[b];
-    const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
-    if (!in_range(x, y, z, lim)) return;
-    const int xl = (int)__fadd_rn(__fmul_rn(x, aff.v[0]), aff.v[1]), yl = (int)__fadd_rn(__fmul_rn(y, aff.v[2]), aff.v[3]),
-              zl = (int)__fadd_rn(__fmul_rn(z, aff.v[4]), aff.v[5]);
-    const unsigned long long *tab = reinterpret_cast<const unsigned long long *>(owners + (size_t)b * 2 * nvox);
-    const int cell = (zl * L + xl) * W + yl;
-    {
-        const unsigned s0 = vox_slot(cell, hp);
-        if (vox_lookup(tab, cell, tab[s0], s0, hp) != i + 1) return;          // not the last point of its cell
-    }
-    TO *grid = grids + (size_t)b * nvox;
-    // the 27 neighbours' first probes go out together (independent loads), then each lookup is resolved; the rest is
-    // k_voxel_cell_gather's arithmetic, word for word
-    unsigned long long first[27];
-    unsigned slot0[27];
-#pragma unroll
-    for (int t = 0; t < 27; ++t) {
-        const int oz = t / 9 - 1, ox = (t / 3) % 3 - 1, oy = t % 3 - 1;
-        const int nc = cell + (oz * L + ox) * W + oy;
-        const bool ok = nc >= 0 && nc < nvox;
-        slot0[t] = vox_slot(ok ? nc : 0, hp);
-        first[t] = ok ? tab[slot0[t]] : 0ull;
-    }
-    float contrib[8][8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) contrib[k][c] = 0.f;
-#pragma unroll
-    for (int t = 0; t < 27; ++t) {
-        const int oz = t / 9 - 1, ox = (t / 3) % 3 - 1, oy = t % 3 - 1;
-        const int nc = cell + (oz * L + ox) * W + oy;
-        if (nc < 0 || nc >= nvox) continue;
-        const int j1 = vox_lookup(tab, nc, first[t], slot0[t], hp);
-        if (j1 <= 0) continue;
-        const float *q = pts + 3 * (size_t)(j1 - 1);
-        const float fx = __fadd_rn(__fmul_rn(q[0], aff.v[0]), aff.v[1]);
-        const float fy = __fadd_rn(__fmul_rn(q[1], aff.v[2]), aff.v[3]);
-        const float fz = __fadd_rn(__fmul_rn(q[2], aff.v[4]), aff.v[5]);
-        const float dx = __fsub_rn(fx, (float)(int)fx), dy = __fsub_rn(fy, (float)(int)fy), dz = __fsub_rn(fz, (float)(int)fz);
-        const float wxs[2] = {__fsub_rn(1.0f, dx), dx}, wys[2] = {__fsub_rn(1.0f, dy), dy}, wzs[2] = {__fsub_rn(1.0f, dz), dz};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int ez = (k & 1) - oz, ex = ((k >> 1) & 1) - ox, ey = ((k >> 2) & 1) - oy;     // e_c = e_k - offset
-            if (ez < 0 || ez > 1 || ex < 0 || ex > 1 || ey < 0 || ey > 1) continue;
-            contrib[k][ez | (ex << 1) | (ey << 2)] = __fmul_rn(__fmul_rn(wxs[ex], wys[ey]), wzs[ez]);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        float sum = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) sum = __fadd_rn(sum, contrib[k][c]);                       // pass order
-        const int v = cell + ((k & 1) * L + ((k >> 1) & 1)) * W + ((k >> 2) & 1);
-        if (v >= nvox) continue;
-        if (NHWC) {
-            const int vz = v / (L * W), r = v - vz * (L * W);
-            DT<TO>::st(grid + (size_t)r * Cz + vz, sum);
-        } else {
-            DT<TO>::st(grid + v, sum);
-        }
-    }
-}
-
 __global__ void __launch_bounds__(256) k_voxel_accum(const float *pts, int n, Lim6 lim, Aff6 aff, int L, int W, float *grid)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1607,18 +1488,6 @@ extern "C" int dcf_project_filter_batch(const float *const *pts, const int *n, i
 
 extern "C" size_t dcf_voxelize_workspace_bytes(int Cz, int L, int W) { return sizeof(int) * 2 * (size_t)Cz * L * W; }
 
-// Hash table of the occupied cells inside a frame's claim workspace (2 x nvox ints): 4 slots of 8 bytes per point, a power of two,
-// when that fits (it does unless the cloud is dense on a tiny grid: then the dense claim map); option VOXEL_HASH=0 = always dense.
-static bool vox_hash_plan(int nmax, int nvox, VoxHash *hp)
-{
-    static DcfOpt off_o("VOXEL_HASH"); const char *off = off_o.str();
-    if (off && atoi(off) == 0) return false;
-    int bits = 10;
-    while (bits < 30 && (1ll << bits) < 4ll * nmax) ++bits;
-    if ((8ll << bits) > 8ll * nvox || (nvox & 1)) return false;       // (frames 2 * nvox ints apart: 16-byte aligned rows for the clearing kernel)
-    hp->bits = bits; hp->mask = (1u << bits) - 1u;
-    return true;
-}
 
 extern "C" int dcf_voxelize(const float *pts, int n, const float *lim, const float *aff, int Cz, int L, int W,
                             int mode, float *grid, void *owner_ws, dcf_stream_t stream)
@@ -1638,13 +1507,6 @@ extern "C" int dcf_voxelize(const float *pts, int n, const float *lim, const flo
         VoxBatch vb;
         for (int b = 0; b < DCF_MAX_VOXEL_BATCH; ++b) { vb.pts[b] = b == 0 ? pts : nullptr; vb.n[b] = b == 0 ? n : 0; }
         const dim3 g1(nb, 1);
-        VoxHash hp;
-        if (vox_hash_plan(n, nvox, &hp) && ((uintptr_t)owner_ws & 15) == 0) {
-            DCF_LAUNCH("voxel_hash_claim", s, hipLaunchKernelGGL(k_voxel_hash_claim, g1, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, hp));
-            DCF_LAUNCH("voxel_hash_gather", s, hipLaunchKernelGGL((k_voxel_hash_gather<float, false>), g1, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, grid, (const int *)owner_ws, hp));
-            DCF_HIP(hipMemsetAsync(owner_ws, 0, (size_t)8 << hp.bits, s));
-            return DCF_OK;
-        }
         DCF_LAUNCH("voxel_cell_claim", s, hipLaunchKernelGGL(k_voxel_cell_claim, g1, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, 0));
         DCF_LAUNCH("voxel_cell_gather", s, hipLaunchKernelGGL((k_voxel_cell_gather<float, false>), g1, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, grid, (const int *)owner_ws));
         DCF_LAUNCH("voxel_cell_claim", s, hipLaunchKernelGGL(k_voxel_cell_claim, g1, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, 1));
@@ -1686,18 +1548,6 @@ static int voxelize_batch_impl(const char *who, int dtype, bool nhwc, const floa
     memcpy(l.v, lim, sizeof(l.v));
     memcpy(a.v, aff, sizeof(a.v));
     const dim3 grid(cdiv(nmax, 256), B);
-    VoxHash hp;
-    if (vox_hash_plan(nmax, nvox, &hp) && ((uintptr_t)owner_ws & 15) == 0) {
-        DCF_LAUNCH_B("voxel_hash_claim", (double)nmax * B * 20.0, s, hipLaunchKernelGGL(k_voxel_hash_claim, grid, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, hp));
-        if (!nhwc) {
-            DCF_LAUNCH_B("voxel_hash_gather", (double)nmax * B * (12.0 + 27 * 8.0 + 8 * 4.0), s, hipLaunchKernelGGL((k_voxel_hash_gather<float, false>), grid, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, (float *)grids, (const int *)owner_ws, hp));
-        } else {
-            DCF_DISPATCH_DTYPE(dtype, { DCF_LAUNCH_B("voxel_hash_gather", (double)nmax * B * (12.0 + 27 * 8.0 + 8.0 * sizeof(T)), s, hipLaunchKernelGGL((k_voxel_hash_gather<T, true>), grid, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, (T *)grids, (const int *)owner_ws, hp)); })
-        }
-        const int tints = 2 << hp.bits;                    // the tables' ints, one row per frame
-        DCF_LAUNCH_B("voxel_hash_clear", (double)B * tints * 4.0, s, hipLaunchKernelGGL(k_zero_rows, dim3(std::min(cdiv(tints, 1024), 256), B), dim3(256), 0, s, (int *)owner_ws, tints, (int64_t)2 * nvox));
-        return DCF_OK;
-    }
     DCF_LAUNCH_B("voxel_cell_claim", (double)nmax * B * 16.0, s, hipLaunchKernelGGL(k_voxel_cell_claim, grid, dim3(256), 0, s, vb, l, a, L, W, nvox, (int *)owner_ws, 0));
     if (!nhwc) {
         DCF_LAUNCH_B("voxel_cell_gather", (double)nmax * B * (12.0 + 27 * 4.0 + 8 * 4.0), s, hipLaunchKernelGGL((k_voxel_cell_gather<float, false>), grid, dim3(256), 0, s, vb, l, a, Cz, L, W, nvox, (float *)grids, (const int *)owner_ws));

@@ -122,8 +122,20 @@ class FrameLoader(object):
             cap = (cap + 4095) // 4096 * 4096
             self._sets = [_Staging(cap, self.batch_size, ishape, self.device) for _ in range(nsets)]
             self._cap = cap
+            fresh = True
+        else:
+            fresh = False
         if self._copy is None:
             self._copy = torch.cuda.Stream(self.device)
+        if fresh:
+            # Prime every set: its first pinned -> device copy pays one-time costs inside the runtime (the first asynchronous copy
+            # on the copy stream took 45 ms in tools/fromhost_hiccup.py, and some boxes showed a second such pause a batch or
+            # two later -- a 60-90 ms step in the middle of a run).  They are paid here, before the first batch is handed out.
+            with torch.cuda.stream(self._copy):
+                for st in self._sets:
+                    st.dev_points.copy_(st.points, non_blocking=True)
+                    st.dev_image.copy_(st.image, non_blocking=True)
+            self._copy.synchronize()
 
     def _stage(self, host, slot, consumer_stream=None):
         """Pack one host batch into staging set `slot` and enqueue its H2D copies on the copy stream.

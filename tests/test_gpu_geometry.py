@@ -245,25 +245,6 @@ def test_voxel_cell_formulation_equals_nine_rounds(case):
     a = ops.voxelize(pts, g.lim, g.aff, g.dims, H.VOXEL_COMPAT)
     b = ops.voxelize(pts, g.lim, g.aff, g.dims, H.VOXEL_COMPAT_ROUNDS)
     assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and float(a.sum()) > 0
-    # round 5: the claims live in a hash of the occupied cells by default (csrc/geometry.hip, k_voxel_hash_*); the dense claim map
-    # (option VOXEL_HASH=0; also the automatic choice when the table would not fit the workspace) must give the same bits, through
-    # the single-frame and the batched entry points, and both must hand the workspace back zero
-    Cz, L, W = g.dims
-    owner = torch.zeros((2, 2, Cz * L * W), dtype=torch.int32, device="cuda")
-    outs = {}
-    for hashed in (1, 0):
-        H.set_option("VOXEL_HASH", hashed)
-        try:
-            outs[hashed] = ops.voxelize(pts, g.lim, g.aff, g.dims, H.VOXEL_COMPAT)
-            bt = torch.full((2, Cz, L, W), float("nan"), device="cuda")
-            ops.voxelize_batch([pts, pts[: pts.shape[0] // 3]], g.lim, g.aff, g.dims, owner, bt)
-            assert int(owner.abs().max()) == 0
-            assert torch.equal(bt[0].view(torch.int32), b.view(torch.int32))
-            outs[(hashed, "part")] = bt[1].clone()
-        finally:
-            H.set_option("VOXEL_HASH", None)
-    assert torch.equal(outs[1].view(torch.int32), b.view(torch.int32)) and torch.equal(outs[0].view(torch.int32), b.view(torch.int32))
-    assert torch.equal(outs[(1, "part")].view(torch.int32), outs[(0, "part")].view(torch.int32))
 
 
 @pytest.mark.parametrize("dtype", [1, 2, 0])
@@ -603,5 +584,5 @@ def test_project_filter_batch_equals_per_frame(mode):
             assert int(cnt[b]) == 0 and not uv[b].any() and not xyz[b].any()
             continue
         uv1, xyz1, c1, _ = ops.project_filter(p, g.lim, crts[b], cfg["image_height"], cfg["image_width"], mode=mode, n_out=rows)
-        assert int(cnt[b]) == int(c1.item()) and int(c1.item()) > 0
+        assert int(cnt[b]) == int(c1.item()) and (int(c1.item()) > 0 or mode == 1)       # (the CARLA matrix keeps nothing under the corrected bounds)
         assert torch.equal(uv[b].view(torch.int32), uv1.view(torch.int32)) and torch.equal(xyz[b].view(torch.int32), xyz1.view(torch.int32))
