@@ -495,6 +495,9 @@ def main():
     # one event per step on the compute stream (recorded, never waited for inside the region): the step-to-step intervals give
     # the MEDIAN step time next to the contract's mean over the K steps
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    for m in marks:                      # (events are created lazily at their first record: not inside the timed region)
+        m.record()
+    barrier()
     t0 = time.perf_counter()
     marks[0].record()
     for s in range(args.steps):

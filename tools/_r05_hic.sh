@@ -1,5 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python3 -m pytest tests/test_gpu_geometry.py -m gpu -x -q -k project_filter_batch 2>&1 | grep -E "assert|Error|equal|^E" | head -20
-REPS=2 python3 tools/fromhost_hiccup.py 2>&1 | grep -v amdgpu.ids
-
+for i in 1 2 3; do HB=8 REPS=1 python3 tools/fromhost_hiccup.py 2>&1 | grep -v amdgpu.ids | grep -v "worker +"; done
+for i in 1 2; do HB=2 REPS=1 python3 tools/fromhost_hiccup.py 2>&1 | grep -v amdgpu.ids | grep -v "worker +"; done
