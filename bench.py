@@ -433,12 +433,16 @@ def main():
     ap.add_argument("--no-other-leg", action="store_true", help="skip the second leg (the input mode that is not timed as `value`)")
     ap.add_argument("--loss-sampling", default="compat", help="compat = host target assignment on numpy's generator exactly like the reference's "
                     "loss.py:74-127 (default, the mode pinned to the reference); device = assignment + loss in one launch (csrc/loss.hip)")
+    ap.add_argument("--loader-workers", type=int, default=0, help="DataLoader worker processes behind FrameLoader in the from-host loop "
+                    "(0 = the staging thread reads and collates itself)")
     ap.add_argument("--chain", action="store_true", help="run the residual stages' 3x3 layers as chain launches (dcf_conv3x3_chain: one launch per "
                     "stage; needs the GPU to itself; level on time with the per-layer launches, DESIGN.md section 9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if os.environ.get("DCF_SWITCH_INTERVAL"):          # experiments: how long a thread may keep the GIL while another waits for it
+        sys.setswitchinterval(float(os.environ["DCF_SWITCH_INTERVAL"]))
     train = pkg("train")
     ws = train.init_distributed()
     rank = dist.get_rank() if ws > 1 else 0
@@ -488,7 +492,7 @@ def main():
     gc.freeze()
     loader = None
     if args.from_host:
-        loader = iter(pkg("frame_loader").FrameLoader(HostFrames(pool, args.steps + 4, args.batch), args.batch))
+        loader = iter(pkg("frame_loader").FrameLoader(HostFrames(pool, args.steps + 4, args.batch), args.batch, num_workers=args.loader_workers))
         for _ in range(3):                                         # staging buffers allocated, copy engines primed, the hand-off queue in
             trainer.one_step_raw(pool.geometry, next(loader))      # steady state -- all outside the timed region
         barrier()
