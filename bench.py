@@ -5,8 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the whole hot path over one batch of synthetic frames already resident
-in HBM: voxelise + project (raw 100k-point clouds), KNN for the 4 fusion sites, ResNet-18 image
+One step = one pass of the whole hot path over one batch of synthetic frames.  By default (--input host, round 5) the frames
+start in HOST memory and reach HBM through frame_loader.FrameLoader's staging thread and copy stream, up to four batches ahead of
+the step that consumes them (the metric starts at the H2D copy of the raw frame), so every step after the first
+finds its inputs resident when it starts; --input resident keeps the raw clouds and images in HBM (rounds 1-4's headline; it runs
+as a short second leg and is reported beside `value` either way).  The path: voxelise + project (raw 100k-point clouds), KNN for the 4 fusion sites, ResNet-18 image
 stream + FPN, LiDAR-BEV stream with 4 continuous-fusion adds, heads/decode, LossTotal,
 backward, gradient all-reduce (RCCL, N>1) and the fused Adam step.  Workload = BASELINE.json
 configs[1] ("cfg2"): KITTI-scale grid 32x704x800, 100k points, 1242x375 RGB, ResNet-18, K=3,
@@ -84,7 +87,7 @@ class FramePool(object):
 
 class HostFrames(torch.utils.data.Dataset):
     """The pool's frames as HOST tensors in the datasets' raw-mode contract (--from-host: the step then includes pinned
-    staging + the PCIe copies of frame_loader.FrameLoader; not the headline number)."""
+    staging + the PCIe copies of frame_loader.FrameLoader: the bench's default input since round 5)."""
     raw = True
 
     def __init__(self, pool, steps, B):
