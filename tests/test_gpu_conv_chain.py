@@ -204,3 +204,34 @@ def test_give_up_is_reported_one_step_later():
         with pytest.raises(pkg("_hip").DcfError) as e:
             net(x, img)
         assert "layer 3" in str(e.value) and "tile 5" in str(e.value)
+
+
+def test_chain_launches_replay_inside_captured_graphs():
+    """The opt-in chain launches inside the captured step (config hip_graphs + conv_chain): a chain launch resets its own arrival
+    counters (the workgroup that finishes last), so a graph replay finds them zero like a first launch -- same prediction and
+    gradients, bit for bit, as the eager chained step and as the eager per-layer step (LiDAR stream only: nothing order-dependent)."""
+    import yaml, os
+    from _util import ROOT, PKG
+    base = yaml.safe_load(open(os.path.join(ROOT, PKG, "config", "config_carla.yaml")))
+    base.update(dict(voxel_length=64, voxel_width=64, dtype="bf16"))
+    base["lidar_module"] = dict(out_feature1=32, out_feature2=64, out_feature3=128, out_feature4=192, out_feature5=256,
+                                num_res_block1=1, num_res_block2=2, num_res_block3=3, num_res_block4=2, num_res_block5=2)
+    det = pkg("detfill")
+    x = torch.from_numpy(det.uniform((1, 32, 64, 64), 21, 0.0, 1.0)).cuda()
+    img = torch.zeros((1, 3, 8, 8), dtype=torch.uint8, device="cuda")
+    R = torch.from_numpy(det.uniform((1, 32, 16, 16), 22, -1.0, 1.0)).cuda()
+    outs = {}
+    for tag, chain, graphs in (("plain", False, False), ("chain", True, False), ("chain+graphs", True, True)):
+        cfg = dict(base, conv_chain=chain, hip_graphs=graphs)
+        net = pkg("model").ObjectDetection_DCF(cfg).cuda()
+        det.fill_state_dict(net)
+        for rep in range(4):                       # (graphs: one capture step, then replays)
+            pred = net(x * (1.0 + 0.1 * rep), img)
+            (pred * R).sum().backward()
+        torch.cuda.synchronize()
+        if chain:
+            assert net._backend._chain_ws and all(int(ws[1].item()) == 0 for ws in net._backend._chain_ws.values())
+        outs[tag] = (pred.detach().clone(), net.flat_grads.clone())
+    for tag in ("chain", "chain+graphs"):
+        assert torch.equal(outs[tag][0], outs["plain"][0]), tag
+        assert torch.equal(outs[tag][1], outs["plain"][1]), tag
