@@ -123,10 +123,14 @@ class _GraphSet(object):
         self.copy_geom = self.sgeom is not None and not geom.get("static")
         self.copy_x = not (geom is not None and geom.get("static"))
         split = m._plan.with_image and self.sgeom is not None
-        # eager warm-up step on the static buffers: lazy allocations (slabs, anchors, workspaces) happen here
+        # eager warm-up step on the static buffers: lazy allocations (slabs, anchors, workspaces) happen here.  (Train-mode
+        # BatchNorm: the warm-up is not a step of the run -- the running statistics it moved are put back.)
+        keep_stats = m._bufflat.clone() if K.bn_train else None
         K.prepare()
         pred = m._plan.forward(K, self.sx, self.simg, self.sgeom, save=True)
         m._plan.backward(K, torch.zeros_like(pred))
+        if keep_stats is not None:
+            m._bufflat.copy_(keep_stats)
         torch.cuda.synchronize()
         # the captured launches carry raw addresses of the backend's per-signature arenas (split-K slabs, dbeta sums, layer
         # table) and of its weight images: this set keeps them alive for as long as its graphs can be replayed, whatever the
@@ -260,11 +264,13 @@ class _FlatParamModule(nn.Module):
             self._param_list.append(p)
             self._param_meta.append((shape, off, n, layout))
         self._buf_meta = []
-        self._nbt_keys = []
+        self._nbt_keys = [key for key, shape, off, n in t.buffers if key.endswith("num_batches_tracked")]
+        # every BatchNorm's num_batches_tracked is a 0-d view of ONE int64 tensor: a train-mode forward bumps them all with one
+        # launch (62 launches per cfg2 step as separate tensors)
+        self._nbtflat = torch.zeros((max(len(self._nbt_keys), 1),), dtype=torch.long, device=device)
         for key, shape, off, n in t.buffers:
             if key.endswith("num_batches_tracked"):
-                self._register(key, torch.zeros((), dtype=torch.long, device=device), True)
-                self._nbt_keys.append(key)
+                self._register(key, self._nbtflat[self._nbt_keys.index(key)], True)
             else:
                 self._register(key, self._bufflat[off:off + n].view(shape), True)
                 self._buf_meta.append((key, shape, off, n))
@@ -323,10 +329,10 @@ class _FlatParamModule(nn.Module):
         for key, shape, off, n in self._buf_meta:
             node, leaf = self._resolve(key)
             node._buffers[leaf] = self._bufflat[off:off + n].view(shape)
-        for key, shape, off, n in self._table.buffers:
-            if key.endswith("num_batches_tracked"):
-                node, leaf = self._resolve(key)
-                node._buffers[leaf] = fn(node._buffers[leaf])
+        self._nbtflat = fn(self._nbtflat).contiguous()
+        for i, key in enumerate(self._nbt_keys):
+            node, leaf = self._resolve(key)
+            node._buffers[leaf] = self._nbtflat[i]
         self._on_moved()
         return self
 
@@ -531,10 +537,9 @@ class ObjectDetection_DCF(_FlatParamModule):
         if K.set_bn_mode(bn_train):
             self._graphs = None          # captured graphs describe the other BatchNorm mode (other layer table, other kernels)
         if bn_train:
-            for b in self._nbt:
-                b += 1
+            self._nbtflat += 1
         need = torch.is_grad_enabled() and self._param_list[0].requires_grad
-        if self.graphs_wanted(x_lidar.shape[0]) and need and not bn_train and not self._profiling():
+        if self.graphs_wanted(x_lidar.shape[0]) and need and not self._profiling():
             if self._graphs is None:
                 self._graphs = _StepGraphs(self)
             if self._graphs.misses > self._graphs.MAX_MISSES and not self._graphs.disabled:
@@ -549,6 +554,9 @@ class ObjectDetection_DCF(_FlatParamModule):
 
     def graphs_wanted(self, batch):
         if self.use_graphs == "auto":
+            # the launch-bound case of a single-rank run: one frame per step.  (Train-mode BatchNorm can be captured too -- set
+            # hip_graphs: true -- but its ~600 launches per cfg2 step are paced by the GPU's own per-kernel dispatch, not by the
+            # host: 8.06 ms replayed against 7.73 ms eager, profiles/r05n_timeline_trainbn.txt.)
             import torch.distributed as dist
             multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
             return batch == 1 and not multi
@@ -615,8 +623,7 @@ class _ResidualStack(_FlatParamModule):
         bn_train = self.bn_mode == "train" or (self.bn_mode == "module" and self.training)
         K.set_bn_mode(bn_train)
         if bn_train:
-            for b in self._nbt:
-                b += 1
+            self._nbtflat += 1
         need = torch.is_grad_enabled() and (self._param_list[0].requires_grad or x.requires_grad)
         K.prepare()
         return _RunStack.apply(x.contiguous(), self._param_list[0], self, need)

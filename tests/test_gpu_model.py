@@ -198,6 +198,32 @@ def test_hip_graph_replay_matches_eager():
     assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_hip_graph_replay_matches_eager_in_train_mode_batchnorm(dtype):
+    """Train-mode BatchNorm under captured graphs (round 5; `hip_graphs: true`): prediction, gradients, running statistics and
+    num_batches_tracked after three steps equal the eager run's -- the capture's warm-up step must not count as a step."""
+    z = load_golden("model_tiny.npz")
+    x = tiny_input().cuda()
+    img = torch.zeros(2, 3, 8, 8, dtype=torch.uint8, device="cuda")
+    R = torch.from_numpy(pkg("detfill").uniform((2, 32, 16, 8), 777, -1.0, 1.0)).cuda()
+    outs = []
+    for graphs in (False, True):
+        net, cfg = build(golden_cfg(z), dtype, hip_graphs=graphs, bn_mode="train")
+        assert net.graphs_wanted(2) == graphs
+        for rep in range(3):
+            pred = net(x * (1.0 + 0.1 * rep), img)
+            (pred * R).sum().backward()
+        sd = net.state_dict()
+        nbt = [int(v) for k, v in sd.items() if k.endswith("num_batches_tracked")]
+        assert nbt and all(v == 3 for v in nbt)
+        outs.append((pred.detach().float().clone(), net.flat_grads.clone(), net._bufflat.clone()))
+    tol = 1e-5 if dtype == "f32" else 2e-2
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=tol, atol=tol)
+    assert (outs[0][1] - outs[1][1]).abs().max() <= tol * max(1.0, float(outs[0][1].abs().max()))
+    assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-6)          # running mean / var: same three updates
+    assert float((outs[0][2] - pkg("model").ObjectDetection_DCF(cfg)._bufflat.cuda()).abs().max()) > 0
+
+
 def test_checkpoint_resume_is_exact(tmp_path):
     """save after 2 steps, resume in a fresh Train, take step 3: identical parameters to an uninterrupted run."""
     z = load_golden("model_tiny.npz")
