@@ -617,6 +617,7 @@ struct WgArgs {
     int pixbytes;              // byte pitch between adjacent x pixels (= Cin*esize except for the stem)
     unsigned xbytes, gbytes;   // tensor sizes for the buffer descriptors
     int dbg;                   // experiments only (DCF_WGRAD3_DBG): 1 = every DMA reads the zero page
+    int xcd;                   // generic kernel: 1 = XCD-aware work mapping (wgrad_xcd(): nsplit a multiple of 8, enough ranges)
 };
 
 template <typename T, int TM, int TN>
@@ -641,7 +642,7 @@ __device__ __forceinline__ void wgrad_body(const WgArgs &a, const int bid)
     // (Used when the number of pixel ranges is a multiple of 8; otherwise plain tile-major order.)
     const int ninner = a.co_tiles * a.ci_tiles * a.kh * a.kw;
     const int L = bid;
-    const bool xcd = ((a.nsplit & 7) == 0) && (a.nsplit >= 48);   // measured: a loss for the few-range (small-M) layers
+    const bool xcd = a.xcd != 0;                  // (host: wgrad_xcd())
     const int slab_id = xcd ? (L / (8 * ninner)) * 8 + (L & 7) : L / ninner;
     if (slab_id >= a.nsplit) return;          // grouped launches round a layer's grid up to a multiple of 8 workgroups
     int t = xcd ? (L >> 3) % ninner : L % ninner;
@@ -1641,6 +1642,20 @@ static bool wgrad3_tiles(int Cin, int Cout, int kh, int kw, int stride, int &TM,
     return true;
 }
 
+// XCD-aware work mapping of the generic weight-gradient kernel (wgrad_body): the (channel tile, tap) workgroups of a pixel range
+// all run on ONE XCD and read the range's gy / x rows out of its L2.  Needs nsplit to be a multiple of 8 (ranges are dealt to the
+// XCDs eight at a time).  Round 4 used it from 48 ranges on ("a loss for the few-range layers" -- measured on launches that did not
+// fill the chip); round 5's per-layer PMC pass (tools/wgrad_traffic.py, profiles/r05o_wgrad_traffic_layers.txt) found the 3x3 /
+// stride-2 layers below that bound fetching 4-6.6 x their tensors (nine taps x 2-12 channel-tile pairs spread over eight L2s):
+// for nine-tap layers the bound is WGRAD_XCD_MIN9 (default 8).
+static int wgrad_xcd_min(int taps)
+{
+    static DcfOpt a_o("WGRAD_XCD_MIN"), b_o("WGRAD_XCD_MIN9");
+    const char *a = a_o.str(), *b = b_o.str();
+    return taps >= 9 ? (b ? atoi(b) : 8) : (a ? atoi(a) : 48);
+}
+static int wgrad_xcd(int nsplit, int taps) { return ((nsplit & 7) == 0 && nsplit >= wgrad_xcd_min(taps)) ? 1 : 0; }
+
 extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int stride)
 {
     int TM, TN, KR;
@@ -1681,7 +1696,12 @@ extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout,
     const int64_t cap = ((int64_t)(cap_env ? atoi(cap_env) : 16) << 20) / slab_bytes;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
-    if (want >= 44 && !dma) want = (want + 4) / 8 * 8;   // multiples of 8 (>= 48) enable the generic kernel's XCD-aware work mapping
+    // multiples of 8 enable the generic kernel's XCD-aware work mapping (wgrad_xcd)
+    const bool generic = !wgrad3_tiles(Cin, Cout, kh, kw, stride, TM, TN, KR);
+    const int xmin = wgrad_xcd_min(kh * kw);
+    const int64_t r8 = (want + 4) / 8 * 8;
+    if (generic && r8 >= 8 && r8 >= xmin) want = r8;
+    else if (want >= 44 && !dma) want = r8;
     return (int)want;
 }
 
@@ -1698,6 +1718,7 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
     a.M = B * Ho * Wo; a.nsplit = nsplit;
+    a.xcd = wgrad_xcd(nsplit, kh * kw);
     a.pixbytes = Cin * (dtype == DCF_F32 ? 4 : 2);
     DCF_REQUIRE((int64_t)B * H * W * a.pixbytes < 0xFFFFFF00ll && (int64_t)a.M * Cout * 4 < 0xFFFFFF00ll, "dcf_conv2d_wgrad: tensor exceeds the 4 GiB buffer-descriptor range");
     a.xbytes = (unsigned)((int64_t)B * H * W * a.pixbytes);
@@ -1878,6 +1899,7 @@ extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_st
                 a.B = it.B; a.H = it.H; a.W = it.W; a.Cin = it.Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = it.Cout;
                 a.kh = it.kh; a.kw = it.kw; a.stride = it.stride; a.pad = it.pad;
                 a.nsplit = it.nsplit;
+                a.xcd = wgrad_xcd(it.nsplit, it.kh * it.kw);
                 a.pixbytes = it.Cin * 2;
                 DCF_REQUIRE((int64_t)it.B * it.H * it.W * a.pixbytes < 0xFFFFFF00ll && (int64_t)it.B * Ho * Wo * it.Cout * 4 < 0xFFFFFF00ll,
                             "dcf_conv2d_wgrad_group: item %d: tensor exceeds the 4 GiB buffer-descriptor range", i);
@@ -1947,6 +1969,7 @@ extern "C" int dcf_stem7x7_wgrad(int dtype, const void *img4, const void *gy, fl
     a.B = B; a.H = H + 6; a.W = W + 8; a.Cin = 32; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
     a.kh = 7; a.kw = 1; a.stride = 2; a.pad = 0;
     a.M = B * Ho * Wo; a.nsplit = nsplit;
+    a.xcd = wgrad_xcd(nsplit, 1);
     a.pixbytes = 4 * (dtype == DCF_F32 ? 4 : 2);
     a.xbytes = (unsigned)((int64_t)B * (H + 6) * (W + 8) * a.pixbytes);
     a.gbytes = (unsigned)((int64_t)a.M * Cout * (dtype == DCF_F32 ? 4 : 2));
