@@ -1,0 +1,18 @@
+cd "$GRAFT_REPO_ROOT"
+CFG4="--dtype f16 --batch 4 --points 120000 --knn 5 --image-stream resnet50"
+run() {
+  python3 bench.py --no-cpu-baseline --no-from-host $2 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+kb={k['kernel']:k['ms_per_step'] for k in d['kernel_breakdown']}
+print('$1', d['value'], d['ms_per_step'], {k:v for k,v in kb.items() if 'wgrad' in k})"
+}
+echo "== cfg4"
+run new "$CFG4"
+DCF_WGRAD_XCD_MIN9=48 run old "$CFG4"
+DCF_WGRAD_XCD_MIN=8 run xcdmin8 "$CFG4"
+DCF_WGRAD_XCD_MIN=24 run xcdmin24 "$CFG4"
+run new "$CFG4"
+echo "== cfg2"
+DCF_WGRAD_XCD_MIN=8 run xcdmin8 ""
+DCF_WGRAD_XCD_MIN=24 run xcdmin24 ""
+run new ""
