@@ -229,6 +229,8 @@ def rocprof_kernel(name):
     dt = "unsignedshort" if "bf16" in kind else ("f16_t" if "f16" in kind else "float")
     if kind.startswith("conv_wgrad3s_grp"):
         return "k_conv_wgrad3s_grp", [dt] + t
+    if kind.startswith("conv_wgrad1s_grp"):                  # shared-staging kernel of the 1x1 / stride-2 layers (conv_wg1.hip)
+        return "k_conv_wgrad1s_grp", [dt] + t
     if kind.startswith("fusion_gather_bwd_inv"):
         return None          # (the profile name carries no element type: no PMC row is matched for it)
     if kind.startswith("conv_wgrad3g_grp"):

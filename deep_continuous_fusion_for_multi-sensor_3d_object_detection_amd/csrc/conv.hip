@@ -1486,6 +1486,15 @@ int dcf_wgrad3v_launch(int dtype, const void *x, const void *gy, float *slabs, f
 int dcf_wgrad3s_kind(int dtype, int B, int H, int W, int Cin, int Cout);
 int dcf_wgrad3s_splits(int kind, int B, int H, int W, int Cin, int Cout);
 int dcf_wgrad3s_launch(int dtype, int kind, const dcf_wgs_item *items, int n, double flops, double bytes, hipStream_t s);
+// shared-staging kernel for the 1x1 (any stride) and 3x3 / stride-2 layers (conv_wg1.hip)
+struct dcf_wg1_item {
+    const void *x, *gy;
+    float *slabs, *gsum;
+    int B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, nsplit;
+};
+int dcf_wgrad1s_kind(int dtype, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad);
+int dcf_wgrad1s_splits(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw);
+int dcf_wgrad1s_launch(int dtype, const dcf_wg1_item *items, int n, double flops, double bytes, hipStream_t s);
 
 // ================================================================== C ABI
 static int check_conv(const char *who, int dtype, int Cin, int Cout, int kh, int kw, int stride)
@@ -1666,6 +1675,11 @@ extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout,
         const int kind = dcf_wgrad3s_kind(DCF_BF16, B, Ho, Wo, Cin, Cout);
         if (kind) return dcf_wgrad3s_splits(kind, B, Ho, Wo, Cin, Cout);
     }
+    // (1x1 and 3x3 / stride-2 layers of the 16-bit types: conv_wg1.hip; the padding is the usual k / 2 there -- a launch with
+    // another one falls back to the generic kernel, which takes any split count)
+    if (!(kh == 3 && kw == 3 && stride == 1) &&
+        dcf_wgrad1s_kind(DCF_BF16, B, Ho * stride + kh, Wo * stride + kw, Cin, Ho, Wo, Cout, kh, kw, stride, kh / 2))
+        return dcf_wgrad1s_splits(B, Ho, Wo, Cin, Cout, kh, kw);
     static DcfOpt gb_o("WGRAD_BLOCKS"); const char *gb = gb_o.str();
     // Workgroups per layer.  The backward issues the weight gradients in grouped launches (dcf_conv2d_wgrad_group), where
     // the layers overlap each other: a layer does not have to fill the chip on its own, and fewer pixel ranges mean fewer
@@ -1735,6 +1749,10 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
             const double wb = (double)a.xbytes + (double)a.gbytes + (double)nsplit * Cout * 9 * Cin * 4.0;
             return dcf_wgrad3s_launch(dtype, kind, &it, 1, flops, wb, s);
         }
+    }
+    if (dcf_wgrad1s_kind(dtype, B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad)) {
+        const dcf_wg1_item it = {x, gy, slabs, gsum, B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, nsplit};
+        return dcf_wgrad1s_launch(dtype, &it, 1, flops, wbytes_, s);
     }
     if (pad == 1 && H == Ho && W == Wo && wgrad3_tiles(Cin, Cout, kh, kw, stride, TM, TN, KR)) {
         const bool dma = dtype != DCF_F32 && wgrad3_dma(Wo, TM, TN) && (int64_t)B * H * W * a.pixbytes < (1ll << 31) && (int64_t)a.M * Cout * 2 < (1ll << 31);
@@ -1827,6 +1845,7 @@ extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_st
         if (it.dtype == DCF_F32) bucket[i] = -1;
         else if (it.pad == 1 && it.kh == 3 && it.kw == 3 && it.stride == 1 && dcf_wgrad3s_kind(it.dtype, it.B, it.H, it.W, it.Cin, it.Cout))
             bucket[i] = 4 + dcf_wgrad3s_kind(it.dtype, it.B, it.H, it.W, it.Cin, it.Cout);       // 5: shared-staging kernel
+        else if (dcf_wgrad1s_kind(it.dtype, it.B, it.H, it.W, it.Cin, Ho, Wo, it.Cout, it.kh, it.kw, it.stride, it.pad)) bucket[i] = 6;   // conv_wg1.hip
         else if (dcf_conv2d_wgrad_groupable(it.dtype, it.B, it.H, it.W, it.Cin, it.Cout, it.kh, it.kw, it.stride, it.pad)) bucket[i] = 0;
         else if (it.pad == 1 && Ho == it.H && Wo == it.W && wgrad3_tiles(it.Cin, it.Cout, it.kh, it.kw, it.stride, TM, TN, KR)) bucket[i] = -1;
         else {
@@ -1855,6 +1874,22 @@ extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_st
                 if (rc) return rc;
             }
         }
+    for (int dt = DCF_BF16; dt <= DCF_F16; ++dt) {
+        std::vector<dcf_wg1_item> ws;
+        double flops = 0.0, bytes = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const dcf_wgrad_item &it = items[i];
+            if (bucket[i] != 6 || it.dtype != dt) continue;
+            const int Ho = (it.H + 2 * it.pad - it.kh) / it.stride + 1, Wo = (it.W + 2 * it.pad - it.kw) / it.stride + 1;
+            ws.push_back({it.x, it.gy, it.slabs, it.gsum, it.B, it.H, it.W, it.Cin, Ho, Wo, it.Cout, it.kh, it.kw, it.stride, it.pad, it.nsplit});
+            flops += 2.0 * it.B * Ho * Wo * (double)it.Cout * it.Cin * it.kh * it.kw;
+            bytes += ((double)it.B * it.H * it.W * it.Cin + (double)it.B * Ho * Wo * it.Cout) * 2.0 + (double)it.nsplit * it.Cout * it.kh * it.kw * it.Cin * 4.0;
+        }
+        if (!ws.empty()) {
+            int rc = dcf_wgrad1s_launch(dt, ws.data(), (int)ws.size(), flops, bytes, s);
+            if (rc) return rc;
+        }
+    }
     static DcfOpt gen_env_o("WGRAD_GROUP_GENERIC"); const char *gen_env = gen_env_o.str();
     const bool group_generic = !(gen_env && atoi(gen_env) == 0);
     for (int bk = 0; bk <= 4; ++bk) {

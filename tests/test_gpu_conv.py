@@ -390,6 +390,95 @@ def test_conv_wgrad_big_launch(shape, dtype):
     assert float((gsum.sum(0).cpu() - want).abs().max()) < 2e-4 * float(gy.abs().sum((0, 2, 3)).max())
 
 
+# ---- shared-staging weight-gradient kernel of the 1x1 (any stride) and 3x3 / stride-2 layers (conv_wg1.hip).  The product sends it
+# layers of >= 2048 output pixels with 64-multiple channel counts (BIG_SHAPES above: the stride-2 stage heads, the ResNet-50 1x1s);
+# here it is FORCED onto small, awkward shapes (option WGRAD1S_MIN_PIXELS = 1): output rows shorter than a 32-pixel stage, ranges
+# crossing rows and frames, half-empty and several channel tiles on either operand, fewer pixels than one stage per group.
+WG1_SHAPES = [
+    (2, 14, 10, 64, 128, 1, 2),      # 1x1 / stride 2, output rows of 5 pixels: a stage spans 6-7 rows
+    (1, 24, 16, 256, 192, 1, 1),     # two input-channel tiles, 1.5 output-channel tiles
+    (2, 9, 7, 320, 64, 1, 1),        # 2.5 input-channel tiles, half an output-channel tile
+    (3, 23, 37, 64, 128, 3, 2),      # 3x3 / stride 2: nine taps, image borders on every side, frames inside ranges
+    (1, 31, 29, 128, 192, 3, 2),     # odd sizes, partial output-channel tile
+    (1, 5, 5, 64, 64, 1, 1),         # 25 pixels: less than one stage per group
+    (4, 47, 156, 256, 512, 1, 2),    # cfg4 layer2 downsample (the product's own route)
+    (2, 88, 100, 192, 256, 3, 2),    # cfg2 stage-5 head (the product's own route)
+]
+
+
+@pytest.fixture
+def force_wg1():
+    H = pkg("_hip")
+    H.set_option("WGRAD1S_MIN_PIXELS", 1)
+    yield
+    H.set_option("WGRAD1S_MIN_PIXELS", None)
+
+
+@pytest.mark.parametrize("dtype", [1, 2])
+@pytest.mark.parametrize("shape", WG1_SHAPES)
+def test_conv_wgrad_shared_staging_1x1_and_stride2(shape, dtype, force_wg1):
+    ops, H = pkg("ops"), pkg("_hip")
+    B, Hh, W, Cin, Cout, k, s = shape
+    pad = k // 2
+    x, w = _mk(shape, dtype, 131)
+    w.requires_grad_(True)
+    y = F.conv2d(x, w, None, s, pad)
+    gy = q(rnd(tuple(y.shape), 132), dtype)
+    y.backward(gy)
+    Ho, Wo = y.shape[-2:]
+    xd, gd = to_dev(x, dtype), to_dev(gy, dtype)
+    ns = ops.conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, k, k, s)
+    H.call("dcf_prof_reset"); H.call("dcf_prof_enable", 1)
+    slabs = torch.full((ns, Cout, k, k, Cin), float("nan"), device="cuda")
+    gsum = torch.full((4 * ns, Cout), float("nan"), device="cuda")
+    ops.conv2d_wgrad(dtype, xd, gd, slabs, ns, k, k, s, pad, gsum)
+    torch.cuda.synchronize(); H.call("dcf_prof_enable", 0)
+    assert any(name.startswith("conv_wgrad1s_grp") for name in H.prof_read()), "the launch did not take conv_wg1.hip"
+    G = slabs.sum(0).cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(G).all(), "unwritten slab entries"
+    assert rel_err(G, w.grad) < 2e-4                              # fp32 accumulation of exactly representable products
+    want = gy.sum((0, 2, 3))
+    assert float((gsum.sum(0).cpu() - want).abs().max()) < 2e-4 * float(gy.abs().sum((0, 2, 3)).max())
+    slabs2 = torch.zeros_like(slabs)                              # fixed-order reduction: bitwise reproducible
+    ops.conv2d_wgrad(dtype, xd, gd, slabs2, ns, k, k, s, pad)
+    assert torch.equal(slabs, slabs2)
+    # the generic kernel on the same split count (option WGRAD1S = 0): same sums up to the fp32 summation order
+    H.set_option("WGRAD1S", 0)
+    try:
+        slabs3 = torch.full_like(slabs, float("nan"))
+        ops.conv2d_wgrad(dtype, xd, gd, slabs3, ns, k, k, s, pad)
+    finally:
+        H.set_option("WGRAD1S", None)
+    assert rel_err(slabs3.sum(0), slabs.sum(0)) < 2e-5
+
+
+def test_wgrad_group_with_shared_staging_layers_equals_single_launches(force_wg1):
+    """The conv_wg1.hip layers of a grouped launch (one launch for all of them, longest first, XCD rotation per layer) write bitwise
+    what their single launches write."""
+    import ctypes
+    ops, H = pkg("ops"), pkg("_hip")
+    dtype = 1
+    keep, items, want = [], [], []
+    for i, (B, Hh, W, Cin, Cout, k, s) in enumerate(WG1_SHAPES[:6] + [(2, 12, 40, 64, 64, 3, 1)]):
+        pad = k // 2
+        Ho, Wo = (Hh + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+        x = to_dev(q(rnd((B, Cin, Hh, W), 500 + i), dtype), dtype)
+        gy = to_dev(q(rnd((B, Cout, Ho, Wo), 600 + i), dtype), dtype)
+        ns = ops.conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, k, k, s)
+        ref = torch.full((ns, Cout, k, k, Cin), float("nan"), device="cuda")
+        refs = torch.full((4 * ns, Cout), float("nan"), device="cuda")
+        ops.conv2d_wgrad(dtype, x, gy, ref, ns, k, k, s, pad, refs)
+        got, gots = torch.full_like(ref, float("nan")), torch.full_like(refs, float("nan"))
+        keep += [x, gy, got, gots]
+        want.append((ref, refs, got, gots))
+        items.append(H.WgradItem(dtype, ns, x.data_ptr(), gy.data_ptr(), got.data_ptr(), gots.data_ptr(), B, Hh, W, Cin, Cout, k, k, s, pad, 0))
+    arr = (H.WgradItem * len(items))(*items)
+    H.call("dcf_conv2d_wgrad_group", ctypes.addressof(arr), len(items), H.stream_ptr())
+    torch.cuda.synchronize()
+    for ref, refs, got, gots in want:
+        assert torch.equal(ref, got) and torch.equal(refs, gots)
+
+
 # ---- spatial-tile streaming kernel (conv_sp.hip: Cin == Cout in {32, 64}, 3x3 / stride 1).  The product sends it the launches of
 # >= 200 000 pixels (BIG_SHAPES above: 704x800x32, 352x400x64, 301x397x64); here it is FORCED onto small, awkward shapes
 # (option CONV_SP_MIN_PIX = 0): partial tiles in both directions, tiles crossing nothing / everything, several frames, fewer
