@@ -43,20 +43,21 @@ struct W1Args {
     int rot;          // XCD of the layer's first run of units
 };
 
-template <typename T, int NS>
-__device__ __forceinline__ void wg1_body(const W1Args &a, const int bid)
+// HA / HB: the workgroup's tile has a second 64-channel sub-tile on the Cout / Cin side.  A sub-tile the layer does not have (64
+// channels on a side, or the last tile of 192) is neither staged nor multiplied: 12 or 8 KiB per stage instead of 16, the waves of
+// the missing quadrants only issue their share of the pieces and keep the barriers.
+template <typename T, int NS, bool HA, bool HB>
+__device__ __forceinline__ void wg1_tile(const W1Args &a, const int unit, const int tap, char *lds_all)
 {
     static_assert(DT<T>::size == 2, "16-bit element types only");
     constexpr int G = 2, NQ = 4, PK = 32;
     constexpr int NP = 16;                              // 1-KiB pieces (8 rows x 128 B) per stage and group: 2 gy + 2 x sub-tiles x 4
-    constexpr int PPW = NP / NQ;                        // pieces per wave and stage: piece `wq` of every sub-tile
+    constexpr int PPW = 2 + (HA ? 1 : 0) + (HB ? 1 : 0);   // pieces per wave and stage: piece `wq` of every sub-tile the tile has
     constexpr int SLOT = NP * 1024;
     constexpr int RING = G * NS * SLOT;
     constexpr int RED = (G - 1) * NQ * 16 * 1024;       // the 64 x 64 tile of every wave of group 1
-    constexpr int LDS_BYTES = (RING > RED ? RING : RED);
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(RING >= RED && RING <= 160 * 1024, "LDS (wg1_body declares the ring; the reduction re-uses it)");
     static_assert((NS - 1) * PPW < 60, "vmcnt range");
-    __shared__ __attribute__((aligned(1024))) char lds_all[LDS_BYTES];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wid / NQ, wq = wid - grp * NQ;
@@ -64,14 +65,8 @@ __device__ __forceinline__ void wg1_body(const W1Args &a, const int bid)
     const unsigned lds0 = lds_addr(lds_all);
     const unsigned ring0 = lds0 + grp * NS * SLOT;
 
-    // XCD-aware unit order: workgroup bid runs on XCD bid & 7; an XCD owns a contiguous run of (range, co tile, ci tile) units x taps
     const int taps = a.kh * a.kw;
     const int tiles2 = a.co_tiles * a.ci_tiles;
-    const int units = tiles2 * a.nsplit, upx = (units + 7) >> 3;
-    const int slot_id = bid >> 3;
-    const int unit = (((bid & 7) - a.rot) & 7) * upx + slot_id / taps;
-    if (unit >= units) return;
-    const int tap = slot_id % taps;
     const int ki = tap / a.kw, kj = tap - ki * a.kw;
     const int slab_id = unit / tiles2;
     const int t2 = unit - slab_id * tiles2;
@@ -89,7 +84,8 @@ __device__ __forceinline__ void wg1_body(const W1Args &a, const int bid)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-    const bool do_sum = (a.gsum != nullptr) && (tap == 0) && (cit == 0) && (qb == 0);
+    const bool active = (HA || qa == 0) && (HB || qb == 0);     // this wave's quadrant exists
+    const bool do_sum = active && (a.gsum != nullptr) && (tap == 0) && (cit == 0) && (qb == 0);
     float fsum[2] = {0.f, 0.f};
 
     // ---- DMA side.  Lane = (row lr of the 8-row piece, 16-B chunk); 128-B rows, 64-B halves swapped on odd row pairs (the four
@@ -126,9 +122,9 @@ __device__ __forceinline__ void wg1_body(const W1Args &a, const int bid)
         const bool inimg = live & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
         const int offB = ((pb * a.H + ih) * a.W + iw) * pixB + colB;
         glds16(srcG, (live & chA[0]) ? (unsigned)offA : OOB, sbase);
-        glds16(srcG, (live & chA[1]) ? (unsigned)(offA + 128) : OOB, sbase + 4 * 1024);
+        if constexpr (HA) glds16(srcG, (live & chA[1]) ? (unsigned)(offA + 128) : OOB, sbase + 4 * 1024);
         glds16(srcX, (inimg & chB[0]) ? (unsigned)offB : OOB, sbase + 8 * 1024);
-        glds16(srcX, (inimg & chB[1]) ? (unsigned)(offB + 128) : OOB, sbase + 12 * 1024);
+        if constexpr (HB) glds16(srcX, (inimg & chB[1]) ? (unsigned)(offB + 128) : OOB, sbase + 12 * 1024);
         p += PK;
         pow_ += PK;
         while (pow_ >= a.Wo) { pow_ -= a.Wo; ++poh; }
@@ -152,6 +148,7 @@ __device__ __forceinline__ void wg1_body(const W1Args &a, const int bid)
         __builtin_amdgcn_s_barrier();                  // everyone's pieces of stage n have landed; stage n - 1 is consumed
         issue(islot);                                  // stage n + NS - 1 (past the end of the range: zeros)
         const char *pa = ringp + rslot * SLOT + rdA, *pbk = ringp + rslot * SLOT + rdB;
+        if (active)
 #pragma unroll
         for (int ks = 0; ks < PK / 16; ++ks) {
             uint4 fa[2], fb[2];
@@ -206,7 +203,7 @@ __device__ __forceinline__ void wg1_body(const W1Args &a, const int bid)
     float *slab = a.slabs + (size_t)slab_id * a.Cout * taps * a.Cin;
     const int r = lane & 31, h = lane >> 5;
     float4 *red4 = reinterpret_cast<float4 *>(lds_all);
-    if (grp > 0) {
+    if (grp > 0 && active) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -218,7 +215,7 @@ __device__ __forceinline__ void wg1_body(const W1Args &a, const int bid)
                 }
     }
     __syncthreads();
-    if (grp == 0) {
+    if (grp == 0 && active) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -233,6 +230,27 @@ __device__ __forceinline__ void wg1_body(const W1Args &a, const int bid)
                     if (co < a.Cout && ci < a.Cin) *reinterpret_cast<float4 *>(slab + ((size_t)co * taps + tap) * a.Cin + ci) = sum;
                 }
             }
+    }
+}
+
+template <typename T, int NS>
+__device__ __forceinline__ void wg1_body(const W1Args &a, const int bid)
+{
+    // XCD-aware unit order: workgroup bid runs on XCD bid & 7; an XCD owns a contiguous run of (range, co tile, ci tile) units x taps
+    const int taps = a.kh * a.kw;
+    const int tiles2 = a.co_tiles * a.ci_tiles;
+    const int units = tiles2 * a.nsplit, upx = (units + 7) >> 3;
+    const int slot_id = bid >> 3;
+    const int unit = (((bid & 7) - a.rot) & 7) * upx + slot_id / taps;
+    if (unit >= units) return;
+    __shared__ __attribute__((aligned(1024))) char lds_all[2 * NS * 16 * 1024];      // two groups' rings of NS 16-KiB stages
+    const int tap = slot_id % taps;
+    const int t2 = unit % tiles2;
+    const bool ha = a.Cout - (t2 / a.ci_tiles) * 128 > 64, hb = a.Cin - (t2 % a.ci_tiles) * 128 > 64;      // workgroup-uniform
+    if (ha) {
+        if (hb) wg1_tile<T, NS, true, true>(a, unit, tap, lds_all); else wg1_tile<T, NS, true, false>(a, unit, tap, lds_all);
+    } else {
+        if (hb) wg1_tile<T, NS, false, true>(a, unit, tap, lds_all); else wg1_tile<T, NS, false, false>(a, unit, tap, lds_all);
     }
 }
 
@@ -306,8 +324,7 @@ int dcf_wgrad1s_launch(int dtype, const dcf_wg1_item *items_in, int n, double fl
         return (int64_t)p.B * p.Ho * p.Wo * q.nsplit > (int64_t)q.B * q.Ho * q.Wo * p.nsplit;
     });
     const dcf_wg1_item *items = sorted.data();
-    static DcfOpt ns_o("WGRAD1S_STAGES"); const char *nse = ns_o.str();
-    const int ns = nse ? atoi(nse) : 4;
+    const int ns = 4;        // (a ring of 3 stages measured the same on cfg4: 0.711 against 0.722 ms; one instantiation is kept)
     for (int i0 = 0; i0 < n; i0 += DCF_W1_GROUP) {
         const int cnt = std::min(DCF_W1_GROUP, n - i0);
         int blocks = 0, rot = 0;
@@ -341,7 +358,8 @@ int dcf_wgrad1s_launch(int dtype, const dcf_wg1_item *items_in, int n, double fl
         else                                                                                                                                      \
             DCF_LAUNCH_WB("conv_wgrad1s_grp_bf16<" #NS_ ">", f, by, s, hipLaunchKernelGGL((k_conv_wgrad1s_grp<bf16_t, NS_>), dim3(blocks), dim3(512), 0, s, g)); \
     } while (0)
-        if (ns == 3) DCF_WG1_GO(3); else DCF_WG1_GO(4);
+        (void)ns;
+        DCF_WG1_GO(4);
 #undef DCF_WG1_GO
     }
     return DCF_OK;
