@@ -286,6 +286,8 @@ int dcf_wgrad1s_kind(int dtype, int B, int H, int W, int Cin, int Ho, int Wo, in
     const bool k3 = kh == 3 && kw == 3 && stride == 2 && pad == 1;
     if (!k1 && !k3) return 0;
     if ((int64_t)B * H * W * Cin * 2 >= (1ll << 31) || (int64_t)B * Ho * Wo * Cout * 2 >= (1ll << 31)) return 0;
+    static DcfOpt c_o("WGRAD1S_MIN_CH"); const char *mc = c_o.str();
+    if (std::min(Cin, Cout) < (mc ? atoi(mc) : 64)) return 0;
     static DcfOpt m_o("WGRAD1S_MIN_PIXELS"); const char *m = m_o.str();
     if ((int64_t)B * Ho * Wo < (m ? atoi(m) : 2048)) return 0;
     return 1;
