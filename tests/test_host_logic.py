@@ -293,3 +293,25 @@ def test_lidar_backbone_network_replans_in_place():
     with pytest.raises(ValueError):
         inner.set_grid(70, 32)                      # not a multiple of 16 (model.py:151)
     assert (inner.config["voxel_length"], inner.config["voxel_width"]) == (64, 32)
+
+
+def test_num_batches_tracked_counters_are_views_of_one_tensor():
+    """Round 5: every BatchNorm's num_batches_tracked (reference state_dict key, 0-d int64) is a view of ONE flat tensor, so a
+    train-mode forward bumps them with one launch; state_dict round trips and .to() keep the views bound."""
+    import importlib
+    import torch
+    m = importlib.import_module("deep_continuous_fusion_for_multi-sensor_3d_object_detection_amd.model")
+    net = m.LidarBackboneNetwork()
+    inner = getattr(net, "net", net)
+    sd = inner.state_dict()
+    keys = [k for k in sd if k.endswith("num_batches_tracked")]
+    assert len(keys) == len(inner._nbt_keys) > 10
+    assert all(sd[k].shape == () and sd[k].dtype == torch.long for k in keys)
+    inner._nbtflat += 3
+    assert all(int(v) == 3 for k, v in inner.state_dict().items() if k.endswith("num_batches_tracked"))
+    sd2 = {k: (torch.tensor(7) if k.endswith("num_batches_tracked") else v.clone()) for k, v in inner.state_dict().items()}
+    inner.load_state_dict(sd2)
+    assert int(inner._nbtflat.min()) == 7 and int(inner._nbtflat.max()) == 7
+    inner.to("cpu")                               # same device: the arenas stay, the views stay bound
+    inner._nbtflat += 1
+    assert all(int(v) == 8 for k, v in inner.state_dict().items() if k.endswith("num_batches_tracked"))
