@@ -34,6 +34,8 @@ class HipBackend(object):
         self._wtab = {}                    # grouped weight gradients: ctypes tables per layer sequence
         self._chain_ok, self._chain_ws, self._chain_tab = {}, {}, {}     # chain launches: support per shape, arrival counters per shape, ctypes tables per length
         self._fn_fwd, self._fn_dgrad = H.fn("dcf_conv2d_fwd"), H.fn("dcf_conv2d_dgrad")
+        self._fn_bnf, self._fn_bnb = H.fn("dcf_bn_train_fwd"), H.fn("dcf_bn_train_bwd")
+        self._bbase = buffers.data_ptr()
         self._pbase, self._gbase = params.data_ptr(), grads.data_ptr()     # (arena slices go to the C ABI as raw addresses: a view costs ~2.5 us)
         self.bn_train = False          # batch statistics instead of running statistics (train-mode BatchNorm)
         # fp8 forward path (0 = off): convolutions with cin >= fp8_min_cin (and cin % 64 == 0) read e4m3 images
@@ -333,10 +335,6 @@ class HipBackend(object):
             y = self._conv_fwd_fp8(L, x, res, relu, nxt)
             L.out_shape = (y.shape[0], y.shape[1], y.shape[2])
             return y
-        if self.bn_train and L.bn is not None:
-            raw = ops.conv2d_fwd(self.dtype, x, self._w(L), None, None, L.kh, L.kw, L.stride, L.pad, False, L.cout_pad)
-            L.out_shape = (raw.shape[0], raw.shape[1], raw.shape[2])
-            return self._bn_fwd(L, raw, res, relu)
         # the step's ~75 plain forward convolutions: per-layer constants cached, arguments marshalled here (ops.conv2d_fwd ->
         # H.call converts 19 generic arguments per launch; this path is ~half its host time)
         shp = x.shape
@@ -346,12 +344,13 @@ class HipBackend(object):
             Ho, Wo = ops.conv_out_size(Hh, L.kh, L.stride, L.pad), ops.conv_out_size(W, L.kw, L.stride, L.pad)
             c = L._fwc = (shp, (B, Ho, Wo, L.cout_pad), (B, Hh, W, Cin, Ho, Wo, L.cout_pad, L.kh, L.kw, L.stride, L.pad), (B, Ho, Wo))
         y = torch.empty(c[1], dtype=x.dtype, device=x.device)
-        rc = self._fn_fwd(self.dtype, x.data_ptr(), self._wbase + L.wfwd_off, self._shift(L), None if res is None else res.data_ptr(),
-                          y.data_ptr(), *c[2], 1 if relu else 0, H.stream_ptr())
+        bn = self.bn_train and L.bn is not None          # train-mode BatchNorm: the raw convolution, then the batch-statistics kernels
+        rc = self._fn_fwd(self.dtype, x.data_ptr(), self._wbase + L.wfwd_off, self._shift(L), None if (res is None or bn) else res.data_ptr(),
+                          y.data_ptr(), *c[2], 1 if (relu and not bn) else 0, H.stream_ptr())
         if rc:
             H.fail("dcf_conv2d_fwd", rc)
         L.out_shape = c[3]
-        return y
+        return self._bn_fwd(L, y, res, relu) if bn else y
 
     # train-mode BatchNorm as separate kernels (batch statistics; running stats updated in place)
     def _ws(self, C):
@@ -360,10 +359,18 @@ class HipBackend(object):
         return self._bn_ws[C]
 
     def _bn_fwd(self, L, raw, res, relu):
+        # (62 calls per cfg2 step, 62 more in the backward: raw addresses and one tensor for mean | invstd -- the generic
+        # ops.bn_train_fwd path built five arena views and three tensors per call)
         C = L.cout_pad
-        y, mean, invstd = ops.bn_train_fwd(self.dtype, raw, self.params[L.gamma_off:], self.params[L.beta_off:], res,
-                                           self.buffers[L.mean_off:], self.buffers[L.var_off:], relu, self._ws(C), BN_EPS, 0.1)
-        L.bn_saved = (raw, mean, invstd)
+        y = torch.empty_like(raw)
+        stat = torch.empty((2, C), dtype=torch.float32, device=raw.device)      # batch mean, 1 / sqrt(var + eps)
+        sp = stat.data_ptr()
+        rc = self._fn_bnf(self.dtype, raw.data_ptr(), self._pbase + 4 * L.gamma_off, self._pbase + 4 * L.beta_off,
+                          None if res is None else res.data_ptr(), y.data_ptr(), sp, sp + 4 * C, self._bbase + 4 * L.mean_off,
+                          self._bbase + 4 * L.var_off, raw.numel() // C, C, BN_EPS, 0.1, 1 if relu else 0, self._ws(C).data_ptr(), H.stream_ptr())
+        if rc:
+            H.fail("dcf_bn_train_fwd", rc)
+        L.bn_saved = (raw, stat)
         return y
 
     def bn_bwd(self, L, g):
@@ -371,10 +378,16 @@ class HipBackend(object):
         chain rule lives in dcf_wgrad_finalize); the batch-statistics backward in train mode."""
         if not (self.bn_train and L.bn is not None):
             return g
-        raw, mean, invstd = L.bn_saved
+        raw, stat = L.bn_saved
         L.bn_saved = None
-        return ops.bn_train_bwd(self.dtype, g, raw, mean, invstd, self.params[L.gamma_off:], self.grads[L.gamma_off:],
-                                self.grads[L.beta_off:], self._ws(L.cout_pad))
+        C = L.cout_pad
+        dx = torch.empty_like(raw)
+        sp = stat.data_ptr()
+        rc = self._fn_bnb(self.dtype, g.data_ptr(), raw.data_ptr(), sp, sp + 4 * C, self._pbase + 4 * L.gamma_off, self._gbase + 4 * L.gamma_off,
+                          self._gbase + 4 * L.beta_off, dx.data_ptr(), raw.numel() // C, C, self._ws(C).data_ptr(), H.stream_ptr())
+        if rc:
+            H.fail("dcf_bn_train_bwd", rc)
+        return dx
 
     def conv_dgrad(self, L, gy, in_shape, res, mask=None):
         """mask: fused ReLU backward of the layer that produced the tensor gx belongs to."""
