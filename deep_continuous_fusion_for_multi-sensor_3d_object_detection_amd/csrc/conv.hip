@@ -617,7 +617,9 @@ struct WgArgs {
     int pixbytes;              // byte pitch between adjacent x pixels (= Cin*esize except for the stem)
     unsigned xbytes, gbytes;   // tensor sizes for the buffer descriptors
     int dbg;                   // experiments only (DCF_WGRAD3_DBG): 1 = every DMA reads the zero page
-    int xcd;                   // generic kernel: 1 = XCD-aware work mapping (wgrad_xcd(): nsplit a multiple of 8, enough ranges)
+    int xcd;                   // generic kernel: 1 = XCD-aware work mapping (wgrad_xcd(): nsplit a multiple of 8, enough ranges);
+                               // k_conv_wgrad3g: the XCD the layer's first run of units goes to (0 in a single launch)
+    int upx;                   // k_conv_wgrad3g: units per XCD (wgrad_upx())
 };
 
 template <typename T, int TM, int TN>
@@ -1186,9 +1188,10 @@ __device__ __forceinline__ void wgrad3g_body(const WgArgs &a, const int bid)
     // (3 * co_tiles * ci_tiles of them) sit on one or two XCDs and find them in that L2 instead of each of the eight
     // XCDs pulling its own copy of every range over the fabric.
     const int tiles2 = a.co_tiles * a.ci_tiles;
-    const int units = tiles2 * a.nsplit, upx = (units + 7) >> 3;
+    // (round 5: units per XCD from the host -- dcf_wgrad_upx -- and a layer's first run goes to XCD a.xcd, as in conv_wgs.hip)
+    const int units = tiles2 * a.nsplit, upx = a.upx;
     const int slot = bid >> 3;
-    const int unit = (bid & 7) * upx + slot / 3;
+    const int unit = (((bid & 7) - a.xcd) & 7) * upx + slot / 3;
     if (unit >= units) return;
     const int ki = slot % 3;
     const int slab_id = unit / tiles2;
@@ -1663,6 +1666,17 @@ static int wgrad_xcd_min(int taps)
     const char *a = a_o.str(), *b = b_o.str();
     return taps >= 9 ? (b ? atoi(b) : 8) : (a ? atoi(a) : 48);
 }
+// Units (= (pixel range, channel-tile pair)) per XCD of the row-sharing / shared-staging kernels: the units dealt evenly over the
+// eight XCDs.  Option WGRAD_RANGE_XCD=1 (round 5, measured, not the default): whole pixel ranges per XCD -- every layer's fetch then
+// falls to 1.0-1.1x of its tensors (profiles/r05v_wgrad_traffic_layers.txt: the step's weight gradients 2.17 GB = 1.05x, against
+// 2.54 GB = 1.20x), but a layer with two or four ranges then runs on two or four XCDs and the grouped launches take LONGER: cfg2
+// 5.32-5.33 ms against 5.21-5.23 (same box), cfg4 11.22 against 11.11 -- these launches wait for their staging, not for HBM.
+int dcf_wgrad_upx(int tiles2, int nsplit)
+{
+    static DcfOpt o("WGRAD_RANGE_XCD"); const char *e = o.str();
+    if (e && atoi(e) == 1) return tiles2 * cdiv(nsplit, 8);
+    return cdiv(tiles2 * nsplit, 8);
+}
 static int wgrad_xcd(int nsplit, int taps) { return ((nsplit & 7) == 0 && nsplit >= wgrad_xcd_min(taps)) ? 1 : 0; }
 
 extern "C" int dcf_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int stride)
@@ -1765,7 +1779,9 @@ extern "C" int dcf_conv2d_wgrad(int dtype, const void *x, const void *gy, float 
         if (dma) {
             const int NW = wgrad3_nw();
             a.per_split = cdiv(cdiv(a.M, NW * nsplit), 32) * 32;
-            grid3 = dim3(8 * 3 * cdiv(a.co_tiles * a.ci_tiles * nsplit, 8));    // see the kernel's work mapping
+            a.upx = dcf_wgrad_upx(a.co_tiles * a.ci_tiles, nsplit);
+            grid3 = dim3(8 * 3 * a.upx);    // see the kernel's work mapping
+            a.xcd = 0;
 #define DCF_WG3G_T(T_, N_, TM_, TN_)                                                                                                                    \
     do {                                                                                                                                                \
         if (NW == 8) DCF_LAUNCH_W("conv_wgrad3g_" N_ "<" #TM_ "," #TN_ ",2,8>", flops, s, hipLaunchKernelGGL((k_conv_wgrad3g<T_, TM_, TN_, 2, 8>), grid3, dim3(512), 0, s, a)); \
@@ -1895,7 +1911,7 @@ extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_st
     for (int bk = 0; bk <= 4; ++bk) {
         for (int dt = DCF_BF16; dt <= DCF_F16; ++dt) {
             WgGroup g;
-            int cnt = 0, blocks = 0;
+            int cnt = 0, blocks = 0, rot3 = 0;
             double flops = 0.0, bytes = 0.0;     // algorithmic: x and gy read once, one fp32 slab set written
             auto flush = [&]() -> int {
                 if (cnt == 0) return DCF_OK;
@@ -1946,7 +1962,10 @@ extern "C" int dcf_conv2d_wgrad_group(const dcf_wgrad_item *items, int n, dcf_st
                     a.per_split = cdiv(cdiv(a.M, 8 * it.nsplit), 32) * 32;
                     a.co_tiles = cdiv(it.Cout, 64);
                     a.ci_tiles = cdiv(it.Cin, 64);
-                    blocks += 8 * 3 * cdiv(a.co_tiles * a.ci_tiles * it.nsplit, 8);
+                    const int upx3 = a.upx = dcf_wgrad_upx(a.co_tiles * a.ci_tiles, it.nsplit);
+                    blocks += 8 * 3 * upx3;
+                    a.xcd = rot3;
+                    rot3 = (rot3 + cdiv(a.co_tiles * a.ci_tiles * it.nsplit, upx3)) & 7;
                 } else {
                     int TM, TN;
                     wgrad_tiles(it.Cin, it.Cout, TM, TN);

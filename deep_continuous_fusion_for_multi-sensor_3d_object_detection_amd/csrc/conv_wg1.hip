@@ -41,6 +41,7 @@ struct W1Args {
     int co_tiles, ci_tiles;
     unsigned xbytes, gbytes;
     int rot;          // XCD of the layer's first run of units
+    int upx;          // units per XCD
 };
 
 // HA / HB: the workgroup's tile has a second 64-channel sub-tile on the Cout / Cin side.  A sub-tile the layer does not have (64
@@ -239,7 +240,7 @@ __device__ __forceinline__ void wg1_body(const W1Args &a, const int bid)
     // XCD-aware unit order: workgroup bid runs on XCD bid & 7; an XCD owns a contiguous run of (range, co tile, ci tile) units x taps
     const int taps = a.kh * a.kw;
     const int tiles2 = a.co_tiles * a.ci_tiles;
-    const int units = tiles2 * a.nsplit, upx = (units + 7) >> 3;
+    const int units = tiles2 * a.nsplit, upx = a.upx;       // whole ranges per XCD (dcf_wgrad_upx, conv.hip)
     const int slot_id = bid >> 3;
     const int unit = (((bid & 7) - a.rot) & 7) * upx + slot_id / taps;
     if (unit >= units) return;
@@ -271,6 +272,8 @@ __global__ void __launch_bounds__(512) k_conv_wgrad1s_grp(W1Group g)
 }
 
 }  // namespace
+
+int dcf_wgrad_upx(int tiles2, int nsplit);       // conv.hip
 
 // ---- host side (called from conv.hip)
 // 1 = this kernel's layer: 16-bit, 64-channel granules on both sides (a stage row of a sub-tile is 128 B), 1x1 / pad 0 at any stride
@@ -344,7 +347,7 @@ int dcf_wgrad1s_launch(int dtype, const dcf_wg1_item *items_in, int n, double fl
             a.xbytes = (unsigned)((int64_t)it.B * it.H * it.W * it.Cin * 2);
             a.gbytes = (unsigned)((int64_t)it.B * it.Ho * it.Wo * it.Cout * 2);
             g.off[k] = blocks;
-            const int units = a.co_tiles * a.ci_tiles * it.nsplit, upx = cdiv(units, 8);
+            const int units = a.co_tiles * a.ci_tiles * it.nsplit, upx = a.upx = dcf_wgrad_upx(a.co_tiles * a.ci_tiles, it.nsplit);
             blocks += 8 * it.kh * it.kw * upx;
             a.rot = rot;
             rot = (rot + cdiv(units, upx)) & 7;

@@ -45,6 +45,7 @@ struct WsArgs {
     int co_tiles, ci_tiles;
     unsigned xbytes, gbytes;
     int rot;          // XCD of the layer's first pixel range
+    int upx;          // units per XCD (dcf_wgrad_upx, conv.hip)
 };
 
 template <typename T, int A, int BC, int G, int NS>
@@ -77,7 +78,9 @@ __device__ __forceinline__ void wgs_body(const WsArgs &a, const int bid)
     // them: L2 hits.  rot = the XCD the layer's first run goes to (the one after the previous layer's last: the few long
     // units of a jointly planned layer must not pile up on the first XCDs).
     const int tiles2 = a.co_tiles * a.ci_tiles;
-    const int units = tiles2 * a.nsplit, upx = (units + 7) >> 3;
+    // (units per XCD: dcf_wgrad_upx, conv.hip -- dealt evenly by default; option WGRAD_RANGE_XCD=1 = whole pixel ranges per XCD:
+    // less traffic, longer launches)
+    const int units = tiles2 * a.nsplit, upx = a.upx;
     const int slot_id = bid >> 3;
     const int unit = (((bid & 7) - a.rot) & 7) * upx + slot_id / 3;
     if (unit >= units) return;
@@ -352,6 +355,8 @@ __global__ void __launch_bounds__(A * BC * G * 64) k_conv_wgrad3s_grp(WsGroup g)
 
 }  // namespace
 
+int dcf_wgrad_upx(int tiles2, int nsplit);       // conv.hip
+
 // ---- host side (called from conv.hip)
 // kind: 0 = not this kernel's; 1 = quadrants 2 x 2 (128 x 128 output tiles: channel counts multiples of 128)
 int dcf_wgrad3s_kind(int dtype, int B, int H, int W, int Cin, int Cout)
@@ -412,7 +417,7 @@ int dcf_wgrad3s_launch(int dtype, int kind, const dcf_wgs_item *items_in, int n,
             a.xbytes = (unsigned)((int64_t)it.B * it.H * it.W * it.Cin * 2);
             a.gbytes = (unsigned)((int64_t)it.B * it.H * it.W * it.Cout * 2);
             g.off[k] = blocks;
-            const int units = a.co_tiles * a.ci_tiles * it.nsplit, upx = cdiv(units, 8);
+            const int units = a.co_tiles * a.ci_tiles * it.nsplit, upx = a.upx = dcf_wgrad_upx(a.co_tiles * a.ci_tiles, it.nsplit);
             blocks += 8 * 3 * upx;
             a.rot = rot;
             rot = (rot + cdiv(units, upx)) & 7;
