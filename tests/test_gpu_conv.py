@@ -403,6 +403,10 @@ WG1_SHAPES = [
     (1, 5, 5, 64, 64, 1, 1),         # 25 pixels: less than one stage per group
     (4, 47, 156, 256, 512, 1, 2),    # cfg4 layer2 downsample (the product's own route)
     (2, 88, 100, 192, 256, 3, 2),    # cfg2 stage-5 head (the product's own route)
+    (2, 20, 90, 64, 128, 3, 2),      # 3x3 / stride 2: 64 input channels (no second x sub-tile), rows of 45 pixels, frames inside ranges
+    (1, 9, 79, 128, 192, 3, 2),      # odd width: the last tap column is the image's last column
+    (3, 7, 100, 192, 64, 3, 2),      # 1.5 input-channel tiles, half an output-channel tile, odd height
+    (1, 353, 399, 128, 192, 3, 2),   # odd sizes, many stages per group
 ]
 
 
