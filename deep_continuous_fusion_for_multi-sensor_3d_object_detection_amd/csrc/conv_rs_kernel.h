@@ -202,9 +202,15 @@ constexpr int rs_allowed(int kj, int dw, int dx, int pww, int pxa, int pxb)
 // shorter than the wait / barrier / issue sequence around them.  The weights then run DW = 3 DX taps ahead in a ring of
 // DW + 3 tap slots (a stage's three slots are refilled together), the pixel tile DX stages ahead as before.
 // CHAIN: the launch walks RsChainArgs::L layer by layer (see RsChainArgs); false = one layer, as before.
-template <typename T, int TN, int TMMAX, int WN, int WM, int DW, int DX, bool S3 = false, bool CHAIN = false>
-__global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(typename std::conditional<CHAIN, RsChainArgs, RsArgs>::type arg)
+// L16 (round 5, option RS_L16, the small-M kind only): SIXTEEN waves -- waves 0 .. NW-1 are CONSUMERS (the tiles, fragment reads,
+// MFMAs and the epilogue of the 8-wave form, but no DMA piece), waves NW .. 2 NW - 1 are LOADERS (wave NW + w issues exactly the
+// pieces wave w issues in the 8-wave form, right behind each barrier, and nothing else: they are "waves without tiles", the C == 0
+// path below).  tools/probe/fill_paths.hip: a CU takes 59-63 B/clk into LDS when eight waves do nothing but issue pieces, the
+// 8-wave form reaches 20-23 because a wave stalled in the vector-memory queue issues no MFMAs either.
+template <typename T, int TN, int TMMAX, int WN, int WM, int DW, int DX, bool S3 = false, bool CHAIN = false, bool L16 = false>
+__global__ void __launch_bounds__(WN * WM * 64 * (L16 ? 2 : 1)) k_conv3x3_rs(typename std::conditional<CHAIN, RsChainArgs, RsArgs>::type arg)
 {
+    static_assert(!(L16 && CHAIN), "the 16-wave form has no chain mode");
     const RsArgs &a = rs_common(arg);
     static_assert(DT<T>::size == 2, "16-bit element types only");
     constexpr int NW = WN * WM;
@@ -222,7 +228,9 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(typename std::condi
     __shared__ __attribute__((aligned(1024))) char lds[NSW * WSLOT + NSX * XSLOT];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wid16 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = L16 && wid16 >= WN * WM;           // (wave-uniform)
+    const int wid = L16 ? (wid16 >= WN * WM ? wid16 - WN * WM : wid16) : wid16;
     // Waves w and w + 4 share a SIMD (and its matrix pipe): the second half of the workgroup takes the position shares in
     // reverse order, so that a wave with one tile more is paired with a wave with one tile less.
     const int wn = wid / WM;
@@ -263,7 +271,7 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(typename std::condi
 
     // this wave's share of the position tiles
     const int base = a.npt / WM, rem = a.npt - base * WM;
-    const int cnt = base + (wm < rem ? 1 : 0);
+    const int cnt = loader ? 0 : base + (wm < rem ? 1 : 0);          // (a loader wave of the 16-wave form has no tiles)
     const int pt0 = wm * base + min(wm, rem);
 
     // operands of the layer being computed (chain mode: re-bound at every layer switch)
@@ -324,7 +332,7 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(typename std::condi
     // pixel pieces of this wave: piece index wid + j*NW (interleaved: the waves' counts differ by at most one);
     // LDS row i of the slot = padded position q0 - 1 + i
     const int npieces = (BM + 2 + 7) >> 3;
-    const int cntx = __builtin_amdgcn_readfirstlane(wid < npieces ? (npieces - 1 - wid) / NW + 1 : 0);
+    const int cntx = __builtin_amdgcn_readfirstlane((L16 && !loader) ? 0 : (wid < npieces ? (npieces - 1 - wid) / NW + 1 : 0));   // (a consumer of the 16-wave form issues nothing)
     const int pxa = (cntx + 1) >> 1, pxb = cntx >> 1;      // issued with tap 0 / tap 1 of an earlier stage
     int xbase[PXW], xok[PXW];
     const int rowpitch = a.W * rowbytes;
@@ -533,8 +541,9 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(typename std::condi
     //     step t needs group t - DW (its weights) and, on tap 0, groups 3 (s - DX) and 3 (s - DX) + 1 (its pixel tile).
     // Per step: counted wait -> barrier (everyone's pieces have landed, everyone is done with the slots about to be
     // refilled) -> issue group t -> MFMAs.
-    auto main_loop = [&](auto CNT, auto CNTX) {
+    auto main_loop = [&](auto CNT, auto CNTX, auto NOISSUE) {
         constexpr int C = decltype(CNT)::value, CX = decltype(CNTX)::value;
+        constexpr bool NI = decltype(NOISSUE)::value;          // 16-wave form, consumer: this wave issues no DMA piece at all
         constexpr int PXA = (CX + 1) / 2, PXB = CX / 2;
         constexpr int DS = (2 + DW) / 3 > DX ? (2 + DW) / 3 : DX;          // stages the bookkeeping looks ahead
         constexpr int A0 = rs_allowed(0, DW, DX, PWW, PXA, PXB), A1 = rs_allowed(1, DW, DX, PWW, PXA, PXB), A2 = rs_allowed(2, DW, DX, PWW, PXA, PXB);
@@ -555,6 +564,7 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(typename std::condi
             if (++lcc == cchunks) { lcc = 0; ++lki; }
         };
         auto issue_w = [&](int d, int kj, int slot) __attribute__((always_inline)) {                  // weights of tap kj of stage s + d
+            if constexpr (NI) return;
             const unsigned dst = __builtin_amdgcn_readfirstlane(ldsW0 + slot * WSLOT + wid * PWW * 1024);
             const bool ok = kis[d] < 3 && !(DCF_DBG(a) & 16);
             const unsigned koff = (unsigned)(wst[d] + kj * tapstep);
@@ -562,6 +572,7 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(typename std::condi
             for (int j = 0; j < PWW; ++j) glds16(srcW, ok ? wbase[j] + koff : OOB, dst + j * 1024);
         };
         auto issue_x = [&](int d, int slot, int j0, int j1) __attribute__((always_inline)) {          // pieces j0 .. j1-1 of the pixel tile of stage s + d
+            if constexpr (NI) return;
             const int ki = kis[d];
 #pragma unroll
             for (int j = 0; j < PXW; ++j)
@@ -641,6 +652,7 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(typename std::condi
                 // matrix pipes idle.  Waves without tiles (C == 0) issue theirs at once.
                 const int xj0 = kj == 0 ? 0 : PXA, xj1 = kj == 0 ? PXA : (kj == 1 ? CX : PXA);       // kj == 2: none
                 auto issue_part = [&](int part) {
+                    if constexpr (NI) return;
                     if constexpr (S3) {                    // the stage's group (3 PWW weight + CX pixel pieces) over its 12 K-quarters
                         const int q12 = kj * 4 + part;
                         const bool okw = kis[DX] < 3 && !(DCF_DBG(a) & 16);
@@ -788,16 +800,40 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(typename std::condi
         }
     };
     // dispatch on (tiles, pixel pieces) of this wave; the host's plan keeps both inside the instantiated ranges
+    if constexpr (L16) {
+        // consumers: (tiles, no pieces, no issue); loaders: (no tiles, their pieces)
+        if (!loader) {
+            switch (cnt) {
+            case 0: main_loop(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), std::true_type()); break;
+            case 1: main_loop(std::integral_constant<int, 1>(), std::integral_constant<int, 0>(), std::true_type()); break;
+            case 2: main_loop(std::integral_constant<int, (TMMAX >= 2 ? 2 : TMMAX)>(), std::integral_constant<int, 0>(), std::true_type()); break;
+            case 3: main_loop(std::integral_constant<int, (TMMAX >= 3 ? 3 : TMMAX)>(), std::integral_constant<int, 0>(), std::true_type()); break;
+            case 4: main_loop(std::integral_constant<int, (TMMAX >= 4 ? 4 : TMMAX)>(), std::integral_constant<int, 0>(), std::true_type()); break;
+            default: main_loop(std::integral_constant<int, TMMAX>(), std::integral_constant<int, 0>(), std::true_type()); break;
+            }
+        } else {
+            switch (cntx) {
+            case 0: main_loop(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), std::false_type()); break;
+            case 1: main_loop(std::integral_constant<int, 0>(), std::integral_constant<int, (PXW >= 1 ? 1 : PXW)>(), std::false_type()); break;
+            case 2: main_loop(std::integral_constant<int, 0>(), std::integral_constant<int, (PXW >= 2 ? 2 : PXW)>(), std::false_type()); break;
+            case 3: main_loop(std::integral_constant<int, 0>(), std::integral_constant<int, (PXW >= 3 ? 3 : PXW)>(), std::false_type()); break;
+            case 4: main_loop(std::integral_constant<int, 0>(), std::integral_constant<int, (PXW >= 4 ? 4 : PXW)>(), std::false_type()); break;
+            case 5: main_loop(std::integral_constant<int, 0>(), std::integral_constant<int, (PXW >= 5 ? 5 : PXW)>(), std::false_type()); break;
+            case 6: main_loop(std::integral_constant<int, 0>(), std::integral_constant<int, (PXW >= 6 ? 6 : PXW)>(), std::false_type()); break;
+            default: main_loop(std::integral_constant<int, 0>(), std::integral_constant<int, PXW>(), std::false_type()); break;
+            }
+        }
+    } else {
 #define DCF_RS_CX(C_)                                                                                               \
     switch (cntx) {                                                                                                  \
-    case 0: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, 0>()); break;                   \
-    case 1: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, (PXW >= 1 ? 1 : PXW)>()); break; \
-    case 2: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, (PXW >= 2 ? 2 : PXW)>()); break; \
-    case 3: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, (PXW >= 3 ? 3 : PXW)>()); break; \
-    case 4: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, (PXW >= 4 ? 4 : PXW)>()); break; \
-    case 5: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, (PXW >= 5 ? 5 : PXW)>()); break; \
-    case 6: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, (PXW >= 6 ? 6 : PXW)>()); break; \
-    default: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, PXW>()); break;                \
+    case 0: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, 0>(), std::false_type()); break;                   \
+    case 1: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, (PXW >= 1 ? 1 : PXW)>(), std::false_type()); break; \
+    case 2: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, (PXW >= 2 ? 2 : PXW)>(), std::false_type()); break; \
+    case 3: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, (PXW >= 3 ? 3 : PXW)>(), std::false_type()); break; \
+    case 4: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, (PXW >= 4 ? 4 : PXW)>(), std::false_type()); break; \
+    case 5: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, (PXW >= 5 ? 5 : PXW)>(), std::false_type()); break; \
+    case 6: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, (PXW >= 6 ? 6 : PXW)>(), std::false_type()); break; \
+    default: main_loop(std::integral_constant<int, C_>(), std::integral_constant<int, PXW>(), std::false_type()); break;                \
     }
     switch (cnt) {
     case 0: DCF_RS_CX(0) break;
@@ -808,6 +844,7 @@ __global__ void __launch_bounds__(WN * WM * 64) k_conv3x3_rs(typename std::condi
     default: DCF_RS_CX(TMMAX) break;
     }
 #undef DCF_RS_CX
+    }
     chain_finish();
 }
 

@@ -390,6 +390,36 @@ def test_conv_wgrad_big_launch(shape, dtype):
     assert float((gsum.sum(0).cpu() - want).abs().max()) < 2e-4 * float(gy.abs().sum((0, 2, 3)).max())
 
 
+# ---- the small-M kind of the row-sharing kernel with eight consumer + eight loader waves (option RS_L16, the default for that kind
+# since round 5): every consumer wave does exactly what it does in the 8-wave form, the loader waves issue the same DMA pieces into the
+# same LDS slots -- so the results must be BIT-identical, also over persistent workgroups that walk several tiles (RS_KIND / RS_NPT
+# force the small-M kind onto launches of more tiles than workgroups) and for the 128- / 192-channel kinds that the option can reach.
+@pytest.mark.parametrize("dtype", [1, 2])
+@pytest.mark.parametrize("case", [((2, 44, 50, 256, 256), None, None), ((2, 24, 78, 256, 256), None, None), ((2, 12, 39, 512, 512), None, None),
+                                  ((6, 44, 50, 256, 256), 2, 1), ((3, 88, 100, 64, 64), 2, 3), ((2, 88, 100, 192, 192), None, None)])
+def test_conv_rs_sixteen_wave_form_equals_eight_wave_form(case, dtype):
+    ops, H = pkg("ops"), pkg("_hip")
+    (B, Hh, W, Cin, Cout), kind, npt = case
+    shape = (B, Hh, W, Cin, Cout, 3, 1)
+    x, w = _mk(shape, dtype, 171)
+    shift = rnd((Cout,), 172).cuda()
+    res = to_dev(q(rnd((B, Cout, Hh, W), 173), dtype), dtype)
+    xd, wd = to_dev(x, dtype), to_dev(w, dtype)
+    outs = []
+    try:
+        if kind is not None:
+            H.set_option("RS_KIND", kind); H.set_option("RS_NPT", npt)
+        for l16 in (0, 7):
+            H.set_option("RS_L16", l16)
+            y = ops.conv2d_fwd(dtype, xd, wd, shift, res, 3, 3, 1, 1, True, Cout)
+            outs.append(y.clone())
+    finally:
+        H.set_option("RS_L16", None); H.set_option("RS_KIND", None); H.set_option("RS_NPT", None)
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.relu(F.conv2d(x, w, None, 1, 1) + shift.cpu().view(1, -1, 1, 1) + from_dev(res))
+    _assert_quantised_close(from_dev(outs[1]), ref, dtype, "16-wave form")
+
+
 # ---- shared-staging weight-gradient kernel of the 1x1 (any stride) and 3x3 / stride-2 layers (conv_wg1.hip).  The product sends it
 # layers of >= 2048 output pixels with 64-multiple channel counts (BIG_SHAPES above: the stride-2 stage heads, the ResNet-50 1x1s);
 # here it is FORCED onto small, awkward shapes (option WGRAD1S_MIN_PIXELS = 1): output rows shorter than a 32-pixel stage, ranges

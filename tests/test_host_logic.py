@@ -254,13 +254,18 @@ def test_profile_names_map_to_kernels_of_the_committed_pmc_summary():
     chained = any(f == "k_conv3x3_rs" and a[-1] == "true" and len(a) == 9 for f, a in have)
     names = ["conv_fwd_bf16<sp32>", "conv_dgrad_bf16<sp32>", "conv_fwd_bf16<sp64>", "conv_fwd_bf16<rs1,9>", "conv_fwd_bf16<rs2,5>"]
     names += ["conv_fwd_bf16<rs0,9,x7>", "conv_dgrad_bf16<rs1,7,x11>", "conv_fwd_bf16<rs2,3,x11>"] if chained else ["conv_fwd_bf16<rs0,9>"]
+    # (summaries collected before the 16-wave form of the small-M kind existed -- up to r05w -- carry nine template arguments)
+    nargs = max((len(a) for f, a in have if f == "k_conv3x3_rs"), default=10)
     for name in names:
         func, args = bench.rocprof_kernel(name)
+        if func == "k_conv3x3_rs" and nargs < 10:
+            args = args[:-1]
         if legacy and func == "k_conv3x3_rs":
             assert args[-1] == "false"
             args = args[:-1]
         assert (func, tuple(args)) in have, (name, func, args)
-    assert bench.rocprof_kernel("conv_dgrad_bf16<rs2,4,x21>") == ("k_conv3x3_rs", ["unsignedshort", "1", "1", "2", "4", "6", "2", "true", "true"])
+    assert bench.rocprof_kernel("conv_dgrad_bf16<rs2,4,x21>") == ("k_conv3x3_rs", ["unsignedshort", "1", "1", "2", "4", "6", "2", "true", "true", "false"])
+    assert bench.rocprof_kernel("conv_fwd_bf16<rs2,3>") == ("k_conv3x3_rs", ["unsignedshort", "1", "1", "2", "4", "6", "2", "true", "false", "true"])
 
 
 def test_lidar_backbone_network_needs_no_config():
