@@ -248,7 +248,7 @@ def rocprof_kernel(name):
         return "k_conv3x3_lc", [dt] + {0: ["2", "5", "2", "2", "3", "440"], 1: ["1", "5", "2", "2", "4", "504"]}[int(t[0][2:])]
     if t and t[0].startswith("rs"):                          # row-sharing kernel: 'conv_fwd_bf16<rs0,9>' = tile kind 0, 9 position tiles;
         chain = "true" if any(x.startswith("x") for x in t[1:]) else "false"      # 'conv_fwd_bf16<rs2,4,x21>' = a chain of 21 layers in one launch
-        l16 = "true" if (int(t[0][2:]) == 2 and chain == "false") else "false"    # the small-M kind runs as 8 consumer + 8 loader waves (option RS_L16, default)
+        l16 = "8" if (int(t[0][2:]) == 2 and chain == "false") else "0"           # loader waves: the small-M kind runs as 8 consumers + 8 loaders (option RS_L16, default)
         return "k_conv3x3_rs", [dt] + {0: ["1", "5", "4", "2", "2", "1", "false"], 1: ["1", "3", "2", "4", "2", "1", "false"],
                                        2: ["1", "1", "2", "4", "6", "2", "true"]}[int(t[0][2:])] + [chain, l16]
     if kind.startswith("conv_fwd") or kind.startswith("conv_dgrad") or kind.startswith("stem_fwd"):

@@ -32,17 +32,20 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
     static DcfOpt s3e_o("RS_S3"); const char *s3e = s3e_o.str();
     const bool s3 = !(s3e && atoi(s3e) == 0);
     static DcfOpt l16_o("RS_L16"); const char *l16e = l16_o.str();
-    // eight consumer + eight loader waves (conv_rs_kernel.h): bit 0 = the small-M kind, bit 1 = kind 1, bit 2 = kind 0
-    const int l16m = l16e ? atoi(l16e) : 1;
-    const bool l16 = (l16m & 1) != 0;
+    // consumer + loader waves (conv_rs_kernel.h).  RS_L16: the small-M kind with eight loader waves (default on).  RS_L12 (bit 0 =
+    // kind 1, bit 1 = kind 0): those kinds with FOUR loader waves -- twelve waves leave a wave the 170 registers their 48-80
+    // accumulator registers need (with sixteen waves they spill, and scratch traffic counts in the DMA's vmcnt)
+    const bool l16 = !(l16e && atoi(l16e) == 0);
+    static DcfOpt l12_o("RS_L12"); const char *l12e = l12_o.str();
+    const int l12m = l12e ? atoi(l12e) : 0;
 #define DCF_RS(T_)                                                                                                               \
     do {                                                                                                                         \
-        if (p.kind == 0 && (l16m & 4)) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1, false, false, true>), grid, dim3(1024), 0, s, a)); \
+        if (p.kind == 0 && (l12m & 2)) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1, false, false, 4>), grid, dim3(768), 0, s, a)); \
         else if (p.kind == 0) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1>), grid, dim3(512), 0, s, a)); \
-        else if (p.kind == 1 && (l16m & 2)) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 3, 2, 4, 2, 1, false, false, true>), grid, dim3(1024), 0, s, a)); \
+        else if (p.kind == 1 && (l12m & 1)) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 3, 2, 4, 2, 1, false, false, 4>), grid, dim3(768), 0, s, a)); \
         else if (p.kind == 1) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 3, 2, 4, 2, 1>), grid, dim3(512), 0, s, a)); \
         else if (!s3) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 5, 2>), grid, dim3(512), 0, s, a)); \
-        else if (l16) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 6, 2, true, false, true>), grid, dim3(1024), 0, s, a)); \
+        else if (l16) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 6, 2, true, false, 8>), grid, dim3(1024), 0, s, a)); \
         else DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 6, 2, true>), grid, dim3(512), 0, s, a)); \
     } while (0)
     if (dtype == DCF_F16) DCF_RS(f16_t); else DCF_RS(bf16_t);

@@ -207,19 +207,24 @@ constexpr int rs_allowed(int kj, int dw, int dx, int pww, int pxa, int pxb)
 // pieces wave w issues in the 8-wave form, right behind each barrier, and nothing else: they are "waves without tiles", the C == 0
 // path below).  tools/probe/fill_paths.hip: a CU takes 59-63 B/clk into LDS when eight waves do nothing but issue pieces, the
 // 8-wave form reaches 20-23 because a wave stalled in the vector-memory queue issues no MFMAs either.
-template <typename T, int TN, int TMMAX, int WN, int WM, int DW, int DX, bool S3 = false, bool CHAIN = false, bool L16 = false>
-__global__ void __launch_bounds__(WN * WM * 64 * (L16 ? 2 : 1)) k_conv3x3_rs(typename std::conditional<CHAIN, RsChainArgs, RsArgs>::type arg)
+// NL = number of loader waves (0: the 8-wave form; 8: sixteen waves; 4: twelve waves -- a loader then issues the pieces of TWO of
+// the 8-wave form's waves, i.e. the pieces are dealt over NL waves instead of over NW; 170 registers per wave instead of 128, for
+// the kinds whose consumers hold 48-80 accumulator registers).
+template <typename T, int TN, int TMMAX, int WN, int WM, int DW, int DX, bool S3 = false, bool CHAIN = false, int NL = 0>
+__global__ void __launch_bounds__((WN * WM + NL) * 64) k_conv3x3_rs(typename std::conditional<CHAIN, RsChainArgs, RsArgs>::type arg)
 {
-    static_assert(!(L16 && CHAIN), "the 16-wave form has no chain mode");
+    constexpr bool L16 = NL > 0;
+    static_assert(!(L16 && CHAIN) && (NL == 0 || NL == 4 || NL == 8), "loader waves: none, four or eight; no chain mode with them");
     const RsArgs &a = rs_common(arg);
     static_assert(DT<T>::size == 2, "16-bit element types only");
     constexpr int NW = WN * WM;
     constexpr int BN = WN * TN * 32;
     constexpr int BMMAX = WM * TMMAX * 32;
-    constexpr int PWW = BN / 8 / NW;                          // weight pieces (8 rows x 128 B) per wave and tap
-    static_assert(PWW >= 1 && PWW * 8 * NW == BN, "weight tile must split evenly over the waves");
-    constexpr int PXW = (BMMAX + 2 + 8 * NW - 1) / (8 * NW);  // most pixel pieces a wave issues per stage
-    constexpr int XROWS = NW * PXW * 8;
+    constexpr int NWD = NL ? NL : NW;                         // waves the DMA pieces are dealt over
+    constexpr int PWW = BN / 8 / NWD;                         // weight pieces (8 rows x 128 B) per issuing wave and tap
+    static_assert(PWW >= 1 && PWW * 8 * NWD == BN, "weight tile must split evenly over the issuing waves");
+    constexpr int PXW = (BMMAX + 2 + 8 * NWD - 1) / (8 * NWD);  // most pixel pieces an issuing wave issues per stage
+    constexpr int XROWS = NWD * PXW * 8;
     constexpr int WSLOT = BN * 128, XSLOT = XROWS * 128;
     constexpr int NSW = S3 ? DW + 3 : DW + 1, NSX = DX + 1;
     static_assert(DW >= 1 && DX >= 1 && (DW - 1) * PWW + 2 * PXW <= 48, "vmcnt range");
@@ -230,7 +235,7 @@ __global__ void __launch_bounds__(WN * WM * 64 * (L16 ? 2 : 1)) k_conv3x3_rs(typ
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid16 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = L16 && wid16 >= WN * WM;           // (wave-uniform)
-    const int wid = L16 ? (wid16 >= WN * WM ? wid16 - WN * WM : wid16) : wid16;
+    const int wid = L16 ? (wid16 >= WN * WM ? wid16 - WN * WM : wid16) : wid16;       // consumer: its tile role; loader: its DMA share
     // Waves w and w + 4 share a SIMD (and its matrix pipe): the second half of the workgroup takes the position shares in
     // reverse order, so that a wave with one tile more is paired with a wave with one tile less.
     const int wn = wid / WM;
@@ -332,7 +337,7 @@ __global__ void __launch_bounds__(WN * WM * 64 * (L16 ? 2 : 1)) k_conv3x3_rs(typ
     // pixel pieces of this wave: piece index wid + j*NW (interleaved: the waves' counts differ by at most one);
     // LDS row i of the slot = padded position q0 - 1 + i
     const int npieces = (BM + 2 + 7) >> 3;
-    const int cntx = __builtin_amdgcn_readfirstlane((L16 && !loader) ? 0 : (wid < npieces ? (npieces - 1 - wid) / NW + 1 : 0));   // (a consumer of the 16-wave form issues nothing)
+    const int cntx = __builtin_amdgcn_readfirstlane((L16 && !loader) ? 0 : (wid < npieces ? (npieces - 1 - wid) / NWD + 1 : 0));   // (a consumer of the 12- / 16-wave forms issues nothing)
     const int pxa = (cntx + 1) >> 1, pxb = cntx >> 1;      // issued with tap 0 / tap 1 of an earlier stage
     int xbase[PXW], xok[PXW];
     const int rowpitch = a.W * rowbytes;
@@ -346,7 +351,7 @@ __global__ void __launch_bounds__(WN * WM * 64 * (L16 ? 2 : 1)) k_conv3x3_rs(typ
         }
 #pragma unroll
         for (int j = 0; j < PXW; ++j) {
-            const int i = (wid + j * NW) * 8 + l8;
+            const int i = (wid + j * NWD) * 8 + l8;
             const int p = q0 - 1 + i;
             const int R = p >= 0 ? p / Wp : 0;
             const int c = p - R * Wp;
@@ -577,7 +582,7 @@ __global__ void __launch_bounds__(WN * WM * 64 * (L16 ? 2 : 1)) k_conv3x3_rs(typ
 #pragma unroll
             for (int j = 0; j < PXW; ++j)
                 if (j >= j0 && j < j1) {
-                    const unsigned dst = __builtin_amdgcn_readfirstlane(ldsX0 + slot * XSLOT + (wid + j * NW) * 1024);
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(ldsX0 + slot * XSLOT + (wid + j * NWD) * 1024);
                     gldsX(srcX, (((xok[j] >> ki) & 1) && !(DCF_DBG(a) & 2)) ? (unsigned)(xbase[j] + xst[d]) : OOB, dst);
                 }
         };
@@ -668,7 +673,7 @@ __global__ void __launch_bounds__(WN * WM * 64 * (L16 ? 2 : 1)) k_conv3x3_rs(typ
 #pragma unroll
                         for (int j = 0; j < PXW; ++j)
                             if (j < CX && (3 * PWW + j) % 12 == q12) {
-                                const unsigned dst = __builtin_amdgcn_readfirstlane(ldsX0 + xsi * XSLOT + (wid + j * NW) * 1024);
+                                const unsigned dst = __builtin_amdgcn_readfirstlane(ldsX0 + xsi * XSLOT + (wid + j * NWD) * 1024);
                                 gldsX(srcX, (((xok[j] >> kix) & 1) && !(DCF_DBG(a) & 2)) ? (unsigned)(xbase[j] + xst[DX]) : OOB, dst);
                             }
                         return;
@@ -684,7 +689,7 @@ __global__ void __launch_bounds__(WN * WM * 64 * (L16 ? 2 : 1)) k_conv3x3_rs(typ
 #pragma unroll
                     for (int j = 0; j < PXW; ++j)
                         if (j >= xj0 && j < xj1 && ((PWW + j - xj0) & 3) == part) {
-                            const unsigned dst = __builtin_amdgcn_readfirstlane(ldsX0 + xsi * XSLOT + (wid + j * NW) * 1024);
+                            const unsigned dst = __builtin_amdgcn_readfirstlane(ldsX0 + xsi * XSLOT + (wid + j * NWD) * 1024);
                             gldsX(srcX, (((xok[j] >> kix) & 1) && !(DCF_DBG(a) & 2)) ? (unsigned)(xbase[j] + xst[DX]) : OOB, dst);
                         }
                 };
@@ -812,16 +817,13 @@ __global__ void __launch_bounds__(WN * WM * 64 * (L16 ? 2 : 1)) k_conv3x3_rs(typ
             default: main_loop(std::integral_constant<int, TMMAX>(), std::integral_constant<int, 0>(), std::true_type()); break;
             }
         } else {
+#define DCF_RS_LX(X_) case X_: main_loop(std::integral_constant<int, 0>(), std::integral_constant<int, (PXW >= X_ ? X_ : PXW)>(), std::false_type()); break;
             switch (cntx) {
-            case 0: main_loop(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), std::false_type()); break;
-            case 1: main_loop(std::integral_constant<int, 0>(), std::integral_constant<int, (PXW >= 1 ? 1 : PXW)>(), std::false_type()); break;
-            case 2: main_loop(std::integral_constant<int, 0>(), std::integral_constant<int, (PXW >= 2 ? 2 : PXW)>(), std::false_type()); break;
-            case 3: main_loop(std::integral_constant<int, 0>(), std::integral_constant<int, (PXW >= 3 ? 3 : PXW)>(), std::false_type()); break;
-            case 4: main_loop(std::integral_constant<int, 0>(), std::integral_constant<int, (PXW >= 4 ? 4 : PXW)>(), std::false_type()); break;
-            case 5: main_loop(std::integral_constant<int, 0>(), std::integral_constant<int, (PXW >= 5 ? 5 : PXW)>(), std::false_type()); break;
-            case 6: main_loop(std::integral_constant<int, 0>(), std::integral_constant<int, (PXW >= 6 ? 6 : PXW)>(), std::false_type()); break;
+                DCF_RS_LX(0) DCF_RS_LX(1) DCF_RS_LX(2) DCF_RS_LX(3) DCF_RS_LX(4) DCF_RS_LX(5) DCF_RS_LX(6) DCF_RS_LX(7)
+                DCF_RS_LX(8) DCF_RS_LX(9) DCF_RS_LX(10) DCF_RS_LX(11) DCF_RS_LX(12)
             default: main_loop(std::integral_constant<int, 0>(), std::integral_constant<int, PXW>(), std::false_type()); break;
             }
+#undef DCF_RS_LX
         }
     } else {
 #define DCF_RS_CX(C_)                                                                                               \

@@ -264,8 +264,8 @@ def test_profile_names_map_to_kernels_of_the_committed_pmc_summary():
             assert args[-1] == "false"
             args = args[:-1]
         assert (func, tuple(args)) in have, (name, func, args)
-    assert bench.rocprof_kernel("conv_dgrad_bf16<rs2,4,x21>") == ("k_conv3x3_rs", ["unsignedshort", "1", "1", "2", "4", "6", "2", "true", "true", "false"])
-    assert bench.rocprof_kernel("conv_fwd_bf16<rs2,3>") == ("k_conv3x3_rs", ["unsignedshort", "1", "1", "2", "4", "6", "2", "true", "false", "true"])
+    assert bench.rocprof_kernel("conv_dgrad_bf16<rs2,4,x21>") == ("k_conv3x3_rs", ["unsignedshort", "1", "1", "2", "4", "6", "2", "true", "true", "0"])
+    assert bench.rocprof_kernel("conv_fwd_bf16<rs2,3>") == ("k_conv3x3_rs", ["unsignedshort", "1", "1", "2", "4", "6", "2", "true", "false", "8"])
 
 
 def test_lidar_backbone_network_needs_no_config():
