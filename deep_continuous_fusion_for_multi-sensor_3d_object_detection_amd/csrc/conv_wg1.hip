@@ -47,7 +47,10 @@ struct W1Args {
 // HA / HB: the workgroup's tile has a second 64-channel sub-tile on the Cout / Cin side.  A sub-tile the layer does not have (64
 // channels on a side, or the last tile of 192) is neither staged nor multiplied: 12 or 8 KiB per stage instead of 16, the waves of
 // the missing quadrants only issue their share of the pieces and keep the barriers.
-template <typename T, int NS, bool HA, bool HB>
+// LD (round 5, last change): SIXTEEN waves -- waves 0-7 are the consumers (fragment reads, MFMAs, reduction, stores; no DMA piece),
+// waves 8-15 the loaders (wave 8 + w issues exactly the pieces wave w issued and nothing else).  As in conv_rs_kernel.h: a wave
+// stalled in the vector-memory queue issues no MFMAs, and this kernel's waves spent half their cycles parked at the fill.
+template <typename T, int NS, bool HA, bool HB, bool LD>
 __device__ __forceinline__ void wg1_tile(const W1Args &a, const int unit, const int tap, char *lds_all)
 {
     static_assert(DT<T>::size == 2, "16-bit element types only");
@@ -60,7 +63,9 @@ __device__ __forceinline__ void wg1_tile(const W1Args &a, const int unit, const 
     static_assert(RING >= RED && RING <= 160 * 1024, "LDS (wg1_body declares the ring; the reduction re-uses it)");
     static_assert((NS - 1) * PPW < 60, "vmcnt range");
     const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wid16 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool loader = LD && wid16 >= G * NQ;          // (wave-uniform)
+    const int wid = loader ? wid16 - G * NQ : wid16;
     const int grp = wid / NQ, wq = wid - grp * NQ;
     const int qa = wq >> 1, qb = wq & 1;                // this wave's quadrant: co sub-tile qa, ci sub-tile qb
     const unsigned lds0 = lds_addr(lds_all);
@@ -85,7 +90,8 @@ __device__ __forceinline__ void wg1_tile(const W1Args &a, const int unit, const 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-    const bool active = (HA || qa == 0) && (HB || qb == 0);     // this wave's quadrant exists
+    const bool active = !loader && (HA || qa == 0) && (HB || qb == 0);     // this wave computes a quadrant that exists
+    const bool issues = LD ? loader : true;                                 // this wave issues DMA pieces
     const bool do_sum = active && (a.gsum != nullptr) && (tap == 0) && (cit == 0) && (qb == 0);
     float fsum[2] = {0.f, 0.f};
 
@@ -116,6 +122,7 @@ __device__ __forceinline__ void wg1_tile(const W1Args &a, const int unit, const 
     }
     const int dh = ki - a.pad, dw = kj - a.pad;
     auto issue = [&](int is) {
+        if (!issues) return;
         const unsigned sbase = __builtin_amdgcn_readfirstlane(ring0 + is * SLOT) + (unsigned)wq * 1024u;
         const bool live = p < q_end;
         const int offA = p * rowA + colA;
@@ -234,7 +241,7 @@ __device__ __forceinline__ void wg1_tile(const W1Args &a, const int unit, const 
     }
 }
 
-template <typename T, int NS>
+template <typename T, int NS, bool LD>
 __device__ __forceinline__ void wg1_body(const W1Args &a, const int bid)
 {
     // XCD-aware unit order: workgroup bid runs on XCD bid & 7; an XCD owns a contiguous run of (range, co tile, ci tile) units x taps
@@ -249,9 +256,9 @@ __device__ __forceinline__ void wg1_body(const W1Args &a, const int bid)
     const int t2 = unit % tiles2;
     const bool ha = a.Cout - (t2 / a.ci_tiles) * 128 > 64, hb = a.Cin - (t2 % a.ci_tiles) * 128 > 64;      // workgroup-uniform
     if (ha) {
-        if (hb) wg1_tile<T, NS, true, true>(a, unit, tap, lds_all); else wg1_tile<T, NS, true, false>(a, unit, tap, lds_all);
+        if (hb) wg1_tile<T, NS, true, true, LD>(a, unit, tap, lds_all); else wg1_tile<T, NS, true, false, LD>(a, unit, tap, lds_all);
     } else {
-        if (hb) wg1_tile<T, NS, false, true>(a, unit, tap, lds_all); else wg1_tile<T, NS, false, false>(a, unit, tap, lds_all);
+        if (hb) wg1_tile<T, NS, false, true, LD>(a, unit, tap, lds_all); else wg1_tile<T, NS, false, false, LD>(a, unit, tap, lds_all);
     }
 }
 
@@ -262,13 +269,13 @@ struct W1Group {
     int n;
 };
 
-template <typename T, int NS>
-__global__ void __launch_bounds__(512) k_conv_wgrad1s_grp(W1Group g)
+template <typename T, int NS, bool LD = false>
+__global__ void __launch_bounds__(LD ? 1024 : 512) k_conv_wgrad1s_grp(W1Group g)
 {
     int i = 0;
 #pragma unroll
     for (int k = 1; k < DCF_W1_GROUP; ++k) i += (k < g.n && (int)blockIdx.x >= g.off[k]);
-    wg1_body<T, NS>(g.a[i], (int)blockIdx.x - g.off[i]);
+    wg1_body<T, NS, LD>(g.a[i], (int)blockIdx.x - g.off[i]);
 }
 
 }  // namespace
@@ -356,15 +363,17 @@ int dcf_wgrad1s_launch(int dtype, const dcf_wg1_item *items_in, int n, double fl
         for (int k = cnt; k < DCF_W1_GROUP; ++k) g.a[k] = g.a[0];
         g.n = cnt;
         const double f = flops * cnt / n, by = bytes * cnt / n;       // a launch's share when a bucket spills into several
-#define DCF_WG1_GO(NS_)                                                                                                                           \
+#define DCF_WG1_GO(NS_, LD_, TH_)                                                                                                                 \
     do {                                                                                                                                          \
         if (dtype == DCF_F16)                                                                                                                     \
-            DCF_LAUNCH_WB("conv_wgrad1s_grp_f16<" #NS_ ">", f, by, s, hipLaunchKernelGGL((k_conv_wgrad1s_grp<f16_t, NS_>), dim3(blocks), dim3(512), 0, s, g)); \
+            DCF_LAUNCH_WB("conv_wgrad1s_grp_f16<" #NS_ ">", f, by, s, hipLaunchKernelGGL((k_conv_wgrad1s_grp<f16_t, NS_, LD_>), dim3(blocks), dim3(TH_), 0, s, g)); \
         else                                                                                                                                      \
-            DCF_LAUNCH_WB("conv_wgrad1s_grp_bf16<" #NS_ ">", f, by, s, hipLaunchKernelGGL((k_conv_wgrad1s_grp<bf16_t, NS_>), dim3(blocks), dim3(512), 0, s, g)); \
+            DCF_LAUNCH_WB("conv_wgrad1s_grp_bf16<" #NS_ ">", f, by, s, hipLaunchKernelGGL((k_conv_wgrad1s_grp<bf16_t, NS_, LD_>), dim3(blocks), dim3(TH_), 0, s, g)); \
     } while (0)
         (void)ns;
-        DCF_WG1_GO(4);
+        static DcfOpt ld_o("WGRAD1S_L16"); const char *lde = ld_o.str();
+        // eight consumer + eight loader waves (default) or the eight-wave form (WGRAD1S_L16=0)
+        if (lde && atoi(lde) == 0) DCF_WG1_GO(4, false, 512); else DCF_WG1_GO(4, true, 1024);
 #undef DCF_WG1_GO
     }
     return DCF_OK;
