@@ -249,8 +249,12 @@ def rocprof_kernel(name):
     if t and t[0].startswith("rs"):                          # row-sharing kernel: 'conv_fwd_bf16<rs0,9>' = tile kind 0, 9 position tiles;
         chain = "true" if any(x.startswith("x") for x in t[1:]) else "false"      # 'conv_fwd_bf16<rs2,4,x21>' = a chain of 21 layers in one launch
         l16 = "8" if (int(t[0][2:]) == 2 and chain == "false") else "0"           # loader waves: the small-M kind runs as 8 consumers + 8 loaders (option RS_L16, default)
+        kind = int(t[0][2:])
+        npt = int(t[1]) if len(t) > 1 and t[1].isdigit() else 99
+        if kind == 1 and npt <= 8 and chain == "false":      # <= 256 positions per workgroup: the instantiation with the pixel tile two stages ahead
+            return "k_conv3x3_rs", [dt, "1", "2", "2", "4", "2", "2", "false", chain, l16]
         return "k_conv3x3_rs", [dt] + {0: ["1", "5", "4", "2", "2", "1", "false"], 1: ["1", "3", "2", "4", "2", "1", "false"],
-                                       2: ["1", "1", "2", "4", "6", "2", "true"]}[int(t[0][2:])] + [chain, l16]
+                                       2: ["1", "1", "2", "4", "6", "2", "true"]}[kind] + [chain, l16]
     if kind.startswith("conv_fwd") or kind.startswith("conv_dgrad") or kind.startswith("stem_fwd"):
         tr = "true" if "dgrad" in kind else "false"
         if t and t[-1].startswith("dma"):
@@ -273,6 +277,19 @@ def _csrc_digest():
     return hsh.hexdigest()[:16]
 
 
+def pmc_summaries(tag=""):
+    """The committed PMC summaries profiles/rNN<letters>_<tag>pmc_traffic.csv of a workload (tag "" = cfg2), oldest first: by round,
+    then by the letters of the profile set (a .. z, then za, zb, ... -- the sets of a round are named in that order)."""
+    import glob, re
+    pat = re.compile(r"^r(\d\d)([a-z]+)_" + re.escape(tag) + r"pmc_traffic\.csv$")
+    out = []
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_" + tag + "pmc_traffic.csv")):
+        m = pat.match(os.path.basename(f))
+        if m:
+            out.append(((int(m.group(1)), len(m.group(2)), m.group(2)), f))
+    return [f for _, f in sorted(out)]
+
+
 def pmc_traffic(name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
     command (profiles/*_pmc_traffic.csv; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).
@@ -281,7 +298,7 @@ def pmc_traffic(name):
     import csv, glob
     if PMC_TAG is None:
         return None, None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9][a-z]_" + PMC_TAG + "pmc_traffic.csv")))
+    files = pmc_summaries(PMC_TAG)
     if not files:
         return None, None, None
     want = rocprof_kernel(name)

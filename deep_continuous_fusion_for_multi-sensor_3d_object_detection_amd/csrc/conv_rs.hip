@@ -32,17 +32,20 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
     static DcfOpt s3e_o("RS_S3"); const char *s3e = s3e_o.str();
     const bool s3 = !(s3e && atoi(s3e) == 0);
     static DcfOpt l16_o("RS_L16"); const char *l16e = l16_o.str();
-    // consumer + loader waves (conv_rs_kernel.h).  RS_L16: the small-M kind with eight loader waves (default on).  RS_L12 (bit 0 =
-    // kind 1, bit 1 = kind 0): those kinds with FOUR loader waves -- twelve waves leave a wave the 170 registers their 48-80
-    // accumulator registers need (with sixteen waves they spill, and scratch traffic counts in the DMA's vmcnt)
+    // consumer + loader waves (conv_rs_kernel.h).  RS_L16: the small-M kind with eight loader waves (default on).  (The other two
+    // kinds were built with four loader waves -- twelve waves leave a wave the 170 registers their 48-80 accumulator registers
+    // need; with sixteen they spill -- and measured no faster: DESIGN.md section 9; the instantiations are not kept.)
     const bool l16 = !(l16e && atoi(l16e) == 0);
-    static DcfOpt l12_o("RS_L12"); const char *l12e = l12_o.str();
-    const int l12m = l12e ? atoi(l12e) : 0;
+    // kind 1 with at most eight position tiles per workgroup: the same tile shape instantiated for <= 256 positions (TMMAX = 2), whose
+    // smaller pixel slot leaves LDS for a THIRD one -- the pixel tile of a stage then goes out two stages ahead (DX = 2) instead of
+    // during the previous stage's first taps, 1-3 taps (~0.4-1.2 us) before its first use: those pixels come from HBM / the fabric,
+    // and the loop waited for them at every stage.  Option RS_DX2=0: the DX = 1 instantiation for every launch of the kind.
+    static DcfOpt dx2_o("RS_DX2"); const char *dx2e = dx2_o.str();
+    const bool dx2 = p.kind == 1 && p.npt <= 8 && !(dx2e && atoi(dx2e) == 0);
 #define DCF_RS(T_)                                                                                                               \
     do {                                                                                                                         \
-        if (p.kind == 0 && (l12m & 2)) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1, false, false, 4>), grid, dim3(768), 0, s, a)); \
-        else if (p.kind == 0) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1>), grid, dim3(512), 0, s, a)); \
-        else if (p.kind == 1 && (l12m & 1)) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 3, 2, 4, 2, 1, false, false, 4>), grid, dim3(768), 0, s, a)); \
+        if (p.kind == 0) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1>), grid, dim3(512), 0, s, a)); \
+        else if (dx2) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 2, 2, 4, 2, 2>), grid, dim3(512), 0, s, a)); \
         else if (p.kind == 1) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 3, 2, 4, 2, 1>), grid, dim3(512), 0, s, a)); \
         else if (!s3) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 5, 2>), grid, dim3(512), 0, s, a)); \
         else if (l16) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 6, 2, true, false, 8>), grid, dim3(1024), 0, s, a)); \

@@ -239,8 +239,8 @@ def test_profile_names_map_to_kernels_of_the_committed_pmc_summary():
     sys.path.insert(0, root)
     import bench
     # the newest cfg2 summary (rNNx_pmc_traffic.csv; the cfg4 / cfg5 ones carry a tag in their names)
-    files = sorted(f for f in glob.glob(os.path.join(root, "profiles", "r0[3-9][a-z]_pmc_traffic.csv")))
-    assert files
+    files = bench.pmc_summaries("")              # (oldest first; r05z < r05zb < r05zc)
+    assert files and [os.path.basename(f)[:5] for f in files if os.path.basename(f).startswith("r05z")][:3] == ["r05z_", "r05zb", "r05zc"][:len([f for f in files if os.path.basename(f).startswith("r05z")])]
     legacy = int(os.path.basename(files[-1])[1:3]) < 5          # before round 5 k_conv3x3_rs had no CHAIN template argument
     have = set()
     for row in csv.DictReader(open(files[-1])):
@@ -252,7 +252,9 @@ def test_profile_names_map_to_kernels_of_the_committed_pmc_summary():
     # (round 5: a summary collected with the opt-in chain launches carries the CHAIN = true instantiations, and the 128-channel stage's
     # single-layer instantiation is then not in a cfg2 step; the default tree runs the single-layer ones)
     chained = any(f == "k_conv3x3_rs" and a[-1] == "true" and len(a) == 9 for f, a in have)
-    names = ["conv_fwd_bf16<sp32>", "conv_dgrad_bf16<sp32>", "conv_fwd_bf16<sp64>", "conv_fwd_bf16<rs1,9>", "conv_fwd_bf16<rs2,5>"]
+    # (since the end of round 5 every kind-1 launch of a cfg2 step has at most eight position tiles and runs the DX = 2 instantiation)
+    dx2 = any(f == "k_conv3x3_rs" and a[1:7] == ("1", "2", "2", "4", "2", "2") for f, a in have)
+    names = ["conv_fwd_bf16<sp32>", "conv_dgrad_bf16<sp32>", "conv_fwd_bf16<sp64>", "conv_fwd_bf16<rs1,7>" if dx2 else "conv_fwd_bf16<rs1,9>", "conv_fwd_bf16<rs2,5>"]
     names += ["conv_fwd_bf16<rs0,9,x7>", "conv_dgrad_bf16<rs1,7,x11>", "conv_fwd_bf16<rs2,3,x11>"] if chained else ["conv_fwd_bf16<rs0,9>"]
     # (summaries collected before the 16-wave form of the small-M kind existed -- up to r05w -- carry nine template arguments)
     nargs = max((len(a) for f, a in have if f == "k_conv3x3_rs"), default=10)
