@@ -2,6 +2,7 @@
 """Benchmark of the continuous-fusion train step on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          (no launcher: starts its N rank processes itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -430,6 +431,55 @@ def cpu_baseline(cfg, pool_seed):
                       "area ratio (%.1fs)" % (threads, t_geo, t_knn, t_fwd, t_bwd, t_one)}
 
 
+def rank_envs(n, port, base=None):
+    """Environment of each of the n rank processes of one node (what `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node n --master-addr 127.0.0.1` would export): rank r drives GPU r."""
+    base = dict(os.environ if base is None else base)
+    return [dict(base, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), RANK=str(r), LOCAL_RANK=str(r),
+                 LOCAL_WORLD_SIZE=str(n)) for r in range(n)]
+
+
+def launch_ranks(n, argv):
+    """Starts n rank processes of this script (one per GPU, reference train.py:24,51-56 is the single-process launcher this
+    replaces) and waits for them; rank 0 inherits stdout, so its JSON line is this process's output.  Called BEFORE anything
+    initialises HIP here: a process that has must not start ranks by exec, and this one only forks children.  Returns the exit
+    status to leave with (the first failing rank's; the others are ended when one fails)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()              # does not initialise the GPU
+    if have < n and os.environ.get("DCF_DIST_BACKEND", "nccl") == "nccl":
+        print("bench.py: --gpus %d but %d GPU(s) visible (RCCL needs one device per rank; DCF_DIST_BACKEND=gloo lets ranks share a "
+              "GPU for functional runs)" % (n, have), file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r, env in enumerate(rank_envs(n, port)):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    status = 0
+    try:
+        live = list(procs)
+        while live:
+            for p in list(live):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                live.remove(p)
+                if rc != 0 and status == 0:
+                    status = rc if rc > 0 else 1
+                    for q in live:                # a rank failed: its peers would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -463,6 +513,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    env_ws = os.environ.get("WORLD_SIZE")
+    if env_ws is None and args.gpus > 1:
+        # `python bench.py --gpus N` typed without a launcher: this process becomes the launcher (it has not touched the GPU and
+        # never will), its N children are the ranks
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if env_ws is not None and int(env_ws) != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher's WORLD_SIZE is %s: one rank per GPU, the two must agree" % (args.gpus, env_ws))
 
     if os.environ.get("DCF_SWITCH_INTERVAL"):          # experiments: how long a thread may keep the GIL while another waits for it
         sys.setswitchinterval(float(os.environ["DCF_SWITCH_INTERVAL"]))

@@ -49,14 +49,14 @@ def _start_dp_children(config):
             log = open(os.path.join(outdir, "n2_r%d.log" % rank), "w")
             procs.append(("n2_r%d" % rank, subprocess.Popen([sys.executable, child, "rccl2", str(rank), port3, outdir], stdout=log,
                                                             stderr=subprocess.STDOUT, cwd=ROOT)))
-    # ... and bench.py itself with two ranks on this one GPU (gloo instead of RCCL): the N > 1 code path of the benchmark
-    port2 = _free_port()
-    for rank in range(2):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port2, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", DCF_DIST_BACKEND="gloo")
-        out = open(os.path.join(outdir, "bench_r%d.out" % rank), "w")
-        log = open(os.path.join(outdir, "bench_r%d.log" % rank), "w")
-        procs.append(("bench_r%d" % rank, subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                                                            "--no-cpu-baseline"], stdout=out, stderr=log, cwd=ROOT, env=env)))
+    # ... and bench.py itself exactly as the driver types it -- `python bench.py --gpus 2 ...`, NO launcher and none of its variables
+    # in the environment: bench.py has to start its two ranks itself (both on this one GPU, gloo instead of RCCL)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["DCF_DIST_BACKEND"] = "gloo"
+    out = open(os.path.join(outdir, "bench_launch.out"), "w")
+    log = open(os.path.join(outdir, "bench_launch.log"), "w")
+    procs.append(("bench_launch", subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                                                    "--no-cpu-baseline"], stdout=out, stderr=log, cwd=ROOT, env=env)))
     config._dcf_dp_children = (outdir, procs)
 
 

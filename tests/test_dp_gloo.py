@@ -88,3 +88,94 @@ def test_single_process_world_is_one():
     assert train.world() == 1
     g = torch.ones(4)
     assert train.allreduce_grads(g) == 1 and torch.equal(g, torch.ones(4))
+
+
+def _bucket_worker(rank, world, port, out):
+    """One of `world` ranks: the backend's bucket bookkeeping (HipBackend.bucket_ready / end_backward over the cfg2 layer table)
+    drives Train._bucket_ready exactly as a backward does -- lidar_hi, lidar+fusion, image_hi, remainder -- on a CPU gradient
+    arena; the collectives are gloo's asynchronous all-reduces."""
+    import importlib
+    import sys
+    import types
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    engine = importlib.import_module(PKG + ".engine")
+    backend_hip = importlib.import_module(PKG + ".backend_hip")
+    train = importlib.import_module(PKG + ".train")
+    plan = engine.Plan(bench.kitti_config(2), with_image=True)
+    n = plan.table.n_params
+    K = backend_hip.HipBackend.__new__(backend_hip.HipBackend)          # bookkeeping only: no device, no library call
+    K.params = torch.zeros(n)
+    K.nconv = len(plan.layers)
+    finalised = []
+    K._finalize = lambda lo, hi: finalised.append((lo, hi))
+    K._flush_wgrads = lambda: None
+    T = train.Train.__new__(train.Train)
+    g = torch.arange(n, dtype=torch.float32).remainder_(97.0) * float(rank + 1)
+    T.model = types.SimpleNamespace(flat_grads=g)
+    T.grad_bucket_dtype, T.allreduce_premul = "f32", None
+    T._pending, T._reduced, T._widen = [], 0, []
+    calls = []
+
+    def hook(ranges):
+        calls.append(list(ranges))
+        T._bucket_ready(ranges)
+    K.bucket_hook = hook
+    for which in ("lidar_hi", "lidar+fusion", "image_hi"):
+        K.bucket_ready(plan.layers, which)
+    K.end_backward(plan.layers)
+    for w in T._pending:
+        w.wait()
+    # four hand-overs whose arena ranges tile [0, n) exactly once
+    assert len(calls) == 4, calls
+    flat = sorted(r for c in calls for r in c)
+    assert flat[0][0] == 0 and flat[-1][1] == n and all(flat[i][1] == flat[i + 1][0] for i in range(len(flat) - 1)), flat
+    assert T._reduced == n
+    # every layer finalised exactly once
+    cover = sorted(finalised)
+    assert cover[0][0] == 0 and cover[-1][1] == len(plan.layers) and all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1))
+    expect = torch.arange(n, dtype=torch.float32).remainder_(97.0) * float(sum(r + 1 for r in range(world)))
+    assert torch.equal(g, expect)
+    sizes = [sum(b - a for a, b in c) * 4 / 1e6 for c in calls]
+    if rank == 0:
+        out.put(sizes)
+    dist.destroy_process_group()
+
+
+def test_four_gradient_buckets_world_size_8_gloo():
+    """cfg3's exchange on 8 ranks (reference train.py:24: DDP's bucketed gradient all-reduce): the four buckets the backward hands
+    over cover the cfg2 gradient arena exactly once and every rank ends with the sum over ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    sizes = q.get(timeout=5)
+    assert len(sizes) == 4 and all(s > 5.0 for s in sizes) and 90.0 < sum(sizes) < 100.0, sizes      # MB: 96 MB in all, none of them tiny
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """`python bench.py --gpus 2` under a launcher that exported WORLD_SIZE=4 must not print an n_gpus line at all."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr and not p.stdout.strip()
+
+
+def test_bench_rank_environments():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    envs = bench.rank_envs(8, 29511, base={"PATH": "/bin", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert [e["RANK"] for e in envs] == [str(r) for r in range(8)] and [e["LOCAL_RANK"] for e in envs] == [str(r) for r in range(8)]
+    assert all(e["WORLD_SIZE"] == "8" and e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == "29511" and
+               e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in envs)

@@ -31,16 +31,17 @@ def _wait(request, prefix):
 
 
 def test_bench_two_ranks_on_one_gpu(request):
-    """bench.py --gpus 2 (the driver's N > 1 launch contract: RANK / WORLD_SIZE from the environment, barrier-fenced timing,
-    MAX over ranks, one JSON line from rank 0) with both ranks on GPU 0 and gloo in place of RCCL: cfg2 steps including the
-    bucketed gradient all-reduce.  A functional check of the code path the 8-GPU scaling run takes."""
+    """`python bench.py --gpus 2 --steps 3 --warmup 1` typed WITHOUT a launcher and with a clean environment (the driver's scaling
+    command): bench.py starts its two rank processes itself, both here on GPU 0 with gloo in place of RCCL -- cfg2 steps including
+    the bucketed gradient all-reduce, barrier-fenced timing, MAX over ranks, ONE JSON line (rank 0's) whose n_gpus is the flag's.
+    A functional check of the code path the 8-GPU scaling run takes (reference train.py:24,51-56)."""
     import json
-    outdir = _wait(request, "bench_r")
-    line = open(os.path.join(outdir, "bench_r0.out")).read().strip().splitlines()[-1]
-    d = json.loads(line)
+    outdir = _wait(request, "bench_launch")
+    lines = [ln for ln in open(os.path.join(outdir, "bench_launch.out")).read().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines                                      # only rank 0 prints the line
+    d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["parallelism"] == "dp2" and d["roofline"] is not None
-    assert not [ln for ln in open(os.path.join(outdir, "bench_r1.out")).read().splitlines() if ln.startswith("{")]       # only rank 0 prints the line
 
 
 def test_two_ranks_equal_one_rank_with_twice_the_batch(request):
