@@ -90,10 +90,12 @@ def decode(reg, anc):
 
 
 # ------------------------------------------------------------------ image stream
-def image_stream(sd, img_u8, bn_mode="eval", pfx="image_backbone", fpn="image_fpn"):
+def image_stream(sd, img_u8, bn_mode="eval", pfx="image_backbone", fpn="image_fpn", return_feats=False):
     """App. D image stream: ResNet-18 trunk (torchvision key names) + FPN to stride 4.
 
     img_u8 [B,3,H,W] uint8 -> F [B,C_f,H/4,W/4] (sizes follow the conv arithmetic).
+    return_feats: the trunk's four stage outputs (c2..c5) instead -- tests/test_oracle_independent.py compares them with
+    a literal torch.nn build of the published topology.
     """
     x = img_u8.to(torch.float32) / 255.0
     x = F.relu(_bn(sd, pfx + ".bn1", F.conv2d(x, sd[pfx + ".conv1.weight"], None, 2, 3), bn_mode))
@@ -118,6 +120,8 @@ def image_stream(sd, img_u8, bn_mode="eval", pfx="image_backbone", fpn="image_fp
             x = F.relu(y + r)
             bi += 1
         feats.append(x)
+    if return_feats:
+        return feats
     c2, c3, c4, c5 = feats
     p5 = F.conv2d(c5, sd[fpn + ".lat4.weight"])
     p4 = F.conv2d(c4, sd[fpn + ".lat3.weight"]) + F.interpolate(p5, size=c4.shape[-2:], mode="bilinear", align_corners=False)
