@@ -252,10 +252,11 @@ def rocprof_kernel(name):
         l16 = "8" if (int(t[0][2:]) == 2 and chain == "false") else "0"           # loader waves: the small-M kind runs as 8 consumers + 8 loaders (option RS_L16, default)
         kind = int(t[0][2:])
         npt = int(t[1]) if len(t) > 1 and t[1].isdigit() else 99
+        pf = "true" if "pf" in t[1:] else "false"             # round 6: 'conv_fwd_bf16<rs1,7,pf>' = the rotated, fragment-prefetching tap loop (11th template argument)
         if kind == 1 and npt <= 8 and chain == "false":      # <= 256 positions per workgroup: the instantiation with the pixel tile two stages ahead
-            return "k_conv3x3_rs", [dt, "1", "2", "2", "4", "2", "2", "false", chain, l16]
+            return "k_conv3x3_rs", [dt, "1", "2", "2", "4", "2", "2", "false", chain, l16, pf]
         return "k_conv3x3_rs", [dt] + {0: ["1", "5", "4", "2", "2", "1", "false"], 1: ["1", "3", "2", "4", "2", "1", "false"],
-                                       2: ["1", "1", "2", "4", "6", "2", "true"]}[kind] + [chain, l16]
+                                       2: ["1", "1", "2", "4", "6", "2", "true"]}[kind] + [chain, l16, pf]
     if kind.startswith("conv_fwd") or kind.startswith("conv_dgrad") or kind.startswith("stem_fwd"):
         tr = "true" if "dgrad" in kind else "false"
         if t and t[-1].startswith("dma"):

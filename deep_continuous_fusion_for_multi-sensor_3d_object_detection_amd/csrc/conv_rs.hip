@@ -27,7 +27,9 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
     if (!(pe && atoi(pe) == 0)) nwg = std::min<int64_t>(nwg, 256 * RS_KINDS[p.kind].per_cu);
     const dim3 grid((unsigned)nwg);
     char name[96];
-    snprintf(name, sizeof(name), "%s<rs%d,%d>", name_base, p.kind, p.npt);
+    static DcfOpt pfn_o("RS_PF"); const char *pfn = pfn_o.str();
+    const bool pf_name = p.kind != 2 && ((pfn && atoi(pfn) == 2) || (!(pfn && atoi(pfn) == 0) && Ck >= 128));       // (= `pf` below: the profile name says which loop ran)
+    snprintf(name, sizeof(name), pf_name ? "%s<rs%d,%d,pf>" : "%s<rs%d,%d>", name_base, p.kind, p.npt);
     const double bytes = (double)a.xbytes + (double)a.wbytes + (double)B * H * W * Cn * 2.0 * (1 + (res ? 1 : 0) + (mask ? 1 : 0));
     static DcfOpt s3e_o("RS_S3"); const char *s3e = s3e_o.str();
     const bool s3 = !(s3e && atoi(s3e) == 0);
@@ -42,17 +44,48 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
     // and the loop waited for them at every stage.  Option RS_DX2=0: the DX = 1 instantiation for every launch of the kind.
     static DcfOpt dx2_o("RS_DX2"); const char *dx2e = dx2_o.str();
     const bool dx2 = p.kind == 1 && p.npt <= 8 && !(dx2e && atoi(dx2e) == 0);
+    // RS_PF (round 6, default on): the rotated, fragment-prefetching tap loop for the two per-tap-synchronised kinds (conv_rs_kernel.h)
+    static DcfOpt pf_o("RS_PF"); const char *pfe = pf_o.str();
+    // (Ck = 64: three stages of HBM-bound taps -- the earlier synchronisation point of the rotated loop leaves the DMA a quarter tap less
+    // to land: 64 -> 64 @352x400 33.3 -> 37.7 us; those layers keep the plain loop.  RS_PF=2 forces the rotated loop everywhere.)
+    const bool pf = (pfe && atoi(pfe) == 2) || (!(pfe && atoi(pfe) == 0) && Ck >= 128);
+    // RS_NL4 (round 6): kind 1 as eight consumer + four loader waves on the rotated loop (the DMA pieces leave the waves that issue the MFMAs)
+    static DcfOpt nl4_o("RS_NL4"); const char *nl4e = nl4_o.str();
+    const bool nl4 = pf && dx2 && (nl4e && atoi(nl4e) != 0);        // (the TMMAX = 3 instantiation spills at the 168 registers twelve waves leave)
 #define DCF_RS(T_)                                                                                                               \
     do {                                                                                                                         \
-        if (p.kind == 0) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1>), grid, dim3(512), 0, s, a)); \
+        if (dx2 && nl4) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 2, 2, 4, 2, 2, false, false, 4, true>), grid, dim3(768), 0, s, a)); \
+        else if (p.kind == 0 && pf) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1, false, false, 0, true>), grid, dim3(512), 0, s, a)); \
+        else if (dx2 && pf) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 2, 2, 4, 2, 2, false, false, 0, true>), grid, dim3(512), 0, s, a)); \
+        else if (p.kind == 1 && pf) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 3, 2, 4, 2, 1, false, false, 0, true>), grid, dim3(512), 0, s, a)); \
+        else if (p.kind == 0) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1>), grid, dim3(512), 0, s, a)); \
         else if (dx2) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 2, 2, 4, 2, 2>), grid, dim3(512), 0, s, a)); \
         else if (p.kind == 1) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 3, 2, 4, 2, 1>), grid, dim3(512), 0, s, a)); \
         else if (!s3) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 5, 2>), grid, dim3(512), 0, s, a)); \
         else if (l16) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 6, 2, true, false, 8>), grid, dim3(1024), 0, s, a)); \
         else DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 6, 2, true>), grid, dim3(512), 0, s, a)); \
     } while (0)
+#ifdef RS_BF16_ONLY            /* tools/rw_variants.sh: half the compile time */
+    if (dtype == DCF_F16) return DCF_EUNSUPPORTED;
+    DCF_RS(bf16_t);
+#else
     if (dtype == DCF_F16) DCF_RS(f16_t); else DCF_RS(bf16_t);
+#endif
 #undef DCF_RS
     return DCF_OK;
 }
 
+
+#ifdef RS_WSTAMP
+// variant builds only (tools/rs_wstamps.py): the per-wave barrier stamps of the last single-layer launch
+extern "C" int dcf_rs_wstamps_read(void *dst, int *dims)
+{
+    dims[0] = RS_WS_WGS; dims[1] = 8; dims[2] = 3; dims[3] = 64;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rs_wstamps), sizeof(g_rs_wstamps)) == hipSuccess ? 0 : -1;
+}
+extern "C" int dcf_rs_wstamps_clear()
+{
+    static unsigned zero[RS_WS_WGS * 8 * 3 * 64];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_rs_wstamps), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif

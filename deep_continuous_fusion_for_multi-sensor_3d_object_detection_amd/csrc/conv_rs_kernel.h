@@ -88,6 +88,20 @@ __device__ long long g_rs_stamps[RS_STAMP_WGS][RS_STAMP_ITEMS][10];
 #else
 #define RS_T(k) do { } while (0)
 #endif
+// -DRS_WSTAMP (variant builds only: KFILE=conv_rs bash tools/rw_variants.sh wstamp="-DRS_WSTAMP"; tools/rs_wstamps.py): EVERY wave of a
+// single-layer launch keeps the low 32 bits of s_memtime for its arrival at and its release from every tap barrier of its first
+// tile, plus six phase marks, in three VGPRs (one lane per stamp: v_writelane -- no memory instruction, so the counted vmcnt waits
+// are untouched) and writes them out when the workgroup is done:
+//   misc 0 kernel entry   1 first DMA groups + stand-in stores issued   2 last MFMA issued   3 DMA tail drained   4 epilogue stores
+//   issued   5 stores drained
+#ifdef RS_WSTAMP
+#define RS_WS_WGS 256
+__device__ unsigned g_rs_wstamps[RS_WS_WGS][8][3][64];
+#define RS_WS(reg, idx) do { if constexpr (!CHAIN) { const unsigned t__ = (unsigned)__builtin_amdgcn_s_memtime(); const int i__ = __builtin_amdgcn_readfirstlane(idx); \
+    unsigned k__; asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(reg), "=&s"(k__) : "s"(t__), "s"(i__)); } } while (0)
+#else
+#define RS_WS(reg, idx) do { } while (0)
+#endif
 #define RS_CHAIN_MAX 24
 struct RsChainLayer {
     const char *x, *w;
@@ -160,6 +174,8 @@ template <> __device__ __forceinline__ uint4 pack8<f16_t>(const float (&v)[8])
     return __builtin_bit_cast(uint4, h);
 }
 
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // s_waitcnt vmcnt(n) for a wave-uniform runtime n (the immediate must be a constant: one scalar branch)
 __device__ __forceinline__ void wait_vmcnt_dyn(int n)
 {
@@ -210,10 +226,20 @@ constexpr int rs_allowed(int kj, int dw, int dx, int pww, int pxa, int pxb)
 // NL = number of loader waves (0: the 8-wave form; 8: sixteen waves; 4: twelve waves -- a loader then issues the pieces of TWO of
 // the 8-wave form's waves, i.e. the pieces are dealt over NL waves instead of over NW; 170 registers per wave instead of 128, for
 // the kinds whose consumers hold 48-80 accumulator registers).
-template <typename T, int TN, int TMMAX, int WN, int WM, int DW, int DX, bool S3 = false, bool CHAIN = false, int NL = 0>
+// PF (round 6): the tap loop ROTATED and the fragment reads double-buffered.  The plain loop reads a k-step's fragments, waits for
+// them (lgkmcnt 0) and only then issues its MFMAs, and starts every tap behind a barrier with nothing in flight: with two waves per
+// SIMD the matrix pipe sat idle for an LDS latency per k-step and for barrier + latency per tap (~50 % busy inside the loop, SQ
+// counters of rounds 4-5; the disassembly showed `ds_read ; s_waitcnt lgkmcnt(0) ; v_mfma` pairs).  Here (a) k-step ks + 1's fragments
+// are requested BEFORE the MFMAs of k-step ks are issued (two register sets, order pinned with sched_barrier), and (b) the wait +
+// barrier of tap t + 1 sits in front of the LAST k-step of tap t, whose MFMAs then cover the first fragment reads of tap t + 1; group
+// t + 1's DMA pieces follow that barrier (one per k-step as before).  Every LDS read a wave issued from tap t's slots has returned
+// when it arrives there (explicit lgkmcnt(0): the last k-step's fragments are needed at once anyway), so the slot hand-over to the
+// DMA is a dependency, not a race the L2 latency wins.  Same groups, same order, same counted vmcnt immediates; bit-identical sums.
+template <typename T, int TN, int TMMAX, int WN, int WM, int DW, int DX, bool S3 = false, bool CHAIN = false, int NL = 0, bool PF = false>
 __global__ void __launch_bounds__((WN * WM + NL) * 64) k_conv3x3_rs(typename std::conditional<CHAIN, RsChainArgs, RsArgs>::type arg)
 {
     constexpr bool L16 = NL > 0;
+    static_assert(!PF || (!S3 && !CHAIN), "the rotated loop: per-tap synchronisation, single layer");
     static_assert(!(L16 && CHAIN) && (NL == 0 || NL == 4 || NL == 8), "loader waves: none, four or eight; no chain mode with them");
     const RsArgs &a = rs_common(arg);
     static_assert(DT<T>::size == 2, "16-bit element types only");
@@ -382,6 +408,11 @@ __global__ void __launch_bounds__((WN * WM + NL) * 64) k_conv3x3_rs(typename std
     // chain mode: wait until the tiles of the previous layer that tile (layer, q0) reads are complete.  Wave 0 polls, one counter
     // per lane; the others wait at the barrier it joins afterwards.
     bool gave_up = false;
+#ifdef RS_WSTAMP
+    unsigned ws_arr = 0, ws_rel = 0, ws_misc = 0;
+    int ws_tile = 0;
+    RS_WS(ws_misc, 0);
+#endif
 #ifdef RS_STAMP
     long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int item = 0;
@@ -623,29 +654,169 @@ __global__ void __launch_bounds__((WN * WM + NL) * 64) k_conv3x3_rs(typename std
         auto begin_tile = [&]() __attribute__((always_inline)) { begin_tile_parts(std::true_type(), std::true_type()); };
         RS_T(0); RS_T(1);
         begin_tile();
-#pragma unroll
-        for (int k = 0; k < ST; ++k) gst16_dummy(dstY);      // stand-ins for a previous tile's stores
+        // The previous tile's ST stores sit between a tile's first groups and its loop in the vmcnt queue, and the first steps' waits
+        // allow for them.  The FIRST tile has none: its waits use the plain immediates (exact without stores).  (Rounds 2-5 issued
+        // ST out-of-range stand-in stores here instead: 4-10 store instructions per wave in front of the first tap of every launch --
+        // -DRS_WSTAMP: 3.3 k cycles from kernel entry to "first groups issued" on the 192-channel stage, 9.5 k on the 128-channel one.)
+        bool stores_pending = false;
         RS_T(2);
+#ifdef RS_WSTAMP
+        RS_WS(ws_misc, 1);
+#endif
         for (;;) {
         if constexpr (CHAIN) make_descs();
         int wsr = 0, wsi = DW % NSW, xsr = 0, xsi = DX % NSX;         // ring slots: read / issue
+        if constexpr (PF) {
+            constexpr int CC = C > 0 ? C : 1;
+            uint4 fa0[TN], fb0[CC], fa1[TN], fb1[CC];
+            auto load_frags = [&](uint4 (&fa)[TN], uint4 (&fb)[CC], int kj, int ks) __attribute__((always_inline)) {
+#if defined(RS_ABL) && (RS_ABL & 2)
+                if (kj + ks != 0) return;                  // timing ablation (variant builds): fragments read once per stage only
+#endif
+                const char *pw = lds + wsr * WSLOT + rdA;
+                const char *px = lds + NSW * WSLOT + xsr * XSLOT + rdX + kj * 128;
+                const int swx0 = (h ^ (((r + kj) >> 1) & 7)) << 4;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) fa[i] = *reinterpret_cast<const uint4 *>(pw + i * 32 * 128 + (swa0 ^ (ks << 5)));
+#pragma unroll
+                for (int j = 0; j < C; ++j) fb[j] = *reinterpret_cast<const uint4 *>(px + j * 32 * 128 + (swx0 ^ (ks << 5)));
+            };
+            auto mfmas = [&](const uint4 (&fa)[TN], const uint4 (&fb)[CC]) __attribute__((always_inline)) {
+#if defined(RS_ABL) && (RS_ABL & 4)
+                return;
+#endif
+#pragma unroll
+                for (int j = 0; j < C; ++j)
+#pragma unroll
+                    for (int i = 0; i < TN; ++i) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+            };
+            auto wait_tap = [&](int kj, int t) __attribute__((always_inline)) {          // the synchronisation in front of tap t
+                const bool early = stores_pending && t < (kj == 0 ? BK0 : DW);
+                if (kj == 0) { if (early) wait_vmcnt<A0 + ST>(); else wait_vmcnt<A0>(); }
+                else if (kj == 1) { if (early) wait_vmcnt<A1 + ST>(); else wait_vmcnt<A1>(); }
+                else { if (early) wait_vmcnt<A2 + ST>(); else wait_vmcnt<A2>(); }
+                wait_lgkm0();
+#ifdef RS_WSTAMP
+                if (ws_tile == 0 && t < 64) RS_WS(ws_arr, t);
+#endif
+#if !(defined(RS_ABL) && (RS_ABL & 8))
+                __builtin_amdgcn_s_barrier();
+#endif
+#ifdef RS_WSTAMP
+                if (ws_tile == 0 && t < 64) RS_WS(ws_rel, t);
+#endif
+            };
+            auto issue_quarter = [&](int kj, int part) __attribute__((always_inline)) {   // quarter `part` of group t (tap kj of the current stage)
+                if constexpr (NI) return;
+#if defined(RS_ABL) && (RS_ABL & 1)
+                return;                                    // timing ablation (variant builds): no DMA piece inside the loop
+#endif
+                const int xj0 = kj == 0 ? 0 : PXA, xj1 = kj == 0 ? PXA : (kj == 1 ? CX : PXA);
+                const int dw = (kj + DW) / 3, kw = (kj + DW) % 3;
+                const unsigned dstw = __builtin_amdgcn_readfirstlane(ldsW0 + wsi * WSLOT + wid * PWW * 1024);
+                const bool okw = kis[dw] < 3 && !(DCF_DBG(a) & 16);
+                const unsigned koff = (unsigned)(wst[dw] + kw * tapstep);
+#pragma unroll
+                for (int j = 0; j < PWW; ++j)
+                    if ((j & 3) == part) glds16(srcW, okw ? wbase[j] + koff : OOB, dstw + j * 1024);
+                const int kix = kis[DX];
+#pragma unroll
+                for (int j = 0; j < PXW; ++j)
+                    if (j >= xj0 && j < xj1 && ((PWW + j - xj0) & 3) == part) {
+                        const unsigned dst = __builtin_amdgcn_readfirstlane(ldsX0 + xsi * XSLOT + (wid + j * NWD) * 1024);
+                        gldsX(srcX, (((xok[j] >> kix) & 1) && !(DCF_DBG(a) & 2)) ? (unsigned)(xbase[j] + xst[DX]) : OOB, dst);
+                    }
+            };
+            auto issue_group = [&](int kj) __attribute__((always_inline)) {               // a wave without tiles: the whole group at once
+                issue_w((kj + DW) / 3, (kj + DW) % 3, wsi);
+                if (kj == 0) issue_x(DX, xsi, 0, PXA);
+                if (kj == 1) issue_x(DX, xsi, PXA, CX);
+            };
+            wait_tap(0, 0);
+            if constexpr (C > 0) { load_frags(fa0, fb0, 0, 0); issue_quarter(0, 0); } else issue_group(0);
+            for (int s = 0; s < nstage; ++s) {
+#pragma unroll
+                for (int kj = 0; kj < 3; ++kj) {
+                    const int kjn = kj == 2 ? 0 : kj + 1;
+                    if constexpr (C > 0) {
+                        load_frags(fa1, fb1, kj, 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfmas(fa0, fb0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_quarter(kj, 1);
+                        load_frags(fa0, fb0, kj, 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfmas(fa1, fb1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_quarter(kj, 2);
+                        load_frags(fa1, fb1, kj, 3);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfmas(fa0, fb0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_quarter(kj, 3);
+                    }
+                    // the state of tap t + 1 ...
+                    wsr = wsr + 1 == NSW ? 0 : wsr + 1;
+                    wsi = wsi + 1 == NSW ? 0 : wsi + 1;
+                    if (kj == 2) {
+                        xsr = xsr + 1 == NSX ? 0 : xsr + 1;
+                        xsi = xsi + 1 == NSX ? 0 : xsi + 1;
+#pragma unroll
+                        for (int d = 0; d < DS; ++d) { wst[d] = wst[d + 1]; xst[d] = xst[d + 1]; kis[d] = kis[d + 1]; }
+                        stage_entry(DS);
+                    }
+                    // ... its synchronisation and its first fragments, under this tap's last k-step
+                    const bool has_next = !(kj == 2 && s == nstage - 1);
+                    if (has_next) {
+                        wait_tap(kjn, 3 * s + kj + 1);
+                        if constexpr (C > 0) load_frags(fa0, fb0, kjn, 0);
+                    }
+                    if constexpr (C > 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfmas(fa1, fb1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (has_next) {
+                        if constexpr (C > 0) issue_quarter(kjn, 0); else issue_group(kjn);
+                    }
+                }
+            }
+        } else
         for (int s = 0; s < nstage; ++s) {
 #pragma unroll
             for (int kj = 0; kj < 3; ++kj) {
                 if constexpr (S3) {
                     if (kj == 0) {
-                        if (s < DX) wait_vmcnt<AS + ST>(); else wait_vmcnt<AS>();
+                        if (s < DX && stores_pending) wait_vmcnt<AS + ST>(); else wait_vmcnt<AS>();
+                        wait_lgkm0();             // (see below)
+#ifdef RS_WSTAMP
+                        if (ws_tile == 0 && s < 64) RS_WS(ws_arr, s);
+#endif
                         __builtin_amdgcn_s_barrier();
+#ifdef RS_WSTAMP
+                        if (ws_tile == 0 && s < 64) RS_WS(ws_rel, s);
+#endif
 #ifdef RS_STAMP
                         if (s == 0) RS_T(3);
 #endif
                     }
                 } else {
-                    const bool early = 3 * s + kj < (kj == 0 ? BK0 : DW);       // the group this step needs went out before the stores
+                    const bool early = stores_pending && 3 * s + kj < (kj == 0 ? BK0 : DW);       // the group this step needs went out before the stores
                     if (kj == 0) { if (early) wait_vmcnt<A0 + ST>(); else wait_vmcnt<A0>(); }
                     else if (kj == 1) { if (early) wait_vmcnt<A1 + ST>(); else wait_vmcnt<A1>(); }
                     else { if (early) wait_vmcnt<A2 + ST>(); else wait_vmcnt<A2>(); }
+                    // Behind this barrier other waves aim DMA pieces at the slots the previous tap was read from: every fragment
+                    // read of this wave must have RETURNED by now.  The compiler may sink the previous tap's last MFMA -- and the
+                    // lgkmcnt wait in front of it -- below a raw s_barrier (tools/audit_barrier_lds.py found 885 such barriers in
+                    // the round-5 object: a race the L2 latency won); the explicit wait makes it a dependency.
+                    wait_lgkm0();
+#ifdef RS_WSTAMP
+                    if (ws_tile == 0 && 3 * s + kj < 64) RS_WS(ws_arr, 3 * s + kj);
+#endif
                     __builtin_amdgcn_s_barrier();
+#ifdef RS_WSTAMP
+                    if (ws_tile == 0 && 3 * s + kj < 64) RS_WS(ws_rel, 3 * s + kj);
+#endif
 #ifdef RS_STAMP
                     if (s == 0 && kj == 0) RS_T(3);
 #endif
@@ -734,8 +905,14 @@ __global__ void __launch_bounds__((WN * WM + NL) * 64) k_conv3x3_rs(typename std
             stage_entry(DS);
         }
         RS_T(4);
+#ifdef RS_WSTAMP
+        if (ws_tile == 0) RS_WS(ws_misc, 2);
+#endif
         wait_vmcnt<0>();              // the trailing dummy pieces still target this workgroup's LDS
         RS_T(5);
+#ifdef RS_WSTAMP
+        if (ws_tile == 0) RS_WS(ws_misc, 3);
+#endif
         const int q0c = q0, n0c = n0;
         if constexpr (CHAIN) {
             // Publish this tile, then move on to the next work item -- (layer, next tile of this workgroup) or (layer + 1, its
@@ -795,6 +972,16 @@ __global__ void __launch_bounds__((WN * WM + NL) * 64) k_conv3x3_rs(typename std
             begin_tile();                                              // in flight under the epilogue below
         }
         store_tile(q0c, n0c);
+        stores_pending = true;
+#ifdef RS_WSTAMP
+        if constexpr (!CHAIN) {
+            if (ws_tile == 0) {
+                RS_WS(ws_misc, 4);
+                if (!more) { wait_vmcnt<0>(); RS_WS(ws_misc, 5); }
+            }
+            ++ws_tile;
+        }
+#endif
         if (!more) break;
 #pragma unroll
         for (int i = 0; i < TN; ++i)
@@ -847,6 +1034,15 @@ __global__ void __launch_bounds__((WN * WM + NL) * 64) k_conv3x3_rs(typename std
     }
 #undef DCF_RS_CX
     }
+#ifdef RS_WSTAMP
+    if constexpr (!CHAIN) {
+        if (blockIdx.x < RS_WS_WGS && wid16 < 8) {
+            g_rs_wstamps[blockIdx.x][wid16][0][lane] = ws_arr;
+            g_rs_wstamps[blockIdx.x][wid16][1][lane] = ws_rel;
+            g_rs_wstamps[blockIdx.x][wid16][2][lane] = ws_misc;
+        }
+    }
+#endif
     chain_finish();
 }
 

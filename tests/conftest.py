@@ -57,6 +57,12 @@ def _start_dp_children(config):
     log = open(os.path.join(outdir, "bench_launch.log"), "w")
     procs.append(("bench_launch", subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                                                     "--no-cpu-baseline"], stdout=out, stderr=log, cwd=ROOT, env=env)))
+    # ... and the repeatability stress runs of tests/test_gpu_stress.py (they start their own sibling process before touching the GPU)
+    if not os.environ.get("DCF_NO_STRESS_CHILDREN"):
+        for mode in ("stream", "sibling"):
+            log = open(os.path.join(outdir, "stress_%s.log" % mode), "w")
+            procs.append(("stress_" + mode, subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "stress_child.py"), mode, outdir,
+                                                              os.environ.get("DCF_STRESS_RUNS", "50")], stdout=log, stderr=subprocess.STDOUT, cwd=ROOT)))
     config._dcf_dp_children = (outdir, procs)
 
 
@@ -92,7 +98,7 @@ def pytest_collection_modifyitems(config, items):
     # selection keeps them) -- and before anything below initialises the GPU in this process.  Under pytest-xdist every
     # worker would start its own set on the one GPU: the tests skip there instead.
     expr = getattr(config.option, "markexpr", "") or ""
-    wanted = [it for it in items if it.fspath.basename == "test_gpu_dp.py"]
+    wanted = [it for it in items if it.fspath.basename in ("test_gpu_dp.py", "test_gpu_stress.py")]
     if (wanted and "not gpu" not in expr and not os.environ.get("DCF_NO_DP_CHILDREN") and not os.environ.get("PYTEST_XDIST_WORKER")
             and torch.cuda.device_count() >= 1 and not hasattr(config, "_dcf_dp_children")):
         _start_dp_children(config)

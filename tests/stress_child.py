@@ -1,0 +1,105 @@
+"""Child process of tests/test_gpu_stress.py (not a test module): bitwise repeatability of the cfg2 forward + backward.
+
+    python tests/stress_child.py <mode> <outdir> [runs]
+
+mode "stream":  the step runs <runs> times while a second HIP stream of THIS process moves 512 MB back and forth (a bandwidth hog
+                that shares the CUs, the L2s and the fabric with the step's kernels);
+mode "sibling": the step runs <runs> times while ANOTHER PROCESS -- bench.py --steps 400 (eager per-layer launches, no chains),
+                started here before this process touches the GPU -- trains on the same GPU.
+
+For fp32 and bf16, batch 2 (the bench's step shape: every launch as in the benchmark): geometry + KNN from the raw clouds, forward,
+backward.  Run 0 is the reference; every later run must reproduce, BIT FOR BIT, the prediction and the LiDAR stream's part of
+the gradient arena (fixed-order slab reduction; nothing in it depends on the fusion backward), and the camera / fusion part --
+which the fusion backward's float atomics touch -- to 2e-5 of its largest element (the documented bound).  A timing-dependent
+slot hand-over in any of the LDS-DMA ring kernels shows up here as a changed bit.  Writes <outdir>/stress_<mode>.json.
+Reference: /root/reference/model.py:194-204 (one forward is a pure function of its inputs)."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    mode, outdir = sys.argv[1], sys.argv[2]
+    runs = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+    sib = None
+    if mode == "sibling":
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        sib = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "400", "--warmup", "2", "--no-cpu-baseline", "--no-roofline",
+                                "--no-other-leg", "--input", "resident"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, cwd=ROOT)
+    import torch
+    from _util import pkg
+    from test_gpu_benchsize import _cfg2_config
+    det, calib, D, T = pkg("detfill"), pkg("calib"), pkg("data_import_carla"), pkg("train")
+    lim6 = (0.0, 70.4, -40.0, 40.0, -2.4, 0.8)
+    crt = calib.kitti_like_crt()
+    pts = [torch.from_numpy(det.synthetic_points(100000, lim6, 41 + b)).cuda() for b in range(2)]
+    img = torch.stack([torch.from_numpy(det.synthetic_image(375, 1242, 41 + b)) for b in range(2)], 0).cuda()
+    hog_stream = torch.cuda.Stream()
+    hog_a = torch.empty(128 << 20, dtype=torch.float32, device="cuda")       # 512 MB: far beyond the L2s and the Infinity Cache
+    hog_b = torch.empty_like(hog_a)
+    result = {"mode": mode, "runs": runs, "dtypes": {}}
+    for dt in ("f32", "bf16"):
+        cfg = _cfg2_config(dt, batch=2)
+        cfg["hip_graphs"] = False
+        tr = T.Train(cfg)
+        det.fill_state_dict(tr.model)
+        geo = D.FrameGeometry(cfg, crt)
+        R = None
+        ref = None
+        lidar_end = None
+        worst_soft, bad = 0.0, []
+        sib_alive = 0
+        for run in range(runs + 1):
+            if mode == "stream" and run > 0:
+                with torch.cuda.stream(hog_stream):
+                    for _ in range(6):
+                        hog_b.copy_(hog_a, non_blocking=True)
+                        hog_a.copy_(hog_b, non_blocking=True)
+            x_lidar, geom = tr.geometry_async(geo, pts)
+            pred = tr.model(x_lidar, img, geom=geom)
+            if R is None:
+                R = torch.from_numpy(det.uniform(tuple(pred.shape), 99, -1.0, 1.0)).cuda()
+                R[:, 18:] = 0
+            tr.optimizer.zero_grad()
+            (pred * R).sum().backward()
+            torch.cuda.synchronize()
+            if sib is not None and sib.poll() is None:
+                sib_alive += 1
+            g = tr.model.flat_grads
+            if ref is None:
+                layers = tr.model._plan.layers
+                lidar_end = min(L.w_off for L in layers if L.name.startswith("image_"))
+                ref = (pred.detach().clone(), g.clone())
+                continue
+            same_pred = torch.equal(pred.detach(), ref[0])
+            same_lidar = torch.equal(g[:lidar_end], ref[1][:lidar_end])
+            soft = float((g[lidar_end:] - ref[1][lidar_end:]).abs().max() / ref[1][lidar_end:].abs().max())
+            worst_soft = max(worst_soft, soft)
+            if not (same_pred and same_lidar and soft <= 2e-5):
+                bad.append({"run": run, "pred_bitwise": same_pred, "lidar_grads_bitwise": same_lidar, "camera_fusion_rel": soft,
+                            "pred_max_diff": float((pred.detach().float() - ref[0].float()).abs().max()),
+                            "lidar_max_diff": float((g[:lidar_end] - ref[1][:lidar_end]).abs().max())})
+        result["dtypes"][dt] = {"bad": bad, "camera_fusion_worst_rel": worst_soft, "lidar_arena_elements": int(lidar_end),
+                                "arena_elements": int(g.numel()), "runs_with_sibling_alive": sib_alive}
+        del tr
+        torch.cuda.empty_cache()
+    if sib is not None:
+        if sib.poll() is None:
+            sib.terminate()
+        try:
+            sib.wait(timeout=60)
+        except Exception:
+            sib.kill()
+    json.dump(result, open(os.path.join(outdir, "stress_%s.json" % mode), "w"))
+    print(json.dumps(result))
+    return 1 if any(v["bad"] for v in result["dtypes"].values()) else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -64,3 +64,19 @@ def test_sampler_hash_restatement_equals_the_library():
     lib = pkg("_hip").lib()
     for args in ((0, 0, 1, 0, 0), (12345678901234567, 3, 2, 511, 7), (M64, 15, 1, 1023, 0), (42, 1, 2, 128, 1000), (2 ** 63 + 5, 7, 2, 99999, 3)):
         assert lib.dcf_loss_sample_rand(*args) == rand32(*args)
+
+
+def test_no_raw_barrier_is_reached_with_lds_reads_in_flight():
+    """The LDS-DMA ring kernels hand slots back to the DMA behind raw s_barrier instructions: every fragment read a wave issued must
+    have returned when it arrives there (Weak #2).  tools/audit_barrier_lds.py walks the disassembly of the built
+    objects; round 5's conv_rs.o had 885 such barriers (the compiler sank an MFMA and its lgkmcnt wait below the barrier), the
+    explicit waits of round 6 leave none."""
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "deep_continuous_fusion_for_multi-sensor_3d_object_detection_amd", "csrc")
+    objs = [os.path.join(csrc, f) for f in ("conv_rs.o", "conv_chain.o", "conv_wgs.o", "conv_wg1.o", "conv_sp.o", "conv_lc.o", "conv_wgv.o", "conv.o")]
+    pkg("_hip").build()                                   # (no-op when the library is up to date)
+    assert all(os.path.exists(o) for o in objs)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_barrier_lds.py")] + objs, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert p.stdout.count(" 0 with LDS reads possibly in flight") == len(objs), p.stdout
