@@ -49,13 +49,9 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
     // (Ck = 64: three stages of HBM-bound taps -- the earlier synchronisation point of the rotated loop leaves the DMA a quarter tap less
     // to land: 64 -> 64 @352x400 33.3 -> 37.7 us; those layers keep the plain loop.  RS_PF=2 forces the rotated loop everywhere.)
     const bool pf = (pfe && atoi(pfe) == 2) || (!(pfe && atoi(pfe) == 0) && Ck >= 128);
-    // RS_NL4 (round 6): kind 1 as eight consumer + four loader waves on the rotated loop (the DMA pieces leave the waves that issue the MFMAs)
-    static DcfOpt nl4_o("RS_NL4"); const char *nl4e = nl4_o.str();
-    const bool nl4 = pf && dx2 && (nl4e && atoi(nl4e) != 0);        // (the TMMAX = 3 instantiation spills at the 168 registers twelve waves leave)
 #define DCF_RS(T_)                                                                                                               \
     do {                                                                                                                         \
-        if (dx2 && nl4) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 2, 2, 4, 2, 2, false, false, 4, true>), grid, dim3(768), 0, s, a)); \
-        else if (p.kind == 0 && pf) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1, false, false, 0, true>), grid, dim3(512), 0, s, a)); \
+        if (p.kind == 0 && pf) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1, false, false, 0, true>), grid, dim3(512), 0, s, a)); \
         else if (dx2 && pf) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 2, 2, 4, 2, 2, false, false, 0, true>), grid, dim3(512), 0, s, a)); \
         else if (p.kind == 1 && pf) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 3, 2, 4, 2, 1, false, false, 0, true>), grid, dim3(512), 0, s, a)); \
         else if (p.kind == 0) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1>), grid, dim3(512), 0, s, a)); \

@@ -923,6 +923,7 @@ __global__ void __launch_bounds__((WN * WM + NL) * 64) k_conv3x3_rs(typename std
             if (ngidx >= chunk_hi) { nlayer = __builtin_amdgcn_readfirstlane(layer + 1); ngidx = gidx_first; }
             const bool more = nlayer < arg.nlayers;
             if (more) {
+                wait_lgkm0();
                 __builtin_amdgcn_s_barrier();                          // every wave is done with the rings
                 if (nlayer != layer) bind_weights(nlayer);
                 if (ngidx != gidx) setup_tile(ngidx);                  // (one tile per layer: the DMA offsets of the tile stay)
@@ -967,6 +968,7 @@ __global__ void __launch_bounds__((WN * WM + NL) * 64) k_conv3x3_rs(typename std
         gidx += wpx;
         const bool more = gidx < chunk_hi;
         if (more) {
+            wait_lgkm0();
             __builtin_amdgcn_s_barrier();                              // every wave is done with the rings
             setup_tile(gidx);
             begin_tile();                                              // in flight under the epilogue below
