@@ -40,7 +40,7 @@ def test_cfg2_forward_backward_is_bitwise_repeatable_under_load(request, mode):
     res, rc, log = _result(request, mode)
     for dt, r in res["dtypes"].items():
         assert not r["bad"], "%s, %s: %d of %d runs differ from run 0: %s" % (mode, dt, len(r["bad"]), res["runs"], r["bad"][:3])
-        assert r["camera_fusion_worst_rel"] <= 2e-5
+        assert r["camera_fusion_worst_rel"] <= r["camera_fusion_bound"]
         assert 0 < r["lidar_arena_elements"] < r["arena_elements"]
     if mode == "sibling":
         assert max(r["runs_with_sibling_alive"] for r in res["dtypes"].values()) > 0, "the sibling process was never running beside the step"

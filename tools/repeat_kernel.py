@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Stand-alone repeatability of single launches while a sibling process trains on the same GPU: the camera map's point sampling
+(fp32 / bf16) and an fp32 elementwise kernel of torch's, each N times on fixed inputs, outputs compared bit for bit with run 0.
+Usage (GPU box): python tools/repeat_kernel.py [--runs 3000] [--no-sibling]"""
+import argparse, importlib, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--runs", type=int, default=3000)
+    ap.add_argument("--no-sibling", action="store_true")
+    args = ap.parse_args()
+    sib = None
+    if not args.no_sibling:
+        sib = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40000", "--warmup", "2", "--no-cpu-baseline", "--no-roofline",
+                                "--no-other-leg", "--input", "resident"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
+    import time
+    import torch
+    if sib is not None:
+        time.sleep(40)                # the sibling's start-up (imports, model, warm-up) before it keeps the GPU busy
+    ops = importlib.import_module("deep_continuous_fusion_for_multi-sensor_3d_object_detection_amd.ops")
+    torch.manual_seed(0)
+    n = 38912
+    for dt, td in ((0, torch.float32), (1, torch.bfloat16)):
+        fmap = (torch.rand((94, 311, 64), device="cuda") - 0.5).to(td)
+        uv = torch.stack([torch.rand(n, device="cuda") * 1240.0, torch.rand(n, device="cuda") * 374.0], 1).contiguous()
+        cnt = torch.tensor([n - 100], dtype=torch.int32, device="cuda")
+        ref = ops.point_sample_fwd(dt, fmap, uv, cnt, n).clone()
+        a = torch.rand((n, 64), device="cuda")
+        ref2 = (a * 1.25 + 0.5).clone()
+        bad = bad2 = 0
+        for r in range(args.runs):
+            out = ops.point_sample_fwd(dt, fmap, uv, cnt, n)
+            o2 = a * 1.25 + 0.5
+            if not torch.equal(out, ref):
+                bad += 1
+                if bad <= 3:
+                    rows = (out != ref).any(dim=1).nonzero().flatten()
+                    ch = (out[rows[0]] != ref[rows[0]]).nonzero().flatten()
+                    print("   run %d: %d rows differ; row %d channels %s" % (r, rows.numel(), int(rows[0]), ch[:16].cpu().tolist()))
+            if not torch.equal(o2, ref2):
+                bad2 += 1
+        alive = sib is not None and sib.poll() is None
+        print("point_sample_fwd %s: %d of %d runs differ; torch a*1.25+0.5: %d differ; sibling alive at the end: %s" % (td, bad, args.runs, bad2, alive), flush=True)
+    if sib is not None:
+        sib.terminate(); sib.wait(timeout=60)
+
+
+if __name__ == "__main__":
+    main()

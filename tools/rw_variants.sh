@@ -16,7 +16,7 @@ SRC=$CS/$KFILE.hip
 pids=()
 for spec in "$@"; do
     name=${spec%%=*}; flags=${spec#*=}
-    ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function -Wno-pass-failed -DRW_BF16_ONLY -DLC_BF16_ONLY -DRS_BF16_ONLY $flags -I $CS -I tools/variants -c $SRC -o /tmp/rwv/${KFILE}_$name.o 2> /tmp/rwv/$name.err \
+    ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wno-unused-function -Wno-pass-failed -DRW_BF16_ONLY -DLC_BF16_ONLY -DRS_BF16_ONLY $flags -I $CS -I tools/variants -c $SRC -o /tmp/rwv/${KFILE}_$name.o 2> /tmp/rwv/$name.err \
       && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/libdcf_hip_v$name.so $OTHERS /tmp/rwv/${KFILE}_$name.o && echo "built $name" || { echo "FAILED $name"; tail -5 /tmp/rwv/$name.err; } ) &
     pids+=($!)
     if [ ${#pids[@]} -ge 6 ]; then wait ${pids[0]}; pids=("${pids[@]:1}"); fi
