@@ -511,6 +511,7 @@ def main():
                     "(0 = the staging thread reads and collates itself)")
     ap.add_argument("--chain", action="store_true", help="run the residual stages' 3x3 layers as chain launches (dcf_conv3x3_chain: one launch per "
                     "stage; needs the GPU to itself; level on time with the per-layer launches, DESIGN.md section 9)")
+    ap.add_argument("--no-batch-sweep", action="store_true", help="skip the short resident-input legs at the other batch sizes of BASELINE.json's metric (1 / 2 / 4 / 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -551,7 +552,7 @@ def main():
     np.random.seed(1234 + rank)
     trainer = train.Train(cfg)
     pkg("detfill").fill_state_dict(trainer.model)        # deterministic random-init weights (no checkpoints offline)
-    pool = FramePool(cfg, n_frames=max(2 * args.batch, 4), n_points=args.points, seed0=100 * rank)
+    pool = FramePool(cfg, n_frames=max(2 * args.batch, 4 if (ws > 1 or args.no_batch_sweep) else 8), n_points=args.points, seed0=100 * rank)
 
     def barrier():
         torch.cuda.synchronize()
@@ -605,6 +606,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(trainer.loss_value.item())
+    frames_main = args.batch * ws * args.steps
     log("timed region done: %.3f s" % dt)
 
     roof, breakdown, classes, cpu, from_host, resident = None, None, None, None, None, None
@@ -637,6 +639,25 @@ def main():
             fl.close()
             from_host = {"value": round(args.batch * n_o / dt_o, 3), "unit": "frames/s", "ms_per_step": round(dt_o / n_o * 1e3, 3), "steps": n_o,
                          "note": "same step fed from host memory through FrameLoader (PCIe-inclusive)"}
+    sweep = None
+    if ws == 1 and not args.no_batch_sweep:
+        # BASELINE.json's metric names batch 1 / 2 / 4 / 8: the other batch sizes of the same workload on the same trainer, resident
+        # input, 10 timed steps each behind 4 untimed ones (batch 1 replays captured graphs under --graphs auto: they are captured there)
+        sweep = {}
+        for b in (1, 2, 4, 8):
+            if b == args.batch or b > pool.n:
+                continue
+            for s in range(4):
+                train_step(trainer, pool, pool.batch(700 + s, b))
+            barrier()
+            t1 = time.perf_counter()
+            for s in range(10):
+                train_step(trainer, pool, pool.batch(710 + s, b))
+            barrier()
+            dt_b = time.perf_counter() - t1
+            sweep[str(b)] = {"frames_per_s": round(b * 10 / dt_b, 2), "ms_per_step": round(dt_b / 10 * 1e3, 3)}
+        sweep[str(args.batch)] = {"frames_per_s": resident["value"] if resident else (round(frames_main / dt, 2) if not args.from_host else None),
+                                  "ms_per_step": resident["ms_per_step"] if resident else (round(dt / args.steps * 1e3, 3) if not args.from_host else None)}
     if not args.no_roofline:
         # every rank runs the instrumented steps (they contain the gradient all-reduce); rank 0 reports its own
         roof, breakdown, classes = roofline_leg(trainer, pool, args.batch, 2)
@@ -670,6 +691,9 @@ def main():
                           "from_host_ms_per_step": from_host["ms_per_step"] if from_host else (round(dt / args.steps * 1e3, 3) if args.from_host else None),
                           "resident_frames_per_s": resident["value"] if resident else (None if args.from_host else round(frames / dt, 3)),
                           "resident_ms_per_step": resident["ms_per_step"] if resident else (None if args.from_host else round(dt / args.steps * 1e3, 3)),
+                          # resident-input frames/s of the same step at the batch sizes BASELINE.json's metric names (this GPU, this run)
+                          "batch_sweep_frames_per_s": {k: v["frames_per_s"] for k, v in sorted(sweep.items(), key=lambda kv: int(kv[0]))} if sweep else None,
+                          "batch_sweep_ms_per_step": {k: v["ms_per_step"] for k, v in sorted(sweep.items(), key=lambda kv: int(kv[0]))} if sweep else None,
                           "loss_sampling": args.loss_sampling, "conv_chain": bool(args.chain or os.environ.get("DCF_CHAIN") in ("1", "force"))},
                "roofline": roof, "cpu_baseline": cpu, "from_host": from_host, "resident": resident, "kernel_classes": classes, "kernel_breakdown": breakdown}
         print(json.dumps(out))

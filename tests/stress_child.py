@@ -31,7 +31,7 @@ def main():
     if mode == "sibling":
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
         sib = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "400", "--warmup", "2", "--no-cpu-baseline", "--no-roofline",
-                                "--no-other-leg", "--input", "resident"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, cwd=ROOT)
+                                "--no-other-leg", "--no-batch-sweep", "--input", "resident"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, cwd=ROOT)
     import torch
     from _util import pkg
     from test_gpu_benchsize import _cfg2_config

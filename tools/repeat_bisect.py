@@ -18,7 +18,7 @@ def main():
     sib = None
     if args.sibling:
         sib = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "600", "--warmup", "2", "--no-cpu-baseline", "--no-roofline",
-                                "--no-other-leg", "--input", "resident"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
+                                "--no-other-leg", "--no-batch-sweep", "--input", "resident"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
     import torch
     from _util import pkg
     from test_gpu_benchsize import _cfg2_config

@@ -24,7 +24,7 @@ def main():
     if args.sibling:
         import subprocess
         sib = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1500", "--warmup", "2", "--no-cpu-baseline", "--no-roofline",
-                                "--no-other-leg", "--input", "resident"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
+                                "--no-other-leg", "--no-batch-sweep", "--input", "resident"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
     dt = {"f32": 0, "bf16": 1, "f16": 2}[args.dtype]
     td = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[dt]
     B = args.batch

@@ -15,7 +15,7 @@ def main():
     sib = None
     if not args.no_sibling:
         sib = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40000", "--warmup", "2", "--no-cpu-baseline", "--no-roofline",
-                                "--no-other-leg", "--input", "resident"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
+                                "--no-other-leg", "--no-batch-sweep", "--input", "resident"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
     import time
     import torch
     if sib is not None:
