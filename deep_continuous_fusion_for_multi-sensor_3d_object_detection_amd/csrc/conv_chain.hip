@@ -16,7 +16,14 @@ bool rs_chain_plan(int dtype, int B, int H, int W, int C, RsPlan *plan, int *nwg
     if (p.kind < 0) return false;
     const int BN = RS_KINDS[p.kind].BN, BM = 32 * p.npt;
     const int64_t mtiles = (Q + BM - 1) / BM, nblk = mtiles * (C / BN);
-    if (nblk > 256 * RS_KINDS[p.kind].per_cu) return false;                   // more than one round: the plain launches do better
+    // every workgroup of a chain launch has to be resident at once: one round of the CUs THIS device (or partition) really has
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    if (nblk > (int64_t)std::min(ncu, 256) * RS_KINDS[p.kind].per_cu) return false;     // more than one round: the plain launches do better (and a chain would starve)
     // More than four channel tiles per position tile: a tile then waits for 3 x 8 or more of a layer's ~90 tiles, which is a
     // grid-wide wait in all but name -- measured on the 512-channel 12x39 camera layers: 21.6 us per layer chained against 19.8
     // as separate launches (profiles/r05e_chain_time.txt); the other cfg2 stages are level or ahead.  Option CHAIN_WIDE=1 lifts it.

@@ -23,7 +23,10 @@ extern "C" const char *dcf_last_error(void) { return g_err; }
 // 101: dcf_fusion_gather_bwd_inv gained its workspace argument (round 3); the CONV_LC / KNN_TILE_WAVES options (round 4).
 // 102 (round 5): the four experimental dcf_conv3x3_*_wf entry points of 101 are GONE from the library (no caller outside
 // tools/; they live in tools/variants/ now) -- INTEGRATION.md, "Versions"
-extern "C" int dcf_version(void) { return 102; }
+// 200 (round 6): no prototype changed since 102, but 102 REMOVED symbols under a minor step; a binding that refuses on a major
+// mismatch would have bound them at load and failed with "undefined symbol" instead.  The major moves now, and the policy is
+// written down ("Versions"): removing or changing an exported symbol = new major; adding = new minor.
+extern "C" int dcf_version(void) { return 200; }
 
 // ------------------------------------------------------------------ tuning options (dcf_common.h)
 std::atomic<int> g_dcf_opt_epoch{0};

@@ -360,8 +360,6 @@ class LossTotal(nn.Module):
             of = len(floats)
             floats += row_w + boxes_host[b, :nb, :7].reshape(-1).tolist()
             plan.append((o, len(pos), len(neg), len(rows), of, nb))
-        if dev.type == "cuda":
-            return self._forward_hip(cls, reg, anc, ints, floats, plan, B, H, W)
         di, df = self._stage(ints, floats, dev)
         # ---- device: gathers + CE + Smooth-L1, vectorised per sample
         total = torch.zeros(1, device=dev)
