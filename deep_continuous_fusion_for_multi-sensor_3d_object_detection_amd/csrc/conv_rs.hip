@@ -28,7 +28,10 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
     const dim3 grid((unsigned)nwg);
     char name[96];
     static DcfOpt pfn_o("RS_PF"); const char *pfn = pfn_o.str();
-    const bool pf_name = p.kind != 2 && ((pfn && atoi(pfn) == 2) || (!(pfn && atoi(pfn) == 0) && Ck >= 128));       // (= `pf` below: the profile name says which loop ran)
+    static DcfOpt pfn2_o("RS_PF2"), pfl_o("RS_L16"), pfs_o("RS_S3");
+    const bool small_pf = p.kind == 2 && !(pfn && atoi(pfn) == 0) && !(pfn2_o.str() && atoi(pfn2_o.str()) == 0) && !(pfl_o.str() && atoi(pfl_o.str()) == 0) &&
+                          !(pfs_o.str() && atoi(pfs_o.str()) == 0);
+    const bool pf_name = small_pf || (p.kind != 2 && ((pfn && atoi(pfn) == 2) || (!(pfn && atoi(pfn) == 0) && Ck >= 128)));       // (= the loop chosen below: the profile name says which one ran)
     snprintf(name, sizeof(name), pf_name ? "%s<rs%d,%d,pf>" : "%s<rs%d,%d>", name_base, p.kind, p.npt);
     const double bytes = (double)a.xbytes + (double)a.wbytes + (double)B * H * W * Cn * 2.0 * (1 + (res ? 1 : 0) + (mask ? 1 : 0));
     static DcfOpt s3e_o("RS_S3"); const char *s3e = s3e_o.str();
@@ -49,6 +52,9 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
     // (Ck = 64: three stages of HBM-bound taps -- the earlier synchronisation point of the rotated loop leaves the DMA a quarter tap less
     // to land: 64 -> 64 @352x400 33.3 -> 37.7 us; those layers keep the plain loop.  RS_PF=2 forces the rotated loop everywhere.)
     const bool pf = (pfe && atoi(pfe) == 2) || (!(pfe && atoi(pfe) == 0) && Ck >= 128);
+    // the small-M kind's consumers on the rotated loop (stage-granular): RS_PF2 (default on with RS_PF)
+    static DcfOpt pf2_o("RS_PF2"); const char *pf2e = pf2_o.str();
+    const bool pf2 = p.kind == 2 && !(pfe && atoi(pfe) == 0) && !(pf2e && atoi(pf2e) == 0);
 #define DCF_RS(T_)                                                                                                               \
     do {                                                                                                                         \
         if (p.kind == 0 && pf) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 5, 4, 2, 2, 1, false, false, 0, true>), grid, dim3(512), 0, s, a)); \
@@ -58,6 +64,7 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
         else if (dx2) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 2, 2, 4, 2, 2>), grid, dim3(512), 0, s, a)); \
         else if (p.kind == 1) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 3, 2, 4, 2, 1>), grid, dim3(512), 0, s, a)); \
         else if (!s3) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 5, 2>), grid, dim3(512), 0, s, a)); \
+        else if (l16 && pf2) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 6, 2, true, false, 8, true>), grid, dim3(1024), 0, s, a)); \
         else if (l16) DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 6, 2, true, false, 8>), grid, dim3(1024), 0, s, a)); \
         else DCF_LAUNCH_WB(name, flops, bytes, s, hipLaunchKernelGGL((k_conv3x3_rs<T_, 1, 1, 2, 4, 6, 2, true>), grid, dim3(512), 0, s, a)); \
     } while (0)

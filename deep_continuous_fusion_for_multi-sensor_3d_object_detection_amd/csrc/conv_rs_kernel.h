@@ -239,7 +239,8 @@ template <typename T, int TN, int TMMAX, int WN, int WM, int DW, int DX, bool S3
 __global__ void __launch_bounds__((WN * WM + NL) * 64) k_conv3x3_rs(typename std::conditional<CHAIN, RsChainArgs, RsArgs>::type arg)
 {
     constexpr bool L16 = NL > 0;
-    static_assert(!PF || (!S3 && !CHAIN), "the rotated loop: per-tap synchronisation, single layer");
+    static_assert(!PF || !CHAIN, "the rotated loop: single-layer launches");
+    static_assert(!(PF && S3) || NL > 0, "the rotated loop with stage-granular synchronisation: the consumer + loader form only");
     static_assert(!(L16 && CHAIN) && (NL == 0 || NL == 4 || NL == 8), "loader waves: none, four or eight; no chain mode with them");
     const RsArgs &a = rs_common(arg);
     static_assert(DT<T>::size == 2, "16-bit element types only");
@@ -691,6 +692,20 @@ __global__ void __launch_bounds__((WN * WM + NL) * 64) k_conv3x3_rs(typename std
                     for (int i = 0; i < TN; ++i) Mma<T>::run(fa[i], fb[j], acc[i][j]);
             };
             auto wait_tap = [&](int kj, int t) __attribute__((always_inline)) {          // the synchronisation in front of tap t
+                if constexpr (S3) {                        // stage-granular form: one wait + barrier in front of a stage's first tap
+                    if (kj != 0) return;
+                    const int sn = t / 3;
+                    if (sn < DX && stores_pending) wait_vmcnt<AS + ST>(); else wait_vmcnt<AS>();
+                    wait_lgkm0();
+#ifdef RS_WSTAMP
+                    if (ws_tile == 0 && sn < 64) RS_WS(ws_arr, sn);
+#endif
+                    __builtin_amdgcn_s_barrier();
+#ifdef RS_WSTAMP
+                    if (ws_tile == 0 && sn < 64) RS_WS(ws_rel, sn);
+#endif
+                    return;
+                }
                 const bool early = stores_pending && t < (kj == 0 ? BK0 : DW);
                 if (kj == 0) { if (early) wait_vmcnt<A0 + ST>(); else wait_vmcnt<A0>(); }
                 else if (kj == 1) { if (early) wait_vmcnt<A1 + ST>(); else wait_vmcnt<A1>(); }
@@ -728,6 +743,13 @@ __global__ void __launch_bounds__((WN * WM + NL) * 64) k_conv3x3_rs(typename std
                     }
             };
             auto issue_group = [&](int kj) __attribute__((always_inline)) {               // a wave without tiles: the whole group at once
+                if constexpr (S3) {                        // the stage's group, behind the stage's barrier
+                    if (kj != 0) return;
+                    issue_x(DX, xsi, 0, CX);
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) issue_w(DX, kw, wsi + kw);
+                    return;
+                }
                 issue_w((kj + DW) / 3, (kj + DW) % 3, wsi);
                 if (kj == 0) issue_x(DX, xsi, 0, PXA);
                 if (kj == 1) issue_x(DX, xsi, PXA, CX);

@@ -261,8 +261,8 @@ def test_profile_names_map_to_kernels_of_the_committed_pmc_summary():
     nargs = max((len(a) for f, a in have if f == "k_conv3x3_rs"), default=11)
     pf_seen = any(f == "k_conv3x3_rs" and len(a) == 11 and a[10] == "true" for f, a in have)
     for name in names:
-        if pf_seen and name in ("conv_fwd_bf16<rs0,9>", "conv_fwd_bf16<rs1,7>"):
-            name = name[:-1] + ",pf>"                  # the 128- / 192-channel layers of a cfg2 step run the rotated loop
+        if pf_seen and name in ("conv_fwd_bf16<rs0,9>", "conv_fwd_bf16<rs1,7>", "conv_fwd_bf16<rs2,5>"):
+            name = name[:-1] + ",pf>"                  # the 128+ channel layers and the small-M kind of a cfg2 step run the rotated loop
         func, args = bench.rocprof_kernel(name)
         if func == "k_conv3x3_rs":
             args = args[:nargs]
@@ -272,6 +272,7 @@ def test_profile_names_map_to_kernels_of_the_committed_pmc_summary():
         assert (func, tuple(args)) in have, (name, func, args)
     assert bench.rocprof_kernel("conv_dgrad_bf16<rs2,4,x21>") == ("k_conv3x3_rs", ["unsignedshort", "1", "1", "2", "4", "6", "2", "true", "true", "0", "false"])
     assert bench.rocprof_kernel("conv_fwd_bf16<rs2,3>") == ("k_conv3x3_rs", ["unsignedshort", "1", "1", "2", "4", "6", "2", "true", "false", "8", "false"])
+    assert bench.rocprof_kernel("conv_fwd_bf16<rs2,3,pf>") == ("k_conv3x3_rs", ["unsignedshort", "1", "1", "2", "4", "6", "2", "true", "false", "8", "true"])
     assert bench.rocprof_kernel("conv_fwd_bf16<rs1,7,pf>") == ("k_conv3x3_rs", ["unsignedshort", "1", "2", "2", "4", "2", "2", "false", "false", "0", "true"])
     assert bench.rocprof_kernel("conv_dgrad_bf16<rs0,9,pf>") == ("k_conv3x3_rs", ["unsignedshort", "1", "5", "4", "2", "2", "1", "false", "false", "0", "true"])
 
