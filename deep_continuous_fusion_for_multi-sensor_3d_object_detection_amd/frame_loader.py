@@ -42,7 +42,8 @@ def collate_raw(samples):
 
 class Batch(dict):
     """dict of tensors + the copy-stream event guarding them.  The device tensors are views of the loader's staging set:
-    they stay valid until the loader has handed out the batch after the next one."""
+    they stay valid until the consumer comes back for the NEXT batch (threaded staging: the set then returns to the worker behind
+    an event on the consumer's stream; inline staging: until the batch after the next one)."""
     event = None
 
     def wait(self, stream=None):
@@ -218,6 +219,8 @@ class FrameLoader(object):
                 torch.cuda.set_device(dev)
                 have = False
                 for host in self.loader:
+                    if stop.is_set():
+                        return
                     if not have:
                         self._ensure_sets(host, self.NSETS)
                         for i in range(self.NSETS):
@@ -259,10 +262,27 @@ class FrameLoader(object):
         finally:
             stop.set()
             th.join(timeout=5.0)
+            if th.is_alive():
+                # (a reader that takes longer than this: the worker may still touch the sets -- a new iteration has to wait for it)
+                self._straggler = th
+            # An iteration that ends early (train.evaluate() breaks at max_batches) leaves batches staged but never handed over, and
+            # the last one handed over without its `consumed` event: the next iteration's copy stream must not overwrite a device twin
+            # the previous consumer's kernels may still read.  One event on the consumer's stream, now, covers everything it enqueued.
+            if self._sets:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                for st in self._sets:
+                    st.consumed = ev
 
     def __iter__(self):
         if self.device is not None and getattr(self, "_active", False):
             raise RuntimeError("FrameLoader: one iteration at a time (the staging sets belong to the running one; close it or finish it first)")
+        old = getattr(self, "_straggler", None)
+        if old is not None:
+            old.join(timeout=60.0)
+            if old.is_alive():
+                raise RuntimeError("FrameLoader: the previous iteration's staging thread is still inside the dataset reader; its staging sets cannot be reused yet")
+            self._straggler = None
         if self.device is None:
             for host in self.loader:
                 host["image"] = torch.stack(host["image"], 0)

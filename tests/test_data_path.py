@@ -245,7 +245,7 @@ class _RawFrames(torch.utils.data.Dataset):
 
 @pytest.mark.gpu
 def test_frame_loader_background_staging_equals_inline_staging():
-    """The staging thread (three sets, two-deep hand-off) delivers the same device batches, in order, as staging on the calling
+    """The staging thread (six staging sets, four batches of look-ahead) delivers the same device batches, in order, as staging on the calling
     thread -- also when a later frame is larger than the sets sized from the first one, and with work enqueued on the consumer's
     stream between batches (the `consumed` event is what keeps the copy stream off buffers that are still being read)."""
     FL = pkg("frame_loader")
