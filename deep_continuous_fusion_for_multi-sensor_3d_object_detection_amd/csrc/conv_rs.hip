@@ -31,7 +31,8 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
     static DcfOpt pfn2_o("RS_PF2"), pfl_o("RS_L16"), pfs_o("RS_S3");
     const bool small_pf = p.kind == 2 && !(pfn && atoi(pfn) == 0) && !(pfn2_o.str() && atoi(pfn2_o.str()) == 0) && !(pfl_o.str() && atoi(pfl_o.str()) == 0) &&
                           !(pfs_o.str() && atoi(pfs_o.str()) == 0);
-    const bool pf_name = small_pf || (p.kind != 2 && ((pfn && atoi(pfn) == 2) || (!(pfn && atoi(pfn) == 0) && Ck >= 128)));       // (= the loop chosen below: the profile name says which one ran)
+    const bool one_round_n = (Q + 32 * p.npt - 1) / (32 * p.npt) * (Cn / RS_KINDS[p.kind].BN) <= 256 * RS_KINDS[p.kind].per_cu;
+    const bool pf_name = small_pf || (p.kind != 2 && ((pfn && atoi(pfn) == 2) || (!(pfn && atoi(pfn) == 0) && (Ck >= 128 || one_round_n))));       // (= the loop chosen below: the profile name says which one ran)
     snprintf(name, sizeof(name), pf_name ? "%s<rs%d,%d,pf>" : "%s<rs%d,%d>", name_base, p.kind, p.npt);
     const double bytes = (double)a.xbytes + (double)a.wbytes + (double)B * H * W * Cn * 2.0 * (1 + (res ? 1 : 0) + (mask ? 1 : 0));
     static DcfOpt s3e_o("RS_S3"); const char *s3e = s3e_o.str();
@@ -51,7 +52,10 @@ int dcf_conv3x3_rs_launch(int dtype, const void *x, const void *w, const float *
     static DcfOpt pf_o("RS_PF"); const char *pfe = pf_o.str();
     // (Ck = 64: three stages of HBM-bound taps -- the earlier synchronisation point of the rotated loop leaves the DMA a quarter tap less
     // to land: 64 -> 64 @352x400 33.3 -> 37.7 us; those layers keep the plain loop.  RS_PF=2 forces the rotated loop everywhere.)
-    const bool pf = (pfe && atoi(pfe) == 2) || (!(pfe && atoi(pfe) == 0) && Ck >= 128);
+    // A 64-channel launch of a single round of workgroups (the camera trunk's layer 1: 94x311) is latency-shaped like the wide ones
+    // and takes the rotated loop too: 11.5 -> 10.5 us.
+    const bool one_round = (int64_t)a.mtiles * (Cn / RS_KINDS[p.kind].BN) <= 256 * RS_KINDS[p.kind].per_cu;
+    const bool pf = (pfe && atoi(pfe) == 2) || (!(pfe && atoi(pfe) == 0) && (Ck >= 128 || one_round));
     // the small-M kind's consumers on the rotated loop (stage-granular): RS_PF2 (default on with RS_PF)
     static DcfOpt pf2_o("RS_PF2"); const char *pf2e = pf2_o.str();
     const bool pf2 = p.kind == 2 && !(pfe && atoi(pfe) == 0) && !(pf2e && atoi(pf2e) == 0);

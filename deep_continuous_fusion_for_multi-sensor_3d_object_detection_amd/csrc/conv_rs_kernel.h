@@ -743,6 +743,9 @@ __global__ void __launch_bounds__((WN * WM + NL) * 64) k_conv3x3_rs(typename std
                     }
             };
             auto issue_group = [&](int kj) __attribute__((always_inline)) {               // a wave without tiles: the whole group at once
+#if defined(RS_ABL) && (RS_ABL & 1)
+                return;
+#endif
                 if constexpr (S3) {                        // the stage's group, behind the stage's barrier
                     if (kj != 0) return;
                     issue_x(DX, xsi, 0, CX);
