@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--opt", default="RS_PF")
+    ap.add_argument("--values", default="0,1", help="the two option values to compare")
     ap.add_argument("names", nargs="*")
     args = ap.parse_args()
     B = args.batch
@@ -31,13 +32,14 @@ def main():
         mask = (torch.rand((B, Hh, W, Ci), device="cuda") - 0.3).bfloat16()
         fl = 2.0 * B * Hh * W * Co * Ci * 9
         out = {}
-        for v in (0, 1):
+        va, vb = [int(t) for t in args.values.split(",")]
+        for key, v in ((0, va), (1, vb)):
             H.set_option(args.opt, v)
             yf = ops.conv2d_fwd(1, x, w, None, None, 3, 3, 1, 1, True, Co)
             yd = ops.conv2d_dgrad(1, gy, wt, res, (B, Hh, W, Ci), 3, 3, 1, 1, mask=mask)
             tf = timeit(lambda: ops.conv2d_fwd(1, x, w, None, None, 3, 3, 1, 1, True, Co), iters=30)
             td = timeit(lambda: ops.conv2d_dgrad(1, gy, wt, res, (B, Hh, W, Ci), 3, 3, 1, 1, mask=mask), iters=30)
-            out[v] = (yf.clone(), yd.clone(), tf, td)
+            out[key] = (yf.clone(), yd.clone(), tf, td)
         H.set_option(args.opt, None)
         same = torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
         tot[0] += (out[0][2] + out[0][3]) * cnt; tot[1] += (out[1][2] + out[1][3]) * cnt
