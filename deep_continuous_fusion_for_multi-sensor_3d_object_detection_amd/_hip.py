@@ -102,6 +102,7 @@ SIGNATURES = {
     "dcf_fusion_gather_bwd_inv": (c_int, [c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P, P, c_int, P, P, P, P, P, P]),
     "dcf_rowscale_bias_fwd": (c_int, [c_int, P, P, P, c_i64, c_int, P]),
     "dcf_rowscale_bias_bwd": (c_int, [c_int, P, P, P, c_i64, c_int, P]),
+    "dcf_relu_mask_rowscale_bwd": (c_int, [c_int, P, P, P, P, P, c_i64, c_int, P]),
     "dcf_cast": (c_int, [c_int, P, c_int, P, c_i64, P]),
     "dcf_loss_fwd_bwd": (c_int, [P, c_i64, P, c_i64, P, P, P, c_int, c_int, c_float, c_int, P, P, c_i64, P, c_i64, P]),
     "dcf_loss_sample_rand": (ctypes.c_uint32, [ctypes.c_uint64, c_int, c_int, c_int, c_int]),

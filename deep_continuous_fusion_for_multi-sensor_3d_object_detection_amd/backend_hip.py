@@ -697,5 +697,9 @@ class HipBackend(object):
     def rowscale_bias_fwd(self, y, cnt, b2_off):
         return ops.rowscale_bias_fwd(self.dtype, y, cnt, self.params[b2_off:])
 
+    def relu_mask_rowscale_bwd(self, gy, y, cnt, b2_off):
+        """At a fusion site: the masked gradient for the stage's last block (a new tensor) + fc2's bias gradient, one pass."""
+        return ops.relu_mask_rowscale_bwd(self.dtype, gy, y, cnt, self._gbase + 4 * b2_off)
+
     def rowscale_bias_bwd(self, gy, cnt, b2_off):
         ops.rowscale_bias_bwd(self.dtype, gy, cnt, self._gbase + 4 * b2_off)

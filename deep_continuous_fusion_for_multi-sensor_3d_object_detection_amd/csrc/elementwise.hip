@@ -933,6 +933,64 @@ __global__ void __launch_bounds__(256) k_rowscale_bias_bwd(const T *gy, const fl
     for (int i = threadIdx.x; i < cgroups * V; i += blockDim.x) atomicAdd(&gb2[i], sm[i]);
 }
 
+// At a fusion site (/root/reference/model.py:199-203 is the TODO) the gradient of the site's output feeds the
+// fusion branch unmasked (fc2's bias gradient is its cnt-weighted channel sum) and the stage's last block masked by that block's
+// ReLU.  One pass instead of two (k_rowscale_bias_bwd, then k_relu_bwd_chansum in place): reads gy, y and cnt, writes the masked
+// gradient to its OWN tensor (the fusion backward still reads gy), accumulates gb2[c] += sum_p cnt[p] * gy[p][c].
+template <typename T, int V>
+__global__ void __launch_bounds__(256) k_relu_mask_rowscale_bwd(const T *__restrict__ gy, const T *__restrict__ y, const float *__restrict__ cnt,
+                                                                T *__restrict__ gout, float *gb2, int64_t nvec, int cgroups, int64_t stride)
+{
+    extern __shared__ float sm[];
+    for (int i = threadIdx.x; i < cgroups * V; i += blockDim.x) sm[i] = 0.f;
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < stride) {
+        const int cg = (int)(t % cgroups);
+        float acc[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) acc[q] = 0.f;
+        int64_t p = t / cgroups;                          // pixel of element e; stride is a multiple of cgroups
+        const int64_t pstep = stride / cgroups;
+        int64_t e = t;
+        for (; e + stride < nvec; e += 2 * stride, p += 2 * pstep) {
+            float g[2][V], yy[2][V], k[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                ldv<V>(gy + (e + u * stride) * V, g[u]);
+                ldv<V>(y + (e + u * stride) * V, yy[u]);
+                k[u] = cnt[p + u * pstep];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float m[V];
+#pragma unroll
+                for (int q = 0; q < V; ++q) {
+                    acc[q] += k[u] * g[u][q];
+                    m[q] = yy[u][q] > 0.f ? g[u][q] : 0.f;
+                }
+                stv<V>(gout + (e + u * stride) * V, m);
+            }
+        }
+        for (; e < nvec; e += stride, p += pstep) {
+            float g[V], yy[V], m[V];
+            ldv<V>(gy + e * V, g);
+            ldv<V>(y + e * V, yy);
+            const float k = cnt[p];
+#pragma unroll
+            for (int q = 0; q < V; ++q) {
+                acc[q] += k * g[q];
+                m[q] = yy[q] > 0.f ? g[q] : 0.f;
+            }
+            stv<V>(gout + e * V, m);
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) atomicAdd(&sm[cg * V + q], acc[q]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cgroups * V; i += blockDim.x) atomicAdd(&gb2[i], sm[i]);
+}
+
 // ------------------------------------------------------------------------------------
 // Train-mode BatchNorm2d (model.py:20,24,29 when the module is in .train(): batch statistics).
 //   stats : per-channel sum / sum-of-squares partials per workgroup, finalised in double
@@ -1350,6 +1408,25 @@ extern "C" int dcf_rowscale_bias_bwd(int dtype, const void *gy, const float *cnt
         const double bytes = (double)npix * C * sizeof(T) + npix * 4.0;
         if (V == 8) DCF_LAUNCH_B("rowscale_bias_bwd", bytes, s, hipLaunchKernelGGL((k_rowscale_bias_bwd<T, 8>), dim3(blocks), dim3(256), sizeof(float) * C, s, (const T *)gy, cnt, gb2, nvec, cg, stride));
         else DCF_LAUNCH_B("rowscale_bias_bwd", bytes, s, hipLaunchKernelGGL((k_rowscale_bias_bwd<T, 4>), dim3(blocks), dim3(256), sizeof(float) * C, s, (const T *)gy, cnt, gb2, nvec, cg, stride));
+    })
+    return DCF_OK;
+}
+
+extern "C" int dcf_relu_mask_rowscale_bwd(int dtype, const void *gy, const void *y, const float *cnt, void *gout, float *gb2, int64_t npix,
+                                          int C, dcf_stream_t stream)
+{
+    DCF_REQUIRE(gy && y && cnt && gout && gb2 && gout != gy && C % 4 == 0, "dcf_relu_mask_rowscale_bwd: bad arguments (gout must be its own tensor)");
+    const int V = C % 8 == 0 ? 8 : 4;
+    const int cg = C / V;
+    const int64_t nvec = npix * cg;
+    if (nvec == 0) return DCF_OK;
+    int blocks;
+    const int64_t stride = chan_stride(nvec, cg, blocks);
+    hipStream_t s = S(stream);
+    DCF_DISPATCH_DTYPE(dtype, {
+        const double bytes = (double)npix * C * sizeof(T) * 3 + npix * 4.0;
+        if (V == 8) DCF_LAUNCH_B("relu_mask_rowscale_bwd", bytes, s, hipLaunchKernelGGL((k_relu_mask_rowscale_bwd<T, 8>), dim3(blocks), dim3(256), sizeof(float) * C, s, (const T *)gy, (const T *)y, cnt, (T *)gout, gb2, nvec, cg, stride));
+        else DCF_LAUNCH_B("relu_mask_rowscale_bwd", bytes, s, hipLaunchKernelGGL((k_relu_mask_rowscale_bwd<T, 4>), dim3(blocks), dim3(256), sizeof(float) * C, s, (const T *)gy, (const T *)y, cnt, (T *)gout, gb2, nvec, cg, stride));
     })
     return DCF_OK;
 }

@@ -26,7 +26,8 @@ extern "C" const char *dcf_last_error(void) { return g_err; }
 // 200 (round 6): no prototype changed since 102, but 102 REMOVED symbols under a minor step; a binding that refuses on a major
 // mismatch would have bound them at load and failed with "undefined symbol" instead.  The major moves now, and the policy is
 // written down ("Versions"): removing or changing an exported symbol = new major; adding = new minor.
-extern "C" int dcf_version(void) { return 200; }
+// 201: + dcf_relu_mask_rowscale_bwd
+extern "C" int dcf_version(void) { return 201; }
 
 // ------------------------------------------------------------------ tuning options (dcf_common.h)
 std::atomic<int> g_dcf_opt_epoch{0};

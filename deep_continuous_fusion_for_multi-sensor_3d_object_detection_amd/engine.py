@@ -25,6 +25,8 @@ import torch
 
 # experiments (read once per process): "0" = no inverse KNN maps at all, "2" = build them but run the pixel-run backward
 FUSION_INV = os.environ.get("DCF_FUSION_INV", "1")
+# fusion sites: fc2's bias gradient and the ReLU mask of the stage's last block in one pass (0 = the two passes of rounds 1-5)
+FUSED_SITE_MASK = os.environ.get("DCF_FUSED_SITE_MASK", "1") != "0"
 # "0" = the 1x1 / stride-2 shortcut's input gradient as a full-resolution tensor again (A/B runs; same values)
 HALFRES_SHORTCUT = os.environ.get("DCF_HALFRES_SHORTCUT", "1") != "0"
 
@@ -588,7 +590,16 @@ class Plan(object):
         masked = False
         for si in range(4, -1, -1):
             if si >= 1 and c["fused"]:
-                gF = self._fusion_backward(K, self.fusion[si - 1], g, si - 1, gF)
+                last = self.stages[si][-1]
+                if FUSED_SITE_MASK and type(last) is Block and last.saved is not None and hasattr(K, "relu_mask_rowscale_bwd"):
+                    # one pass over the site's gradient: fc2's bias gradient (cnt-weighted channel sums of the UNMASKED g) and the
+                    # masked copy the stage's last block goes on with (round 6: was rowscale_bias_bwd here + relu_mask in place there)
+                    f = self.fusion[si - 1]
+                    gm = K.relu_mask_rowscale_bwd(g, last.saved[2], c["fuse%d" % (si - 1)]["cnt"], f["b2_off"])
+                    gF = self._fusion_backward(K, f, g, si - 1, gF, bias_done=True)
+                    g, masked = gm, True
+                else:
+                    gF = self._fusion_backward(K, self.fusion[si - 1], g, si - 1, gF)
             # the block feeding this stage's first one: the previous stage's last block when no fusion site sits in between
             # (the fusion backward needs the unmasked gradient)
             prev0 = self.stages[si - 1][-1] if (si > 0 and not (c["fused"] and si - 1 >= 1)) else None
@@ -693,12 +704,15 @@ class Plan(object):
             geom["n_rows"] = n
         return n
 
-    def _fusion_backward(self, K, f, g, site, gF):
+    def _fusion_backward(self, K, f, g, site, gF, bias_done=False):
         s = self.ctx.pop("fuse%d" % site)
         geom = s["geom"]
         B, n_max, cb = s["P"].shape
-        K.rowscale_bias_bwd(g, s["cnt"], f["b2_off"])
-        K.conv_wgrad(f["fc2"], s["hsum"], g, defer=False)      # g is masked in place by the stage's last block afterwards
+        if not bias_done:
+            K.rowscale_bias_bwd(g, s["cnt"], f["b2_off"])
+        # (two-pass form: g is masked in place by the stage's last block afterwards, so fc2's weight gradient cannot wait for the
+        # grouped launch; one-pass form: g stays as it is and the layer joins the group)
+        K.conv_wgrad(f["fc2"], s["hsum"], g, defer=bias_done)
         ghsum = K.conv_dgrad(f["fc2"], g, tuple(s["hsum"].shape), None)
         inv = geom.get("inv") if FUSION_INV != "2" else None
         if inv and geom.get("inv_event") is not None and not geom.get("_inv_waited"):

@@ -631,6 +631,14 @@ def rowscale_bias_bwd(dtype, gy, cnt, gb2):
     H.call("dcf_rowscale_bias_bwd", dtype, gy, cnt, gb2, gy.numel() // C, C, H.stream_ptr())
 
 
+def relu_mask_rowscale_bwd(dtype, gy, y, cnt, gb2):
+    """gout = gy * (y > 0) as a NEW tensor; gb2[c] += sum_p cnt[p] * gy[p][c] (one pass over gy: dcf_relu_mask_rowscale_bwd)."""
+    C = gy.shape[-1]
+    gout = torch.empty_like(gy)
+    H.call("dcf_relu_mask_rowscale_bwd", dtype, _chk(gy, "gy"), _chk(y, "y"), cnt, gout, gb2, gy.numel() // C, C, H.stream_ptr())
+    return gout
+
+
 def fusion_gather_bwd_pts(dtype, P, xyz, inv, n_max, g, khw, stride, aff, w1d, b1, ghsum, gP, gw1d, gb1):
     """fusion_gather_bwd_inv with one writer per point row: gP [n_rows, Cb] in the compute dtype, fully written (no zero-fill
     before, no cast after).  Arguments as fusion_gather_bwd_inv."""

@@ -372,6 +372,11 @@ int dcf_fusion_gather_bwd(int dtype, const void *P, const float *xyz, const int3
 /* y[p][c] += cnt[p]*b2[c]  (the fc2 bias of the K-sum), and its gradient gb2[c] += sum_p cnt[p]*gy[p][c]. */
 int dcf_rowscale_bias_fwd(int dtype, void *y, const float *cnt, const float *b2, int64_t npix, int C, dcf_stream_t stream);
 int dcf_rowscale_bias_bwd(int dtype, const void *gy, const float *cnt, float *gb2, int64_t npix, int C, dcf_stream_t stream);
+/* (version 201) the same bias gradient and, in the same pass, the gradient that goes on into the stage's last block:
+ *     gout[p][c] = y[p][c] > 0 ? gy[p][c] : 0 ;  gb2[c] += sum_p cnt[p]*gy[p][c]   (gout is its own tensor: the fusion branch still
+ *     reads the unmasked gy).  Replaces dcf_rowscale_bias_bwd + the in-place dcf_relu_bwd_chansum at a fusion site. */
+int dcf_relu_mask_rowscale_bwd(int dtype, const void *gy, const void *y, const float *cnt, void *gout, float *gb2, int64_t npix, int C,
+                               dcf_stream_t stream);
 /* dtype <-> fp32 casts of whole buffers (gradient hand-offs of the fusion path). */
 int dcf_cast(int dtype_src, const void *src, int dtype_dst, void *dst, int64_t n, dcf_stream_t stream);
 

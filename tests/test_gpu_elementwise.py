@@ -79,6 +79,31 @@ def test_rowscale_bias_fwd_bwd(C, npix, dtype):
 
 
 @pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("C,npix", [(64, 70000), (36, 9001), (256, 17600), (128, 300), (192, 2 * 88 * 100)])
+def test_relu_mask_rowscale_bwd(C, npix, dtype):
+    """A fusion site's one-pass form (round 6): gout = g * (y > 0) in a tensor of its own, bit for bit what the in-place mask writes,
+    g itself untouched; db2[c] += sum_p cnt[p] * g[p, c] of the UNMASKED g, against fp64 sums (the two-pass form's bound)."""
+    ops = pkg("ops")
+    gen = torch.Generator().manual_seed(6)
+    cnt = torch.randint(0, 4, (npix,), generator=gen).float()
+    gy = q(rnd((npix, C), 44), dtype)
+    y = q(torch.relu(rnd((npix, C), 45)), dtype)                 # about half of the activations are exactly zero
+    gd = to_dev(gy.view(1, npix, 1, C).permute(0, 3, 1, 2), dtype).view(npix, C)
+    yd = to_dev(y.view(1, npix, 1, C).permute(0, 3, 1, 2), dtype).view(npix, C)
+    keep = gd.clone()
+    gb = torch.full((C,), 0.25, device="cuda")
+    gout = ops.relu_mask_rowscale_bwd(dtype, gd, yd, cnt.cuda(), gb)
+    assert gout.data_ptr() != gd.data_ptr() and torch.equal(gd, keep)
+    two_pass = keep.clone()
+    ops.relu_bwd_chansum(dtype, two_pass, yd, None, True)       # the in-place mask of the two-pass form
+    assert torch.equal(gout, two_pass)
+    assert torch.equal(gout.float().cpu(), torch.where(y > 0, gy, torch.zeros_like(gy)))
+    ref = (cnt[:, None].double() * gy.double()).sum(0) + 0.25
+    bound = 1e-5 * float((cnt[:, None].double() * gy.double().abs()).sum(0).max()) + 1e-6
+    assert float((gb.cpu().double() - ref).abs().max()) <= bound
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 2])
 @pytest.mark.parametrize("case", [((6, 4), (12, 8), True), ((12, 39), (24, 78), False), ((24, 78), (47, 156), False), ((5, 7), (5, 7), False),
                                   ((44, 50), (88, 100), True), ((5, 6), (23, 31), True), ((4, 5), (19, 26), False),      # x4-5: more matches than the register list holds
                                   ((20, 30), (9, 13), False), ((21, 17), (8, 6), True)])                                # downsampling
