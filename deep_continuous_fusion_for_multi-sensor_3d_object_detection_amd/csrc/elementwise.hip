@@ -941,28 +941,28 @@ template <typename T, int V>
 __global__ void __launch_bounds__(256) k_relu_mask_rowscale_bwd(const T *__restrict__ gy, const T *__restrict__ y, const float *__restrict__ cnt,
                                                                 T *__restrict__ gout, float *gb2, int64_t nvec, int cgroups, int64_t stride)
 {
-    extern __shared__ float sm[];
-    for (int i = threadIdx.x; i < cgroups * V; i += blockDim.x) sm[i] = 0.f;
-    __syncthreads();
+    // A latency-bound stream like k_rowscale_bias_bwd: 256 workgroups (the C same-address atomics per workgroup at the end stay
+    // cheap), so every thread keeps FOUR elements' loads in flight (8 x 16 B + 4 counts); the workgroup's channel sums are formed
+    // without atomics (every thread parks its V sums in LDS, one thread per channel adds its column in thread order).
+    extern __shared__ float sm[];  // [256][V]
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < stride) {
-        const int cg = (int)(t % cgroups);
-        float acc[V];
+    float acc[V];
 #pragma unroll
-        for (int q = 0; q < V; ++q) acc[q] = 0.f;
+    for (int q = 0; q < V; ++q) acc[q] = 0.f;
+    if (t < stride) {
         int64_t p = t / cgroups;                          // pixel of element e; stride is a multiple of cgroups
         const int64_t pstep = stride / cgroups;
         int64_t e = t;
-        for (; e + stride < nvec; e += 2 * stride, p += 2 * pstep) {
-            float g[2][V], yy[2][V], k[2];
+        for (; e + 3 * stride < nvec; e += 4 * stride, p += 4 * pstep) {
+            float g[4][V], yy[4][V], k[4];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 ldv<V>(gy + (e + u * stride) * V, g[u]);
                 ldv<V>(y + (e + u * stride) * V, yy[u]);
                 k[u] = cnt[p + u * pstep];
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 float m[V];
 #pragma unroll
                 for (int q = 0; q < V; ++q) {
@@ -984,11 +984,20 @@ __global__ void __launch_bounds__(256) k_relu_mask_rowscale_bwd(const T *__restr
             }
             stv<V>(gout + e * V, m);
         }
-#pragma unroll
-        for (int q = 0; q < V; ++q) atomicAdd(&sm[cg * V + q], acc[q]);
     }
+#pragma unroll
+    for (int q = 0; q < V; ++q) sm[threadIdx.x * V + q] = acc[q];
     __syncthreads();
-    for (int i = threadIdx.x; i < cgroups * V; i += blockDim.x) atomicAdd(&gb2[i], sm[i]);
+    // channel i = group j x lane q of it; the threads of this workgroup whose elements belong to group j: t % cgroups == j
+    for (int i = threadIdx.x; i < cgroups * V; i += blockDim.x) {
+        const int j = i / V, q = i - j * V;
+        const int base = (int)(((int64_t)blockIdx.x * blockDim.x) % cgroups);
+        int first = j - base;
+        if (first < 0) first += cgroups;
+        float sum = 0.f;
+        for (int th = first; th < (int)blockDim.x; th += cgroups) sum += sm[th * V + q];
+        atomicAdd(&gb2[i], sum);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1421,12 +1430,12 @@ extern "C" int dcf_relu_mask_rowscale_bwd(int dtype, const void *gy, const void 
     const int64_t nvec = npix * cg;
     if (nvec == 0) return DCF_OK;
     int blocks;
-    const int64_t stride = chan_stride(nvec, cg, blocks);
+    const int64_t stride = chan_stride(nvec, cg, blocks, 64);
     hipStream_t s = S(stream);
     DCF_DISPATCH_DTYPE(dtype, {
         const double bytes = (double)npix * C * sizeof(T) * 3 + npix * 4.0;
-        if (V == 8) DCF_LAUNCH_B("relu_mask_rowscale_bwd", bytes, s, hipLaunchKernelGGL((k_relu_mask_rowscale_bwd<T, 8>), dim3(blocks), dim3(256), sizeof(float) * C, s, (const T *)gy, (const T *)y, cnt, (T *)gout, gb2, nvec, cg, stride));
-        else DCF_LAUNCH_B("relu_mask_rowscale_bwd", bytes, s, hipLaunchKernelGGL((k_relu_mask_rowscale_bwd<T, 4>), dim3(blocks), dim3(256), sizeof(float) * C, s, (const T *)gy, (const T *)y, cnt, (T *)gout, gb2, nvec, cg, stride));
+        if (V == 8) DCF_LAUNCH_B("relu_mask_rowscale_bwd", bytes, s, hipLaunchKernelGGL((k_relu_mask_rowscale_bwd<T, 8>), dim3(blocks), dim3(256), sizeof(float) * 256 * 8, s, (const T *)gy, (const T *)y, cnt, (T *)gout, gb2, nvec, cg, stride));
+        else DCF_LAUNCH_B("relu_mask_rowscale_bwd", bytes, s, hipLaunchKernelGGL((k_relu_mask_rowscale_bwd<T, 4>), dim3(blocks), dim3(256), sizeof(float) * 256 * 4, s, (const T *)gy, (const T *)y, cnt, (T *)gout, gb2, nvec, cg, stride));
     })
     return DCF_OK;
 }
